@@ -1,0 +1,113 @@
+"""The CPU oracle against golden vectors produced by the reference's own Python
+(tools/make_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wasb_ref, refine_ref, uplift_ref, glue_ref
+from upliftingtabletennis_amd import arch, weights, synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_schemas_match_reference_state_dicts():
+    ref = json.load(open(os.path.join(GOLDEN, 'wasb_schema.json')))
+    assert [(k, tuple(s)) for k, s in ref] == [(k, tuple(s)) for k, s in arch.wasb_schema()]
+    ref = json.load(open(os.path.join(GOLDEN, 'uplift_schema.json')))
+    assert [(k, tuple(s)) for k, s in ref] == [(k, tuple(s)) for k, s in arch.uplift_schema('large')]
+    assert len(arch.hrnet_convs()) == 72
+
+
+def wasb_case_input(g, name):
+    seed, planted, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, planted=bool(planted))
+    if planted:
+        frames, _ = synth.synth_frames(b + 2, h, w, seed=seed)
+        x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (w, h)) for i in range(b)])
+    else:
+        x = np.random.default_rng(seed).standard_normal((b, 9, h, w)).astype(np.float32)
+    return sd, x
+
+
+@pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160', 'planted_96x160'])
+def test_wasb_oracle_matches_reference(golden, name):
+    g = golden('wasb_small.npz')
+    sd, x = wasb_case_input(g, name)
+    heat = wasb_ref.wasb_forward(x, sd).numpy()
+    ref = g[name + '/heat']
+    scale = np.abs(ref).max()
+    assert np.abs(heat - ref).max() <= 1e-5 * scale
+    assert np.array_equal(heat.reshape(heat.shape[0], -1).argmax(1), g[name + '/argmax'])
+    _, taps = wasb_ref.hrnet_features(torch.from_numpy(x), sd, return_taps=True)
+    for k, v in taps.items():
+        got = np.array([v.mean().item(), v.abs().mean().item(), v[0, 0, 1, 2].item(), v[-1, -1, -2, -3].item()])
+        np.testing.assert_allclose(got, g['%s/tap/%s' % (name, k)], rtol=1e-4, atol=1e-6)
+
+
+def test_refine_oracle_matches_reference(golden):
+    g = golden('refine.npz')
+    heat = g['heat']
+    np.testing.assert_allclose(refine_ref.extract_position_ball(heat, 1920, 1080), g['ball'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(refine_ref.extract_position_table(heat, 1920, 1080), g['table'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(refine_ref.extract_position_table(g['mc'], 1920, 1080), g['table_mc'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(refine_ref.extract_position_ball(g['toy'], 5, 5), g['toy_ball'], rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        refine_ref.extract_position_ball(np.zeros((4, 4), np.float32), 10, 10)
+    with pytest.raises(ValueError):
+        refine_ref.extract_position_table(np.zeros((2, 4, 4), np.float32), 10, 10)
+
+
+@pytest.mark.parametrize('name', ['large_T8', 'large_T50', 'large_T121', 'small_T20'])
+def test_uplift_oracle_matches_reference(golden, name):
+    g = golden('uplift.npz')
+    seed = int(g[name + '/meta'][0])
+    size = str(g[name + '/size'])
+    sd = weights.random_uplift_state_dict(seed, size)
+    rot, pos = uplift_ref.uplift_forward(g[name + '/ball'], g[name + '/table'], g[name + '/mask'], g[name + '/times'], sd,
+                                         heads=arch.UPLIFT_SIZES[size][2])
+    np.testing.assert_allclose(rot.numpy(), g[name + '/rot'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pos.numpy(), g[name + '/pos'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(uplift_ref.transform_rotationaxes(rot, pos).numpy(), g[name + '/rot_local'], rtol=1e-5, atol=1e-6)
+
+
+def test_uplift_oracle_rejects_all_ones_mask(golden):
+    assert bool(golden('uplift.npz')['allones_mask_raises'])
+    sd = weights.random_uplift_state_dict(1, 'small')
+    with pytest.raises(ValueError):
+        uplift_ref.uplift_forward(np.zeros((1, 4, 2)), np.zeros((1, 13, 3)), np.ones((1, 4)), np.zeros((1, 4)), sd)
+
+
+@pytest.mark.parametrize('name', ['short', 'mid', 'long'])
+def test_glue_oracle_matches_reference(golden, name):
+    g = golden('glue.npz')
+    pos, idx, times = glue_ref.filter_trajectory_ball(g[name + '/p1'], g[name + '/p2'], float(g[name + '/fps']))
+    np.testing.assert_array_equal(pos, g[name + '/pos'])
+    np.testing.assert_array_equal(idx, g[name + '/idx'])
+    np.testing.assert_array_equal(times, g[name + '/times'])
+    b, tb, tm, mk = glue_ref.uplifting_transform(pos, g[name + '/table'], times)
+    np.testing.assert_array_equal(b, g[name + '/u_ball'])
+    np.testing.assert_array_equal(tb, g[name + '/u_table'])
+    np.testing.assert_array_equal(tm, g[name + '/u_times'])
+    np.testing.assert_array_equal(mk, g[name + '/u_mask'])
+
+
+def test_normalise_oracle_matches_reference(golden):
+    g = golden('glue.npz')
+    np.testing.assert_array_equal(glue_ref.normalize_image(g['norm/img']), g['norm/out'])
+    np.testing.assert_array_equal(glue_ref.normalize_image(g['norm/img'][::-1]), g['norm/out_prev'])
+
+
+def test_resize_unpinned_self_consistency():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (72, 128, 3), dtype=np.uint8)
+    assert np.array_equal(glue_ref.resize_linear_u8(img, 128, 72), img)
+    const = np.full((72, 128, 3), 137, np.uint8)
+    assert np.array_equal(glue_ref.resize_linear_u8(const, 128, 64), np.full((64, 128, 3), 137, np.uint8))
+    out = glue_ref.resize_linear_u8(img, 96, 64)
+    assert out.shape == (64, 96, 3) and out.dtype == np.uint8
+    ramp = np.tile(np.arange(72, dtype=np.uint8)[:, None, None] * 3, (1, 16, 3))
+    r = glue_ref.resize_linear_u8(ramp, 16, 64).astype(int)
+    assert (np.diff(r[:, 0, 0]) >= 0).all()

@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (from /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).  Only tensors,
+seeds and shapes are written -- never reference source.  Inputs are regenerated in the tests
+from the same seeds through ``upliftingtabletennis_amd.synth`` / ``weights`` (numpy PCG64).
+
+Stubs needed to import the reference here: ``torch.utils.tensorboard`` (absent),
+``cv2`` (absent; only imported, never called on the paths used), ``torch.load`` patched while
+``WASBNet.__init__`` reads its initialisation checkpoint (wasb.py:580-582).
+
+    python tools/make_goldens.py            # writes tests/golden/
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('TTUP_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+def install_stubs():
+    import torch.utils
+    tb = types.ModuleType('torch.utils.tensorboard')
+
+    class SummaryWriter(object):
+        def __init__(self, *a, **k):
+            pass
+    tb.SummaryWriter = SummaryWriter
+    tbs = types.ModuleType('torch.utils.tensorboard.summary')
+    tbs.hparams = lambda *a, **k: None
+    tb.summary = tbs
+    torch.utils.tensorboard = tb
+    sys.modules['torch.utils.tensorboard'] = tb
+    sys.modules['torch.utils.tensorboard.summary'] = tbs
+    if 'cv2' not in sys.modules:
+        try:
+            import cv2  # noqa: F401
+        except Exception:
+            sys.modules['cv2'] = types.ModuleType('cv2')
+
+
+def ref_wasb(sd_np):
+    from balldetection.models.wasb import WASBNet
+    orig = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        m = WASBNet(in_frames=3, resolution=(1280, 704))
+    finally:
+        torch.load = orig
+    ref_sd = {k: v for k, v in m.state_dict().items() if 'num_batches_tracked' not in k}
+    schema = [(k, list(v.shape)) for k, v in ref_sd.items()]
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    assert not unexpected and all('num_batches_tracked' in k for k in missing), (missing, unexpected)
+    m.eval()
+    return m, schema
+
+
+def taps_summary(taps):
+    """Per-tap [mean, mean|x|, x[0,0,1,2], x[-1,-1,-2,-3]] -- cheap localisation of a divergence."""
+    return {k: np.array([v.mean().item(), v.abs().mean().item(), v[0, 0, 1, 2].item(), v[-1, -1, -2, -3].item()], np.float64)
+            for k, v in taps.items()}
+
+
+def gen_wasb():
+    from upliftingtabletennis_amd import weights, synth, arch
+    from oracle import wasb_ref, glue_ref
+    out = {}
+    cases = [('noise_64x96', 11, False, (1, 64, 96)), ('noise_96x160', 13, False, (2, 96, 160)), ('planted_96x160', 12, True, (2, 96, 160))]
+    schema = None
+    for name, seed, planted, (b, h, w) in cases:
+        sd = weights.random_wasb_state_dict(seed, planted=planted)
+        model, schema = ref_wasb(sd)
+        if planted:
+            frames, track = synth.synth_frames(b + 2, h, w, seed=seed)
+            x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (w, h)) for i in range(b)])
+            out[name + '/track'] = track
+        else:
+            x = np.random.default_rng(seed).standard_normal((b, 9, h, w)).astype(np.float32)
+        with torch.no_grad():
+            heat, _ = model(torch.from_numpy(x))
+            # hook-free taps: re-run the reference sub-modules in forward order
+            hr = model.model
+            t = {}
+            y = hr.relu(hr.bn1(hr.conv1(torch.from_numpy(x)))); t['stem1'] = y
+            y = hr.relu(hr.bn2(hr.conv2(y))); t['stem2'] = y
+            y = hr.layer1(y); t['layer1'] = y
+            xs = [hr.transition1[0](y), hr.transition1[1](y)]; t['trans1_0'], t['trans1_1'] = xs
+            ys = hr.stage2(xs); t['stage2_0'], t['stage2_1'] = ys
+            xs = [ys[0], ys[1], hr.transition2[2](ys[-1])]
+            ys = hr.stage3(xs); t['stage3_0'], t['stage3_1'], t['stage3_2'] = ys
+            xs = [ys[0], ys[1], ys[2], hr.transition3[3](ys[-1])]
+            ys = hr.stage4(xs)
+            for i, v in enumerate(ys):
+                t['stage4_%d' % i] = v
+        heat = heat.numpy()
+        out[name + '/heat'] = heat
+        out[name + '/argmax'] = heat.reshape(b, -1).argmax(1).astype(np.int64)
+        for k, v in taps_summary(t).items():
+            out['%s/tap/%s' % (name, k)] = v
+        out[name + '/meta'] = np.array([seed, int(planted), b, h, w], np.int64)
+        # sanity: our oracle restatement agrees right here
+        o = wasb_ref.wasb_forward(x, sd).numpy()
+        print('wasb %-16s max|ref-oracle| = %.3e  heat range [%.3f, %.3f]' % (name, np.abs(o - heat).max(), heat.min(), heat.max()))
+    np.savez_compressed(os.path.join(OUT, 'wasb_small.npz'), **out)
+    with open(os.path.join(OUT, 'wasb_schema.json'), 'w') as f:
+        json.dump(schema, f)
+    assert [(k, tuple(s)) for k, s in schema] == [(k, tuple(s)) for k, s in arch.wasb_schema()], 'schema mismatch'
+
+
+def refine_cases():
+    """Heatmaps (N,1,H,W) covering interior / border / corner peaks, ties, flat, negative, saturated."""
+    rng = np.random.default_rng(5)
+    hs = []
+    H, W = 12, 14
+
+    def blob(cx, cy, sx, sy, amp=1.0, base=0.0, noise=0.0):
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+        h = base + amp * np.exp(-((xx - cx) ** 2 / (2 * sx ** 2) + (yy - cy) ** 2 / (2 * sy ** 2)))
+        return (h + noise * rng.standard_normal((H, W))).astype(np.float32)
+    for _ in range(24):   # interior, various widths and amplitudes
+        hs.append(blob(rng.uniform(2, W - 3), rng.uniform(2, H - 3), rng.uniform(0.4, 3.0), rng.uniform(0.4, 3.0),
+                       amp=rng.uniform(0.3, 1.5), noise=0.01))
+    for cx, cy in [(0.2, 5.3), (W - 1.1, 4.6), (6.4, 0.1), (7.7, H - 1.2), (0.3, 0.2), (W - 1.2, H - 1.3), (0.0, H - 1.0), (W - 1.0, 0.0)]:
+        hs.append(blob(cx, cy, 1.2, 0.9))                      # border / corner peaks (zero padding in the window)
+    hs.append(np.zeros((H, W), np.float32))                    # flat zero -> index 0
+    hs.append(np.full((H, W), 0.7, np.float32))                # flat non-zero
+    hs.append(blob(5.5, 5.5, 1.0, 1.0))                        # 4-way tie candidate
+    hs.append(blob(4.0, 6.0, 0.3, 0.3))                        # narrower than the lower sigma bound
+    hs.append(blob(4.0, 6.0, 30.0, 30.0))                      # very wide -> sigma upper bound (table variant)
+    hs.append(blob(8.0, 3.0, 1.0, 1.0, amp=6.0))               # saturated (> 1)
+    hs.append(blob(8.0, 3.0, 1.0, 1.0, amp=1.0, base=-3.0))    # everything negative
+    hs.append(blob(3.3, 7.6, 2.0, 0.6, amp=0.05))              # weak peak below the table threshold
+    t = np.zeros((H, W), np.float32); t[4, 5] = 1.0; t[9, 2] = 1.0
+    hs.append(t)                                               # exact tie -> first index
+    for _ in range(8):
+        hs.append(rng.standard_normal((H, W)).astype(np.float32))   # noise-like (random-weights regime)
+    # the reference's own toy case (helper_balldetection.py:535-541): 5x5 maps are padded into HxW here
+    a = np.zeros((H, W), np.float32); a[2, 2] = 1.0; a[2, 3] = 1.0
+    b = np.zeros((H, W), np.float32); b[1, 4] = 1.0
+    hs += [a, b]
+    return np.stack(hs)[:, None]
+
+
+def gen_refine():
+    from balldetection.helper_balldetection import extract_position_torch_gaussian as ball_fn
+    from tabledetection.helper_tabledetection import extract_position_torch_gaussian as table_fn
+    heat = refine_cases()
+    t = torch.from_numpy(heat)
+    ball = ball_fn(t, 1920, 1080)
+    table = table_fn(t, 1920, 1080)
+    # multi-channel table call (B=2, C=3)
+    mc = heat[:6, 0].reshape(2, 3, *heat.shape[2:])
+    table_mc = table_fn(torch.from_numpy(mc), 1920, 1080)
+    toy = torch.tensor([[[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 1, 1, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]],
+                        [[0, 0, 0, 0, 0], [0, 0, 0, 0, 1], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]]], dtype=torch.float32)
+    toy_ball = ball_fn(toy, 5, 5)
+    np.savez_compressed(os.path.join(OUT, 'refine.npz'), heat=heat, ball=ball, table=table, mc=mc, table_mc=table_mc,
+                        toy=toy.numpy(), toy_ball=toy_ball)
+    print('refine: %d cases, ball out %s table out %s' % (heat.shape[0], ball.shape, table.shape))
+
+
+def gen_uplift():
+    from uplifting.model import get_model
+    from uplifting.helper import transform_rotationaxes
+    from upliftingtabletennis_amd import weights, synth, arch
+    from oracle import uplift_ref
+    out = {}
+    schema = None
+    for name, size, seed, b, t, pad in [('large_T8', 'large', 21, 4, 8, 3), ('large_T50', 'large', 22, 4, 43, 7),
+                                        ('large_T121', 'large', 23, 3, 120, 1), ('small_T20', 'small', 24, 2, 17, 3)]:
+        sd = weights.random_uplift_state_dict(seed, size)
+        m = get_model('connectstage', size, 'dynamic', 'new')
+        ref_sd = m.state_dict()
+        if size == 'large':
+            schema = [(k, list(v.shape)) for k, v in ref_sd.items()]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        m.eval()
+        ball, table, mask, times = synth.synth_trajectories(b, t, seed=seed, pad=pad)
+        if b > 1:  # ragged: second trajectory shorter; irregular timestamps (dropped frames) on the first
+            cut = max(3, t // 2)
+            ball[1, cut:] = 0; mask[1, cut:] = 0; times[1, cut:] = 0
+            keep = np.sort(np.random.default_rng(seed).choice(t + 6, t, replace=False))
+            times[0, :t] = (keep / 60.0).astype(np.float32)
+            table[0, 3, 2] = 0; table[0, 9, 2] = 0
+        with torch.no_grad():
+            rot, pos = m(*[torch.from_numpy(a) for a in (ball, table, mask, times)])
+            rot_local = transform_rotationaxes(rot, pos.clone())
+        out[name + '/rot'] = rot.numpy(); out[name + '/pos'] = pos.numpy(); out[name + '/rot_local'] = rot_local.numpy()
+        out[name + '/ball'] = ball; out[name + '/table'] = table; out[name + '/mask'] = mask; out[name + '/times'] = times
+        out[name + '/meta'] = np.array([seed, b, t, pad], np.int64)
+        out[name + '/size'] = np.array(size)
+        o_rot, o_pos = uplift_ref.uplift_forward(ball, table, mask, times, sd, heads=arch.UPLIFT_SIZES[size][2])
+        print('uplift %-12s max|ref-oracle| rot %.3e pos %.3e' % (name, (o_rot - rot).abs().max(), (o_pos - pos).abs().max()))
+    # error behaviour: all-ones mask raises (model.py:541-546)
+    try:
+        m(torch.zeros(1, 4, 2), torch.zeros(1, 13, 3), torch.ones(1, 4), torch.zeros(1, 4))
+        raised = False
+    except ValueError:
+        raised = True
+    out['allones_mask_raises'] = np.array(raised)
+    np.savez_compressed(os.path.join(OUT, 'uplift.npz'), **out)
+    with open(os.path.join(OUT, 'uplift_schema.json'), 'w') as f:
+        json.dump(schema, f)
+    assert [(k, tuple(s)) for k, s in schema] == [(k, tuple(s)) for k, s in arch.uplift_schema('large')], 'uplift schema mismatch'
+
+
+def gen_glue():
+    out = {}
+    try:
+        from inference.utils import filter_trajectory_ball, _uplifting_transform
+        src = 'reference'
+    except Exception as e:  # pragma: no cover
+        print('inference.utils not importable (%s); glue goldens skipped' % e)
+        return
+    rng = np.random.default_rng(31)
+    for name, T in [('short', 12), ('mid', 37), ('long', 70)]:
+        p1 = np.concatenate([rng.uniform(0, 1920, (T, 1)), rng.uniform(0, 1080, (T, 1)), np.ones((T, 1))], 1)
+        p2 = p1.copy()
+        p2[:, :2] += rng.normal(0, 9.0, (T, 2))
+        p2[3, 2] = 0
+        p1[5, 2] = 0
+        fps = {'short': 60.0, 'mid': 50, 'long': 120.0}[name]
+        pos, idx, times = filter_trajectory_ball(p1, p2, fps)
+        table = np.concatenate([rng.uniform(0, 1920, (13, 1)), rng.uniform(0, 1080, (13, 1)), (rng.uniform(size=(13, 1)) < 0.8).astype(float)], 1)
+        b, tb, tm, mk = _uplifting_transform(pos, table, times)
+        out.update({name + '/p1': p1, name + '/p2': p2, name + '/fps': np.array(fps), name + '/pos': pos, name + '/idx': idx,
+                    name + '/times': times, name + '/table': table, name + '/u_ball': b.numpy(), name + '/u_table': tb.numpy(),
+                    name + '/u_times': tm.numpy(), name + '/u_mask': mk.numpy()})
+    from balldetection.transforms import NormalizeImage
+    img = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    d = NormalizeImage(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])({'image': img.copy(), 'prev_image': img[::-1].copy(), 'next_image': None})
+    out['norm/img'] = img
+    out['norm/out'] = d['image']
+    out['norm/out_prev'] = d['prev_image']
+    np.savez_compressed(os.path.join(OUT, 'glue.npz'), **out)
+    print('glue: filter/transform/normalise goldens from', src)
+
+
+def gen_fullsize():
+    """One 704x1280 planted-peak run through the reference CNN + both refine variants."""
+    from upliftingtabletennis_amd import weights, synth
+    from oracle import glue_ref
+    from balldetection.helper_balldetection import extract_position_torch_gaussian as ball_fn
+    from tabledetection.helper_tabledetection import extract_position_torch_gaussian as table_fn
+    seed, h, w, b = 41, 704, 1280, 2
+    sd = weights.random_wasb_state_dict(seed, planted=True)
+    model, _ = ref_wasb(sd)
+    frames, track = synth.synth_frames(b + 2, h, w, seed=seed)
+    x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (w, h)) for i in range(b)])
+    t0 = time.time()
+    with torch.no_grad():
+        heat, _ = model(torch.from_numpy(x))
+    dt = time.time() - t0
+    ball = ball_fn(heat, 1920, 1080)
+    table = table_fn(heat, 1920, 1080)
+    hn = heat.numpy()
+    idx = hn.reshape(b, -1).argmax(1).astype(np.int64)
+    flat = np.sort(hn.reshape(b, -1), axis=1)
+    crops = np.stack([hn[i, 0, max(0, idx[i] // w - 8):idx[i] // w + 8, max(0, idx[i] % w - 8):idx[i] % w + 8] for i in range(b)])
+    np.savez_compressed(os.path.join(OUT, 'wasb_full.npz'), meta=np.array([seed, b, h, w], np.int64), track=track, argmax=idx,
+                        ball=ball, table=table, top2=flat[:, -2:], crops=crops, sub16=hn[:, :, ::16, ::16],
+                        sha256=np.array(hashlib.sha256(hn.tobytes()).hexdigest()), ref_seconds=np.array(dt))
+    print('full-size: ref forward %.1f s for %d frames (%d threads); argmax %s (track %s); top2 %s'
+          % (dt, b, torch.get_num_threads(), [(int(i % w), int(i // w)) for i in idx], track[1:1 + b].tolist(), flat[:, -2:].tolist()))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full']
+    for w_ in which:
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize}[w_]()
