@@ -1,0 +1,133 @@
+/*
+ * ttup.h -- C ABI of libttup.so: the MI355X (gfx950) implementation of the
+ * detect -> refine -> uplift hot path of KieDani/UpliftingTableTennis.
+ *
+ * The reference has no native code on this path: its boundary is three Python call sites
+ * (SURVEY.md 8b).  Each entry point below names the reference call it replaces; the ctypes
+ * binding a maintainer would add on the reference side is shown in INTEGRATION.md and is what
+ * upliftingtabletennis_amd/_lib.py contains.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory on the current HIP device, owned by the caller
+ *     (torch tensors: tensor.data_ptr()), alive until `stream` has been synchronised;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream), 0 = default;
+ *   - all functions return 0 on success, a TTUP_E* code otherwise; ttup_last_error() returns the
+ *     thread-local message of the last failure;
+ *   - handles own only their packed weights and scratch; create/destroy synchronise, forward never does;
+ *   - no entry point falls back to the CPU: without a usable HIP device every compute call fails.
+ */
+#ifndef TTUP_H
+#define TTUP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTUP_OK          0
+#define TTUP_EINVAL      1   /* bad argument (Python shim raises ValueError)            */
+#define TTUP_EFORMAT     2   /* weight blob does not match the architecture             */
+#define TTUP_EHIP        3   /* HIP runtime error (RuntimeError)                        */
+#define TTUP_ENOMEM      4
+#define TTUP_EMASK       5   /* uplift mask is not {0,1} with at least one 0: the reference's
+                                ValueError at uplifting/model.py:541-546                */
+
+/* activation / arithmetic type of the CNN */
+#define TTUP_DTYPE_BF16  0   /* bf16 storage, bf16 MFMA, fp32 accumulate (production)   */
+#define TTUP_DTYPE_F32   1   /* fp32 storage and arithmetic (parity / debug path)       */
+
+/* refine variants */
+#define TTUP_REFINE_BALL  0  /* balldetection/helper_balldetection.py:29-110            */
+#define TTUP_REFINE_TABLE 1  /* tabledetection/helper_tabledetection.py:50-156          */
+
+/* channel order flag of ttup_preprocess */
+#define TTUP_LAYOUT_NCHW_F32 0
+#define TTUP_LAYOUT_NHWC16   1
+
+typedef struct ttup_wasb   ttup_wasb;
+typedef struct ttup_uplift ttup_uplift;
+
+int         ttup_version(void);
+const char* ttup_last_error(void);
+/* number of visible HIP devices, <0 on error; does not initialise a context */
+int         ttup_device_count(void);
+
+/* ---------------------------------------------------------------- a1: pre-processing
+ * Replaces balldetection/transforms.py:17-52 (cv2.resize, INTER_LINEAR, uint8), :379-402
+ * (x/255, ImageNet mean/std) and the triple concat of interface.py:104-112.
+ * frames_dev: (n_frames, src_h, src_w, 3) uint8, channel order as delivered (BGR on the hub surface).
+ * Triple t uses frames t, t+1, t+2 -> n_triples = n_frames-2 outputs.
+ * out_dev: float32 (n_triples, 9, dst_h, dst_w) NCHW -- the tensor interface.py:112 feeds the model.
+ */
+int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                            int dst_h, int dst_w, float* out_dev, void* stream);
+
+/* ---------------------------------------------------------------- a2: WASB / HRNet CNN
+ * Replaces WASBNet.forward (balldetection/models/wasb.py:596-608) behind `self.model(x)`
+ * (interface.py:115, inference/utils.py:57).
+ *
+ * blob: weights serialised by upliftingtabletennis_amd.weights.pack_wasb_blob:
+ *   char magic[8]="TTUPWSB1"; int32 n_convs, in_ch, head_out, 0;
+ *   per conv (order = reference state_dict order): int32 cout,cin,k,stride,has_bn,has_bias,0,0;
+ *   float w[cout][cin][k][k]; if has_bias float b[cout]; if has_bn float gamma,beta,mean,var [cout] each.
+ * BN folding (eps 1e-5) and MFMA fragment packing happen inside create.
+ * height/width: network input size (multiples of 8); max_batch: largest B accepted by forward.
+ */
+int  ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch,
+                      int dtype, ttup_wasb** out);
+void ttup_wasb_destroy(ttup_wasb* net);
+
+/* x_dev: float32 (B,9,H,W) NCHW.  heat_dev: float32 (B,1,H,W) (nullable).
+ * argmax_dev: int64 (B) flat index of the first maximum of each heatmap (nullable).
+ * win_dev: float32 (B,9) zero-padded 3x3 window around it (nullable). */
+int ttup_wasb_forward(ttup_wasb* net, const float* x_dev, int batch, float* heat_dev,
+                      int64_t* argmax_dev, float* win_dev, void* stream);
+
+/* Fused fast path: uint8 frames in, heatmaps / peaks out (pre-processing runs inside).
+ * frames_dev: (n_frames, src_h, src_w, 3) uint8; produces n_frames-2 heatmaps (triples t,t+1,t+2). */
+int ttup_wasb_forward_frames(ttup_wasb* net, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                             float* heat_dev, int64_t* argmax_dev, float* win_dev, void* stream);
+
+/* debug/test: copy an internal activation ("stem1","stem2","layer1","trans1_0","trans1_1","stage2_0",...,
+ * "stage4_0") of the last forward as float32 NCHW into out_dev; *c,*h,*w receive its shape. */
+int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_dev, int* c, int* h, int* w, void* stream);
+
+/* ---------------------------------------------------------------- a3/a4: heatmap argmax + refine
+ * Replaces extract_position_torch_gaussian (ball: helper_balldetection.py:29-110, called at
+ * inference/utils.py:59; table: helper_tabledetection.py:50-156, called at interface.py:116).
+ * heat_dev: float32 (n_maps, H, W).  out_xyv_dev: float64 (n_maps,3) [x,y,visibility] in
+ * img_w x img_h pixel coordinates.  argmax_dev / win_dev as above (nullable outputs).
+ * ws_dev: scratch of at least ttup_refine_workspace_bytes(n_maps,H,W) bytes.
+ */
+size_t ttup_refine_workspace_bytes(int n_maps, int height, int width);
+int ttup_refine(const float* heat_dev, int n_maps, int height, int width, int img_w, int img_h, int variant,
+                double* out_xyv_dev, int64_t* argmax_dev, float* win_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* second half only: peaks already known (from ttup_wasb_forward) */
+int ttup_refine_windows(const int64_t* argmax_dev, const float* win_dev, int n_maps, int height, int width,
+                        int img_w, int img_h, int variant, double* out_xyv_dev, void* stream);
+
+/* ---------------------------------------------------------------- a6: uplift transformer
+ * Replaces MultiStageModel.forward (uplifting/model.py:529-571, 'connectstage', mode 'dynamic',
+ * time_rotation 'new') behind `self.model(ball, table, mask, times)` (interface.py:235, inference/utils.py:254).
+ * blob: upliftingtabletennis_amd.weights.pack_uplift_blob:
+ *   char magic[8]="TTUPUPL1"; int32 dim, heads, n_pos_layers, n_first_layers, n_second_layers, n_table, 0, 0;
+ *   then every tensor of the state_dict (reference order, without embed.* and inv_freq): int32 numel; float data[numel].
+ */
+int  ttup_uplift_create(const void* blob, size_t blob_bytes, int max_batch, int max_len, ttup_uplift** out);
+void ttup_uplift_destroy(ttup_uplift* net);
+/* ball (B,T,2), table (B,13,3), mask (B,T) in {0,1}, times (B,T) seconds -> rot (B,3), pos (B,T,3); all float32 dev.
+ * check_mask != 0 reproduces the reference's ValueError (TTUP_EMASK) and costs one stream synchronisation. */
+int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* table_dev, const float* mask_dev,
+                        const float* times_dev, int batch, int len, float* rot_dev, float* pos_dev,
+                        int check_mask, void* stream);
+
+/* ---------------------------------------------------------------- a7: spin frame change
+ * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */
+int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTUP_H */

@@ -1,0 +1,245 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the reference-generated goldens.
+Runs on the MI355X box only (-m gpu).  /root/reference is never read here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import has_gpu
+from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
+from upliftingtabletennis_amd import arch, synth, weights
+
+pytestmark = pytest.mark.gpu
+if has_gpu():
+    from upliftingtabletennis_amd import refine, uplift, wasb, _lib
+
+
+def _wasb_case(g, name):
+    seed, planted, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, planted=bool(planted))
+    if planted:
+        frames, _ = synth.synth_frames(b + 2, h, w, seed=seed)
+        x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (w, h)) for i in range(b)])
+    else:
+        frames = None
+        x = np.random.default_rng(seed).standard_normal((b, 9, h, w)).astype(np.float32)
+    return sd, x, frames, (b, h, w)
+
+
+# ------------------------------------------------------------------------------------------ a2: CNN
+@pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160', 'planted_96x160'])
+def test_wasb_f32_path_matches_reference(golden, name):
+    """fp32 HIP path vs the reference heatmap: tolerance 2e-4 of the heatmap range (fp32 re-association only)."""
+    g = golden('wasb_small.npz')
+    sd, x, _, (b, h, w) = _wasb_case(g, name)
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='f32')
+    heat, none = net(torch.from_numpy(x))
+    assert none is None and heat.shape == (b, 1, h, w) and heat.dtype == torch.float32
+    ref = g[name + '/heat']
+    scale = np.abs(ref).max()
+    err = np.abs(heat.cpu().numpy() - ref).max()
+    assert err <= 2e-4 * scale, (err, scale)
+    assert np.array_equal(heat.cpu().numpy().reshape(b, -1).argmax(1), g[name + '/argmax'])
+    _, taps = wasb_ref.hrnet_features(torch.from_numpy(x), sd, return_taps=True)
+    for k, v in taps.items():
+        if k.startswith('stage4_') and k != 'stage4_0':
+            continue        # dead fuse outputs are elided in the build
+        got = net.read_tap(k, batch=b).cpu()
+        assert got.shape == v.shape, (k, got.shape, v.shape)
+        s = v.abs().max().item() + 1e-12
+        assert (got - v).abs().max().item() <= 2e-4 * s, k
+
+
+@pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160', 'planted_96x160'])
+def test_wasb_bf16_path_close_to_reference(golden, name):
+    """bf16-storage MFMA path: every layer output is rounded to bf16 (2^-9 relative), ~40 layers deep.
+    Tolerance: max error 4% of the heatmap range, rms error 1%; planted peaks keep their exact argmax."""
+    g = golden('wasb_small.npz')
+    sd, x, _, (b, h, w) = _wasb_case(g, name)
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    heat, idx, win = net.forward(torch.from_numpy(x), want_peaks=True)
+    ref = g[name + '/heat']
+    got = heat.cpu().numpy()
+    scale = ref.max() - ref.min()
+    assert np.abs(got - ref).max() <= 4e-2 * scale
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-2 * scale
+    # the fused peak outputs agree with the heatmap the same call returned
+    assert np.array_equal(idx.cpu().numpy(), got.reshape(b, -1).argmax(1))
+    if 'planted' in name:
+        assert np.array_equal(idx.cpu().numpy(), g[name + '/argmax'])       # bit-exact argmax index
+    ri, rw = refine_ref.argmax_window(got[:, 0])
+    assert np.array_equal(win.cpu().numpy().reshape(b, 3, 3), rw)
+
+
+def test_wasb_fullsize_planted_argmax_and_refine(golden):
+    """BASELINE size 704x1280: bit-exact argmax vs the reference run, refined position close to the
+    reference's (bf16 heatmap values differ slightly, so the fit input differs: tolerance 0.05 px of 1920)."""
+    g = golden('wasb_full.npz')
+    seed, b, h, w = [int(v) for v in g['meta']]
+    sd = weights.random_wasb_state_dict(seed, planted=True)
+    frames, track = synth.synth_frames(b + 2, h, w, seed=seed)
+    assert np.array_equal(track, g['track'])
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    fr = torch.from_numpy(frames).cuda()
+    heat, idx, win = net.forward_frames(fr, want_heatmap=True)
+    assert np.array_equal(idx.cpu().numpy(), g['argmax'])
+    # u8 fast path == float path fed with the separately pre-processed tensor
+    x = wasb.preprocess_triples(fr, (w, h))
+    heat2, idx2, win2 = net.forward(x, want_peaks=True)
+    assert torch.equal(idx, idx2) and torch.equal(heat, heat2)
+    sub = heat.cpu().numpy()[:, :, ::16, ::16]
+    assert np.abs(sub - g['sub16']).max() <= 4e-2 * (g['sub16'].max() - g['sub16'].min())
+    for variant, key in ((_lib.REFINE_BALL, 'ball'), (_lib.REFINE_TABLE, 'table')):
+        xyv = refine.refine_windows_device(idx, win, h, w, 1920, 1080, variant).cpu().numpy()
+        ref = g[key].reshape(b, 3)
+        assert np.abs(xyv[:, :2] - ref[:, :2]).max() < 0.05, (xyv, ref)
+        assert np.array_equal(xyv[:, 2], ref[:, 2])
+    # f32 path at full size: argmax identical as well
+    net32 = wasb.WASBNet(sd, resolution=(w, h), max_batch=1, dtype='f32')
+    h32, i32, _ = net32.forward(x[:1], want_peaks=True)
+    assert int(i32[0]) == int(g['argmax'][0])
+    crop = g['crops'][0]
+    iy, ix = int(g['argmax'][0]) // w, int(g['argmax'][0]) % w
+    got = h32[0, 0, iy - 8:iy + 8, ix - 8:ix + 8].cpu().numpy()
+    assert np.abs(got - crop).max() <= 2e-4 * np.abs(crop).max()
+
+
+def test_preprocess_matches_oracle():
+    frames, _ = synth.synth_frames(4, 72, 128, seed=3)
+    fr = torch.from_numpy(frames).cuda()
+    for (w, h) in [(128, 72), (128, 64), (96, 64)]:
+        got = wasb.preprocess_triples(fr, (w, h)).cpu().numpy()
+        ref = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (w, h)) for i in range(2)])
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------ a3/a4: refine
+def test_refine_matches_reference_goldens(golden):
+    g = golden('refine.npz')
+    heat = g['heat']
+    n = heat.shape[0]
+    out, idx, win = refine.refine_device(torch.from_numpy(heat[:, 0]).cuda(), 1920, 1080, _lib.REFINE_BALL)
+    ri, rw = refine_ref.argmax_window(heat[:, 0])
+    assert np.array_equal(idx.cpu().numpy(), ri)                                # bit-exact indices (ties -> first)
+    assert np.array_equal(win.cpu().numpy().reshape(n, 3, 3), rw)               # bit-exact zero-padded windows
+    for fn, key in ((refine.extract_position_ball, 'ball'), (refine.extract_position_table, 'table')):
+        got = fn(torch.from_numpy(heat), 1920, 1080)
+        ref = g[key]
+        assert got.shape == ref.shape and got.dtype == np.float64
+        err = np.abs(got - ref).reshape(n, -1).max(1)
+        # same L-BFGS-B iteration in fp64; flat-valley cases amplify last-bit exp() differences
+        assert np.median(err) < 1e-5 and (err < 2e-3).mean() > 0.8 and err.max() < 1.0, err
+        assert np.array_equal(got[..., 2], ref[..., 2])
+    got = refine.extract_position_table(torch.from_numpy(g['mc']), 1920, 1080)
+    assert got.shape == g['table_mc'].shape
+    assert np.median(np.abs(got - g['table_mc'])) < 1e-5
+    np.testing.assert_allclose(refine.extract_position_ball(torch.from_numpy(g['toy']), 5, 5), g['toy_ball'], atol=1e-5)
+    with pytest.raises(ValueError):
+        refine.extract_position_ball(torch.zeros(4, 4), 10, 10)
+    with pytest.raises(ValueError):
+        refine.extract_position_table(torch.zeros(2, 4, 4), 10, 10)
+
+
+def test_refine_well_posed_windows_tight():
+    """Amplitude-1 Gaussian blobs (what a trained detector emits): HIP fit == scipy fit to 1e-4 heatmap px."""
+    rng = np.random.default_rng(0)
+    n, H, W = 64, 16, 20
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    heat = np.stack([np.exp(-((xx - rng.uniform(2, W - 3)) ** 2 / (2 * rng.uniform(0.8, 3) ** 2) +
+                              (yy - rng.uniform(2, H - 3)) ** 2 / (2 * rng.uniform(0.8, 3) ** 2))) for _ in range(n)]).astype(np.float32)
+    for fn, ref_fn in ((refine.extract_position_ball, refine_ref.extract_position_ball),):
+        got = fn(torch.from_numpy(heat), W, H)
+        ref = ref_fn(heat, W, H)
+        assert np.abs(got - ref).max() < 1e-4
+    got = refine.extract_position_table(torch.from_numpy(heat[:, None]), W, H)
+    ref = refine_ref.extract_position_table(heat[:, None], W, H)
+    assert np.abs(got - ref).max() < 1e-4
+
+
+def test_argmax_fullsize_properties():
+    """BASELINE size (704x1280): argmax equals numpy's first-max index on noise, ties resolve to the first
+    index, odd sizes take the scalar path, NaN wins like torch.argmax."""
+    rng = np.random.default_rng(1)
+    heat = rng.standard_normal((6, 704, 1280)).astype(np.float32)
+    heat[1, 0, 0] = 50.0
+    heat[2, -1, -1] = 50.0
+    heat[3, 100, 200] = 60.0; heat[3, 500, 900] = 60.0
+    heat[4] = 0.25
+    t = torch.from_numpy(heat).cuda()
+    out, idx, win = refine.refine_device(t, 1920, 1080, _lib.REFINE_BALL)
+    ri, rw = refine_ref.argmax_window(heat)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(idx.cpu().numpy(), torch.argmax(t.view(6, -1), 1).cpu().numpy())
+    assert np.array_equal(win.cpu().numpy().reshape(6, 3, 3), rw)
+    odd = rng.standard_normal((3, 37, 53)).astype(np.float32)
+    _, idx, win = refine.refine_device(torch.from_numpy(odd).cuda(), 53, 37, _lib.REFINE_TABLE)
+    ri, rw = refine_ref.argmax_window(odd)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(win.cpu().numpy().reshape(3, 3, 3), rw)
+    nan = rng.standard_normal((2, 64, 64)).astype(np.float32)
+    nan[0, 10, 11] = np.nan; nan[0, 40, 2] = np.nan
+    tn = torch.from_numpy(nan).cuda()
+    _, idx, _ = refine.refine_device(tn, 64, 64, _lib.REFINE_BALL)
+    assert np.array_equal(idx.cpu().numpy(), torch.argmax(tn.view(2, -1), 1).cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------ a6/a7: uplift
+@pytest.mark.parametrize('name', ['large_T8', 'large_T50', 'large_T121', 'small_T20'])
+def test_uplift_matches_reference(golden, name):
+    """3-D positions / spin within 1e-4 relative of the reference forward (north_star tolerance)."""
+    g = golden('uplift.npz')
+    seed = int(g[name + '/meta'][0])
+    size = str(g[name + '/size'])
+    sd = weights.random_uplift_state_dict(seed, size)
+    ball, table, mask, times = [g['%s/%s' % (name, k)] for k in ('ball', 'table', 'mask', 'times')]
+    net = uplift.get_model('connectstage', size, 'dynamic', 'new', state_dict=sd, max_batch=8, max_len=ball.shape[1])
+    rot, pos = net(*[torch.from_numpy(a) for a in (ball, table, mask, times)])
+    rref, pref = g[name + '/rot'], g[name + '/pos']
+    assert np.abs(rot.cpu().numpy() - rref).max() <= 1e-4 * np.abs(rref).max()
+    assert np.abs(pos.cpu().numpy() - pref).max() <= 1e-4 * np.abs(pref).max()
+    loc = uplift.transform_rotationaxes(rot, pos.clone()).cpu().numpy()
+    assert np.abs(loc - g[name + '/rot_local']).max() <= 2e-4 * np.abs(g[name + '/rot_local']).max()
+    # single-trajectory form (3,), (T,3)
+    one = uplift.transform_rotationaxes(rot[0], pos[0]).cpu().numpy()
+    np.testing.assert_allclose(one, loc[0], rtol=1e-6, atol=1e-7)
+
+
+def test_uplift_mask_errors_and_batching():
+    sd = weights.random_uplift_state_dict(5, 'large')
+    net = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=sd, max_batch=16, max_len=64)
+    ball, table, mask, times = [torch.from_numpy(a) for a in synth.synth_trajectories(12, 50, seed=9, pad=3)]
+    with pytest.raises(ValueError):
+        net(ball, table, torch.ones_like(mask), times)          # reference raises on an all-ones mask (model.py:541-546)
+    with pytest.raises(ValueError):
+        net(ball, table, torch.zeros_like(mask), times)
+    rot, pos = net(ball, table, mask, times)
+    o_rot, o_pos = uplift_ref.uplift_forward(ball, table, mask, times, sd)
+    assert (rot.cpu() - o_rot).abs().max() <= 1e-4 * o_rot.abs().max()
+    assert (pos.cpu() - o_pos).abs().max() <= 1e-4 * o_pos.abs().max()
+    # independence of trajectories: a sub-batch gives the same rows
+    rot2, pos2 = net(ball[3:7], table[3:7], mask[3:7], times[3:7])
+    assert torch.allclose(rot2, rot[3:7], rtol=1e-5, atol=1e-6) and torch.allclose(pos2, pos[3:7], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ boundary classes
+def test_interface_surface():
+    from upliftingtabletennis_amd.interface import BallDetector, UpliftingModel
+    det = BallDetector('wasb', max_batch=4)
+    assert det.resolution == (1920, 1080)
+    frames, track = synth.synth_frames(5, 720, 1280, seed=2)
+    triples = [[frames[i - 1], frames[i], frames[i + 1]] for i in range(1, 4)]
+    pos, heat = det.predict(triples)
+    assert pos.shape == (3, 3) and pos.dtype == np.float64 and heat.shape == (3, 1, 704, 1280) and heat.dtype == np.float32
+    # planted weights: detections land on the synthetic blob (1280x720 frame -> 1920x1080 coordinates)
+    exp = (track[1:4] + 0.5) * 1.5 - 0.5
+    assert np.abs(pos[:, :2] - exp).max() < 3.0
+    assert (pos[:, 2] == 1).all()
+    filt, idx, times = det.filter_trajectory(pos, pos, 60.0)
+    assert filt.shape == (3, 2) and np.allclose(times, np.arange(3) / 60.0)
+    with pytest.raises(NotImplementedError):
+        BallDetector('segformerpp_b2')
+    up = UpliftingModel()
+    ball, table, mask, times = synth.synth_trajectories(1, 20, seed=1, pad=1)
+    spin, p3 = up.predict_without_normalization(torch.from_numpy(ball), torch.from_numpy(table), torch.from_numpy(mask), torch.from_numpy(times))
+    assert tuple(spin.shape) == (3,) and p3.shape == (20, 3)

@@ -1,0 +1,82 @@
+"""ctypes binding of libttup.so (include/ttup.h).  Fails loudly when the HIP library is missing: there is
+no CPU fallback anywhere in this package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libttup.so')
+
+OK, EINVAL, EFORMAT, EHIP, ENOMEM, EMASK = 0, 1, 2, 3, 4, 5
+DTYPE_BF16, DTYPE_F32 = 0, 1
+REFINE_BALL, REFINE_TABLE = 0, 1
+
+_c = ctypes
+_vp, _i, _sz = _c.c_void_p, _c.c_int, _c.c_size_t
+
+# name -> (restype, argtypes): every symbol include/ttup.h declares
+SIGNATURES = {
+    'ttup_version': (_i, []),
+    'ttup_last_error': (_c.c_char_p, []),
+    'ttup_device_count': (_i, []),
+    'ttup_preprocess_triples': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ttup_wasb_create': (_i, [_vp, _sz, _i, _i, _i, _i, _c.POINTER(_vp)]),
+    'ttup_wasb_destroy': (None, [_vp]),
+    'ttup_wasb_forward': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'ttup_wasb_forward_frames': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'ttup_wasb_read_tap': (_i, [_vp, _c.c_char_p, _i, _vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _vp]),
+    'ttup_refine_workspace_bytes': (_sz, [_i, _i, _i]),
+    'ttup_refine': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ttup_refine_windows': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ttup_uplift_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),
+    'ttup_uplift_destroy': (None, [_vp]),
+    'ttup_uplift_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    'ttup_transform_rotationaxes': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libttup.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libttup.so not found at %s: build it with `python -m upliftingtabletennis_amd.build` '
+                               '(hipcc, gfx950).  There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    """Map a TTUP_E* code to the exception type the reference raises at the same place."""
+    if rc == OK:
+        return
+    msg = load().ttup_last_error().decode('utf-8', 'replace')
+    if rc in (EINVAL, EFORMAT, EMASK):
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('upliftingtabletennis_amd needs a HIP device (MI355X); torch.cuda.is_available() is False '
+                           'and there is no CPU fallback')
+    load()
+
+
+def ptr(t):
+    """data_ptr of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,51 @@
+// Shared helpers of libttup.so (error reporting, HIP checks, bf16 bit tricks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string>
+
+#include "../../include/ttup.h"
+
+namespace ttup {
+
+void set_error(const char* fmt, ...);   // thread-local, returned by ttup_last_error()
+
+#define TTUP_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ttup::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TTUP_EHIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define TTUP_REQUIRE(cond, code, ...)                                                         \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            ttup::set_error(__VA_ARGS__);                                                     \
+            return code;                                                                      \
+        }                                                                                     \
+    } while (0)
+
+#define TTUP_LAUNCH_CHECK()  TTUP_HIP_CHECK(hipGetLastError())
+
+typedef uint16_t bf16_t;   // raw bits
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } x;
+    x.u = (uint32_t)v << 16;
+    return x.f;
+}
+// round-to-nearest-even, NaN preserved
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } x;
+    x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);
+    return (bf16_t)((x.u + 0x7fffu + ((x.u >> 16) & 1u)) >> 16);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace ttup

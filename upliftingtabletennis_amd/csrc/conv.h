@@ -1,0 +1,58 @@
+// Convolution + pointwise kernels of the WASB/HRNet CNN (reference balldetection/models/wasb.py).
+// Activations are NHWC; two arithmetic modes:
+//   bf16 : bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate   (production path)
+//   f32  : fp32 storage, direct fp32 FMA                               (parity / debug path)
+#pragma once
+#include "common.h"
+#include <vector>
+
+namespace ttup {
+
+// One convolution with eval-mode BatchNorm folded in (scale into the weights, shift into the bias).
+struct FoldedConv {
+    int cout = 0, cin = 0, k = 1, stride = 1;
+    std::vector<float> w;      // [cout][cin][k][k]
+    std::vector<float> bias;   // [cout]
+};
+
+// Device-side packed weights for one conv op (possibly two folded convs concatenated along K).
+struct PackedConv {
+    int cout = 0, cin_total = 0, c0 = 0, k = 1, stride = 1, ck = 32;
+    void*  w_dev = nullptr;     // bf16 MFMA fragments, or f32 [tap][cin][cout]
+    float* bias_dev = nullptr;  // [cout]
+    size_t w_bytes = 0;
+};
+
+struct ConvLaunch {
+    const void* src0 = nullptr;   // NHWC, c0 channels
+    const void* src1 = nullptr;   // NHWC, cin_total-c0 channels (two-source 1x1 only) or null
+    const void* residual = nullptr;  // NHWC cout channels at output resolution, or null
+    void* dst = nullptr;          // NHWC cout channels
+    int batch = 0, h = 0, w = 0;  // input spatial size
+    int relu = 0;
+};
+
+// host-side packing (called from ttup_wasb_create)
+int pack_conv(const FoldedConv& a, const FoldedConv* b /*second source or null*/, int cin_pad, int dtype, PackedConv* out);
+void free_conv(PackedConv* p);
+
+int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t stream);
+
+// y = relu(base + sum_k nearest_upsample(t_k, 2^shift_k)); all NHWC with c channels; base at (h,w).
+int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream);
+
+// float32 NCHW (B,cin,H,W) -> NHWC with cpad channels (zero filled)
+int launch_nchw_to_nhwc(const float* src, void* dst, int batch, int cin, int cpad, int h, int w, int dtype, hipStream_t stream);
+// NHWC (any dtype) -> float32 NCHW (debug taps)
+int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, int w, int dtype, hipStream_t stream);
+
+// head: 1x1 conv cin -> one selected output channel (+bias), float32 (B,1,H,W) out
+int launch_head(const void* src, const float* w_dev /*[cin]*/, float bias, float* heat, int batch, int h, int w, int cin,
+                int dtype, hipStream_t stream);
+
+// uint8 frames -> normalised triples: see ttup_preprocess_triples.  out NCHW f32 or NHWC16 (dtype of the net)
+int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
+                      void* out, int out_layout, int dtype, int first_triple, int n_triples, hipStream_t stream);
+
+}  // namespace ttup

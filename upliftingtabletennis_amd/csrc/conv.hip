@@ -1,0 +1,509 @@
+// Implicit-GEMM convolution for the WASB/HRNet CNN on gfx950 (reference: balldetection/models/wasb.py
+// conv/BN/ReLU/residual call sites :48-64, :85-105, :227-245, :446-451).
+//
+// GEMM view (per output tile):  D[cout][pixel] = sum_k  W[cout][k] * X[k][pixel],   k = (tap, cin)
+//   A operand = weights  (M = cout, 16 per MFMA tile), pre-packed on the host in fragment order
+//   B operand = pixels   (N = 16 consecutive output x of one row), read from an LDS halo tile
+//   v_mfma_f32_16x16x32_bf16, fp32 accumulators; epilogue = +bias (+residual) (ReLU) -> bf16 NHWC.
+// A lane ends up with 4*MT consecutive output channels of one pixel (the cout permutation is folded
+// into the weight packing), so stores are 8..64 contiguous bytes per lane and a wave writes whole
+// 16-pixel NHWC runs.
+#include "conv.h"
+#include <string.h>
+
+namespace ttup {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct ConvKArgs {
+    const bf16_t* src0;
+    const bf16_t* src1;
+    const bf16_t* wpack;
+    const float* bias;
+    const bf16_t* residual;
+    bf16_t* dst;
+    int c0, c1;        // channels of the two sources
+    int nchunk0, nchunk;  // chunks taken from src0, total chunks
+    int H, W, OH, OW;
+    int tiles_x;
+    int relu;
+};
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+}
+
+// LDS offset (in bf16 elements) of 8-channel group c8 of tile pixel (iy, ix).
+template <int CK, int IW>
+__device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
+    return ((iy * IW + ix) * (CK / 8) + c8) * 8;
+}
+
+template <int CK, int COUT, int KS, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
+    constexpr int MT = COUT / 16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int TAPS = KS * KS;
+    constexpr int KSTEPS = (CK == 32) ? TAPS : (TAPS + 1) / 2;
+    constexpr int NTW = TW / 16;
+    constexpr int NT = TH * NTW / 4;          // N-tiles per wave
+    constexpr int PAD = KS / 2;
+    constexpr int IN_ELEMS = IH * IW * CK;
+    constexpr int W_ELEMS = KSTEPS * MT * 64 * 8;
+    static_assert(TH * NTW % 4 == 0, "tile must split over 4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_in = (bf16_t*)smem;
+    bf16_t* s_w = s_in + ((IN_ELEMS + 7) & ~7);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
+    const int gy0 = oy0 * S - PAD, gx0 = ox0 * S - PAD;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        const bool first = chunk < a.nchunk0;
+        const bf16_t* src = first ? a.src0 : a.src1;
+        const int csrc = first ? a.c0 : a.c1;
+        const int ch0 = (first ? chunk : chunk - a.nchunk0) * CK;
+        __syncthreads();
+        // ---- stage the halo tile of this channel chunk (zero outside the image)
+        constexpr int UNITS = IH * IW * (CK / 8);
+        for (int u = tid; u < UNITS; u += 256) {
+            const int c8 = u % (CK / 8), pix = u / (CK / 8);
+            const int iy = pix / IW, ix = pix % IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
+            *(u32x4*)(s_in + lds_off<CK, IW>(iy, ix, c8)) = v;
+        }
+        // ---- stage this chunk's weight fragments (already in fragment order)
+        const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
+        for (int u = tid; u < W_ELEMS / 8; u += 256) ((u32x4*)s_w)[u] = wsrc[u];
+        __syncthreads();
+
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 af[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = *(const bf16x8*)(s_w + ((s * MT + m) * 64 + lane) * 8);
+            int dy, dx, c8;
+            if (CK == 32) {
+                dy = s / KS; dx = s % KS; c8 = g;
+            } else {
+                int tap = 2 * s + (g >> 1);
+                if (tap > TAPS - 1) tap = TAPS - 1;     // padded k-group: weights are zero
+                dy = tap / KS; dx = tap % KS; c8 = g & 1;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int nt = wave * NT + t;
+                const int r = nt / NTW, cg = nt % NTW;
+                const int iy = r * S + dy, ix = (cg * 16 + n) * S + dx;
+                const bf16x8 bfr = *(const bf16x8*)(s_in + lds_off<CK, IW>(iy, ix, c8));
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
+    float bias[4 * MT];
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) bias[i] = a.bias[g * 4 * MT + i];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nt = wave * NT + t;
+        const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + g * 4 * MT;
+        float v[4 * MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
+        if (a.residual) {
+            const u32x2* rp = (const u32x2*)(a.residual + o);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x2 rv = rp[m];
+                v[m * 4 + 0] += bf16_to_f32((bf16_t)(rv.x & 0xffff));
+                v[m * 4 + 1] += bf16_to_f32((bf16_t)(rv.x >> 16));
+                v[m * 4 + 2] += bf16_to_f32((bf16_t)(rv.y & 0xffff));
+                v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int i = 0; i < 4 * MT; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        }
+        if (MT == 1) {
+            *(u32x2*)(a.dst + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        } else {
+#pragma unroll
+            for (int q = 0; q < MT / 2; ++q)
+                *(u32x4*)(a.dst + o + q * 8) = u32x4{pack2(v[q * 8 + 0], v[q * 8 + 1]), pack2(v[q * 8 + 2], v[q * 8 + 3]),
+                                                    pack2(v[q * 8 + 4], v[q * 8 + 5]), pack2(v[q * 8 + 6], v[q * 8 + 7])};
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fp32 direct path (parity/debug)
+struct ConvFArgs {
+    const float* src0; const float* src1; const float* w; const float* bias; const float* residual; float* dst;
+    int c0, c1, cout, ks, stride, H, W, OH, OW, relu;
+    long long total;
+};
+
+__global__ void conv_direct_f32_kernel(ConvFArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const int co = (int)(i % a.cout);
+    long long p = i / a.cout;
+    const int ox = (int)(p % a.OW); p /= a.OW;
+    const int oy = (int)(p % a.OH);
+    const int b = (int)(p / a.OH);
+    const int pad = a.ks / 2, cin = a.c0 + a.c1;
+    float acc = 0.f;
+    for (int dy = 0; dy < a.ks; ++dy) {
+        const int gy = oy * a.stride - pad + dy;
+        if (gy < 0 || gy >= a.H) continue;
+        for (int dx = 0; dx < a.ks; ++dx) {
+            const int gx = ox * a.stride - pad + dx;
+            if (gx < 0 || gx >= a.W) continue;
+            const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+            const float* wt = a.w + (size_t)((dy * a.ks + dx) * cin) * a.cout + co;
+            const float* s0 = a.src0 + pix * a.c0;
+            for (int c = 0; c < a.c0; ++c) acc = fmaf(s0[c], wt[(size_t)c * a.cout], acc);
+            if (a.c1) {
+                const float* s1 = a.src1 + pix * a.c1;
+                const float* wt1 = wt + (size_t)a.c0 * a.cout;
+                for (int c = 0; c < a.c1; ++c) acc = fmaf(s1[c], wt1[(size_t)c * a.cout], acc);
+            }
+        }
+    }
+    acc += a.bias[co];
+    if (a.residual) acc += a.residual[i];
+    if (a.relu) acc = acc > 0.f ? acc : 0.f;
+    a.dst[i] = acc;
+}
+
+// ------------------------------------------------------------------ host side: packing
+void free_conv(PackedConv* p) {
+    if (p->w_dev) (void)hipFree(p->w_dev);
+    if (p->bias_dev) (void)hipFree(p->bias_dev);
+    p->w_dev = nullptr; p->bias_dev = nullptr;
+}
+
+int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, PackedConv* out) {
+    const int k = a.k, taps = k * k, cout = a.cout;
+    const int c0 = cin_pad > a.cin ? cin_pad : a.cin;
+    const int c1 = b ? b->cin : 0;
+    TTUP_REQUIRE(!b || (b->cout == cout && b->k == k && k == 1), TTUP_EINVAL, "two-source conv needs matching 1x1 convs");
+    TTUP_REQUIRE(cout % 16 == 0 && cout <= 128, TTUP_EINVAL, "cout %d unsupported", cout);
+    const int cin_total = c0 + c1;
+    out->cout = cout; out->cin_total = cin_total; out->c0 = c0; out->k = k; out->stride = a.stride;
+    std::vector<float> bias(cout);
+    for (int i = 0; i < cout; ++i) bias[i] = a.bias[i] + (b ? b->bias[i] : 0.f);
+    auto wval = [&](int co, int ci, int tap) -> float {
+        if (ci < c0) return ci < a.cin ? a.w[((size_t)co * a.cin + ci) * taps + tap] : 0.f;
+        return b->w[((size_t)co * b->cin + (ci - c0)) * taps + tap];
+    };
+    TTUP_HIP_CHECK(hipMalloc((void**)&out->bias_dev, cout * sizeof(float)));
+    TTUP_HIP_CHECK(hipMemcpy(out->bias_dev, bias.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+    if (dtype == TTUP_DTYPE_F32) {
+        std::vector<float> w((size_t)taps * cin_total * cout);
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < cin_total; ++ci)
+                for (int co = 0; co < cout; ++co) w[((size_t)t * cin_total + ci) * cout + co] = wval(co, ci, t);
+        out->w_bytes = w.size() * sizeof(float);
+        out->ck = 0;
+        TTUP_HIP_CHECK(hipMalloc(&out->w_dev, out->w_bytes));
+        TTUP_HIP_CHECK(hipMemcpy(out->w_dev, w.data(), out->w_bytes, hipMemcpyHostToDevice));
+        return TTUP_OK;
+    }
+    TTUP_REQUIRE(c0 % 16 == 0 && c1 % 32 == 0, TTUP_EINVAL, "channel counts %d+%d unsupported", c0, c1);
+    const int ck = (c0 % 32 == 0) ? 32 : 16;
+    TTUP_REQUIRE(ck == 32 || (c1 == 0 && k == 3), TTUP_EINVAL, "16-channel chunks only for single-source 3x3");
+    const int mt = cout / 16, ksteps = ck == 32 ? taps : (taps + 1) / 2, nchunk = cin_total / ck;
+    std::vector<bf16_t> w((size_t)nchunk * ksteps * mt * 64 * 8);
+    size_t idx = 0;
+    for (int c = 0; c < nchunk; ++c)
+        for (int s = 0; s < ksteps; ++s)
+            for (int m = 0; m < mt; ++m)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, g = l >> 4;
+                    const int co = (i >> 2) * (4 * mt) + m * 4 + (i & 3);
+                    for (int j = 0; j < 8; ++j) {
+                        int tap, ci;
+                        if (ck == 32) { tap = s; ci = c * 32 + 8 * g + j; }
+                        else { tap = 2 * s + (g >> 1); ci = c * 16 + 8 * (g & 1) + j; }
+                        w[idx++] = f32_to_bf16(tap < taps ? wval(co, ci, tap) : 0.f);
+                    }
+                }
+    out->ck = ck;
+    out->w_bytes = w.size() * sizeof(bf16_t);
+    TTUP_HIP_CHECK(hipMalloc(&out->w_dev, out->w_bytes));
+    TTUP_HIP_CHECK(hipMemcpy(out->w_dev, w.data(), out->w_bytes, hipMemcpyHostToDevice));
+    return TTUP_OK;
+}
+
+// ------------------------------------------------------------------ launch
+template <int CK, int COUT, int KS, int S, int TH, int TW>
+static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
+    constexpr int MT = COUT / 16;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int KSTEPS = (CK == 32) ? KS * KS : (KS * KS + 1) / 2;
+    constexpr size_t SMEM = (size_t)(((IH * IW * CK + 7) & ~7) + KSTEPS * MT * 64 * 8) * 2;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    ConvKArgs a;
+    a.src0 = (const bf16_t*)l.src0; a.src1 = (const bf16_t*)l.src1; a.wpack = (const bf16_t*)p.w_dev; a.bias = p.bias_dev;
+    a.residual = (const bf16_t*)l.residual; a.dst = (bf16_t*)l.dst;
+    a.c0 = p.c0; a.c1 = p.cin_total - p.c0; a.nchunk0 = p.c0 / CK; a.nchunk = p.cin_total / CK;
+    a.H = l.h; a.W = l.w; a.OH = (l.h + S - 1) / S; a.OW = (l.w + S - 1) / S;
+    a.tiles_x = cdiv(a.OW, TW);
+    a.relu = l.relu;
+    const int tiles = a.tiles_x * cdiv(a.OH, TH);
+    static bool attr_done = false;
+    if (!attr_done && SMEM > 64 * 1024) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW>), dim3(tiles, l.batch), dim3(256), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+template <int CK, int KS, int S, int TH, int TW>
+static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
+    switch (p.cout) {
+        case 16: return launch_mfma<CK, 16, KS, S, TH, TW>(p, l, st);
+        case 32: return launch_mfma<CK, 32, KS, S, TH, TW>(p, l, st);
+        case 64: return launch_mfma<CK, 64, KS, S, TH, TW>(p, l, st);
+        case 128: return launch_mfma<CK, 128, KS, S, TH, TW>(p, l, st);
+    }
+    set_error("conv: cout %d unsupported", p.cout);
+    return TTUP_EINVAL;
+}
+
+int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t st) {
+    if (dtype == TTUP_DTYPE_F32) {
+        ConvFArgs a;
+        a.src0 = (const float*)l.src0; a.src1 = (const float*)l.src1; a.w = (const float*)p.w_dev; a.bias = p.bias_dev;
+        a.residual = (const float*)l.residual; a.dst = (float*)l.dst;
+        a.c0 = p.c0; a.c1 = p.cin_total - p.c0; a.cout = p.cout; a.ks = p.k; a.stride = p.stride;
+        a.H = l.h; a.W = l.w; a.OH = (l.h + p.stride - 1) / p.stride; a.OW = (l.w + p.stride - 1) / p.stride; a.relu = l.relu;
+        a.total = (long long)l.batch * a.OH * a.OW * a.cout;
+        const int threads = 256;
+        const long long blocks = (a.total + threads - 1) / threads;
+        hipLaunchKernelGGL(conv_direct_f32_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, a);
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
+    if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
+    if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);
+    if (p.k == 1 && p.stride == 1 && p.ck == 32) return dispatch_cout<32, 1, 1, 8, 32>(p, l, st);
+    set_error("conv: k=%d stride=%d ck=%d unsupported", p.k, p.stride, p.ck);
+    return TTUP_EINVAL;
+}
+
+// ------------------------------------------------------------------ pointwise kernels
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+struct UpsumArgs { const void* base; const void* t[3]; int shift[3]; int n; void* dst; int H, W, C; long long total; };
+
+template <typename T>
+__global__ void upsum_kernel(UpsumArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const int c = (int)(i % a.C);
+    long long p = i / a.C;
+    const int x = (int)(p % a.W); p /= a.W;
+    const int y = (int)(p % a.H);
+    const int b = (int)(p / a.H);
+    float v = ld((const T*)a.base + i);
+    for (int k = 0; k < a.n; ++k) {
+        const int sh = a.shift[k], hh = a.H >> sh, ww = a.W >> sh;
+        v += ld((const T*)a.t[k] + ((size_t)(b * hh + (y >> sh)) * ww + (x >> sh)) * a.C + c);
+    }
+    st((T*)a.dst + i, v > 0.f ? v : 0.f);
+}
+
+int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream) {
+    UpsumArgs a;
+    a.base = base; a.n = n_terms; a.dst = dst; a.H = h; a.W = w; a.C = c;
+    for (int k = 0; k < 3; ++k) { a.t[k] = k < n_terms ? terms[k] : nullptr; a.shift[k] = k < n_terms ? shifts[k] : 0; }
+    a.total = (long long)batch * h * w * c;
+    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(upsum_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(upsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* src, T* dst, int cin, int cpad, int hw, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over b*hw*cpad
+    if (i >= total) return;
+    const int c = (int)(i % cpad);
+    const long long p = i / cpad;
+    const int b = (int)(p / hw), pix = (int)(p % hw);
+    st(dst + i, c < cin ? src[((size_t)b * cin + c) * hw + pix] : 0.f);
+}
+
+int launch_nchw_to_nhwc(const float* src, void* dst, int batch, int cin, int cpad, int h, int w, int dtype, hipStream_t stream) {
+    const long long total = (long long)batch * h * w * cpad;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, (float*)dst, cin, cpad, h * w, total);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, cin, cpad, h * w, total);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* src, float* dst, int c, int hw, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over b*c*hw (dst order)
+    if (i >= total) return;
+    const int pix = (int)(i % hw);
+    const long long q = i / hw;
+    const int ch = (int)(q % c), b = (int)(q / c);
+    dst[i] = ld(src + ((size_t)b * hw + pix) * c + ch);
+}
+
+int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, int w, int dtype, hipStream_t stream) {
+    const long long total = (long long)batch * h * w * c;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)src, dst, c, h * w, total);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, dst, c, h * w, total);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+template <typename T, int CIN>
+__global__ void head_kernel(const T* src, const float* w, float bias, float* heat, long long npix) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc = fmaf(ld(src + i * CIN + c), w[c], acc);
+    heat[i] = acc + bias;
+}
+
+int launch_head(const void* src, const float* w_dev, float bias, float* heat, int batch, int h, int w, int cin, int dtype, hipStream_t stream) {
+    TTUP_REQUIRE(cin == 16, TTUP_EINVAL, "head expects 16 input channels, got %d", cin);
+    const long long npix = (long long)batch * h * w;
+    const unsigned blocks = (unsigned)((npix + 255) / 256);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3(blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias, heat, npix);
+    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias, heat, npix);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+// ------------------------------------------------------------------ a1: uint8 frames -> normalised triples
+// OpenCV INTER_LINEAR on uint8 (fixed point, 11-bit coefficients) + (x/255 - mean)/std, see
+// oracle/glue_ref.py for the algorithm statement.  Parity of the resize is unpinned (cv2 absent offline).
+struct PreArgs {
+    const uint8_t* frames; void* out; int src_h, src_w, dst_h, dst_w, first_triple, n_triples, layout; long long total;
+    float scale_x, scale_y;
+};
+
+__device__ __forceinline__ int cv_round(float v) { return (int)rintf(v); }
+
+__device__ __forceinline__ void axis_tap_x(int d, float scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src_n - 1) { f = 0.f; s = src_n - 1; }
+    i0 = s; i1 = s + 1 < src_n ? s + 1 : src_n - 1;
+    c1 = cv_round(f * 2048.f); c0 = cv_round((1.f - f) * 2048.f);
+}
+__device__ __forceinline__ void axis_tap_y(int d, float scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    i0 = s < 0 ? 0 : (s > src_n - 1 ? src_n - 1 : s);
+    i1 = s + 1 < 0 ? 0 : (s + 1 > src_n - 1 ? src_n - 1 : s + 1);
+    c1 = cv_round(f * 2048.f); c0 = cv_round((1.f - f) * 2048.f);
+}
+
+template <typename T>
+__global__ void preprocess_kernel(PreArgs a) {
+    // one thread per (triple, y, x): produces the 9 channels of that pixel
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const int x = (int)(i % a.dst_w);
+    long long p = i / a.dst_w;
+    const int y = (int)(p % a.dst_h);
+    const int t = (int)(p / a.dst_h);
+    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+    const bool same = a.src_h == a.dst_h && a.src_w == a.dst_w;
+    int x0 = x, x1 = x, a0 = 2048, a1 = 0, y0 = y, y1 = y, b0 = 2048, b1 = 0;
+    if (!same) {
+        axis_tap_x(x, a.scale_x, a.src_w, x0, x1, a0, a1);
+        axis_tap_y(y, a.scale_y, a.src_h, y0, y1, b0, b1);
+    }
+    float vals[9];
+    for (int f = 0; f < 3; ++f) {
+        const uint8_t* img = a.frames + (size_t)(a.first_triple + t + f) * a.src_h * a.src_w * 3;
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (same) {
+                v = img[((size_t)y * a.src_w + x) * 3 + c];
+            } else {
+                const int top = img[((size_t)y0 * a.src_w + x0) * 3 + c] * a0 + img[((size_t)y0 * a.src_w + x1) * 3 + c] * a1;
+                const int bot = img[((size_t)y1 * a.src_w + x0) * 3 + c] * a0 + img[((size_t)y1 * a.src_w + x1) * 3 + c] * a1;
+                v = (((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2) >> 2;
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+            vals[f * 3 + c] = (float)(((double)v / 255.0 - mean[c]) / sd[c]);
+        }
+    }
+    const size_t hw = (size_t)a.dst_h * a.dst_w, pix = (size_t)y * a.dst_w + x;
+    if (a.layout == TTUP_LAYOUT_NCHW_F32) {
+        float* o = (float*)a.out + (size_t)t * 9 * hw + pix;
+        for (int c = 0; c < 9; ++c) o[c * hw] = vals[c];
+    } else {
+        T* o = (T*)a.out + ((size_t)t * hw + pix) * 16;
+        for (int c = 0; c < 16; ++c) st(o + c, c < 9 ? vals[c] : 0.f);
+    }
+}
+
+int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
+                      void* out, int out_layout, int dtype, int first_triple, int n_triples, hipStream_t stream) {
+    TTUP_REQUIRE(first_triple >= 0 && first_triple + n_triples + 2 <= n_frames, TTUP_EINVAL, "triple range outside the clip");
+    PreArgs a;
+    a.frames = frames; a.out = out; a.src_h = src_h; a.src_w = src_w; a.dst_h = dst_h; a.dst_w = dst_w;
+    a.first_triple = first_triple; a.n_triples = n_triples; a.layout = out_layout;
+    a.total = (long long)n_triples * dst_h * dst_w;
+    a.scale_x = (float)((double)src_w / dst_w); a.scale_y = (float)((double)src_h / dst_h);
+    if (a.total == 0) return TTUP_OK;
+    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    if (dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32)
+        hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+}  // namespace ttup

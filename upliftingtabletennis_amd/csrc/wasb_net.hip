@@ -1,0 +1,397 @@
+// a2: the WASB / HRNet ball-heatmap CNN as a static op list over NHWC buffers.
+// Graph follows balldetection/models/wasb.py: HRNet.forward :445-486, HighResolutionModule.forward :227-245,
+// fuse construction :179-222, transitions :362-396, config :514-573, WASBNet.forward :596-608.
+//
+// What is different from the reference's eager module tree (results unchanged):
+//   * BatchNorm (eval) is folded into every conv at create time;
+//   * Bottleneck conv3 (1x1 32->128) and its 1x1 downsample (64->128) + add + ReLU run as ONE two-source
+//     1x1 conv with K = 32+64 (the 128-channel pre-activation never touches HBM);
+//   * stage-4 fused outputs 1..3 (only consumed when classify_invisible=True, never set by get_model,
+//     balldetection/train.py:268) and head channels 0 and 2 (dropped at wasb.py:606) are not computed;
+//   * the batch is processed in micro-batches so that intermediate tensors stay near the Infinity Cache.
+#include "conv.h"
+#include <string.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace ttup {
+int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
+}
+
+using namespace ttup;
+
+namespace {
+
+struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
+
+struct Op {
+    enum Kind { CONV, UPSUM } kind = CONV;
+    int conv = -1;            // index into packed convs
+    int src0 = -1, src1 = -1, residual = -1, dst = -1;
+    int relu = 0;
+    int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
+};
+
+const int STAGE_CH[4] = {16, 32, 64, 128};
+
+struct BlobReader {
+    const char* p; size_t left;
+    bool read(void* dst, size_t n) { if (n > left) return false; memcpy(dst, p, n); p += n; left -= n; return true; }
+};
+
+}  // namespace
+
+struct ttup_wasb {
+    int H = 0, W = 0, max_batch = 0, dtype = 0, micro = 1, in_ch = 9;
+    std::vector<PackedConv> convs;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::map<std::string, int> taps;
+    int t_input = -1, t_out = -1;
+    float* head_w_dev = nullptr; float head_bias = 0.f;
+    float* heat_scratch = nullptr;      // (micro,H,W) when the caller does not want heatmaps
+    void* refine_ws = nullptr; size_t refine_ws_bytes = 0;
+    long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
+    int last_batch = 0;
+
+    size_t esize() const { return dtype == TTUP_DTYPE_F32 ? 4 : 2; }
+    ~ttup_wasb() {
+        for (auto& c : convs) free_conv(&c);
+        for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
+        if (head_w_dev) (void)hipFree(head_w_dev);
+        if (heat_scratch) (void)hipFree(heat_scratch);
+        if (refine_ws) (void)hipFree(refine_ws);
+        if (argmax_scratch) (void)hipFree(argmax_scratch);
+        if (win_scratch) (void)hipFree(win_scratch);
+    }
+};
+
+namespace {
+
+// ---- parse the blob into folded convs (order = upliftingtabletennis_amd.arch.hrnet_convs)
+int parse_blob(const void* blob, size_t bytes, std::vector<FoldedConv>* out, int* in_ch, int* head_out,
+               std::vector<float>* head_w, std::vector<float>* head_b) {
+    BlobReader r{(const char*)blob, bytes};
+    char magic[8]; int hdr[4];
+    TTUP_REQUIRE(r.read(magic, 8) && memcmp(magic, "TTUPWSB1", 8) == 0, TTUP_EFORMAT, "wasb blob: bad magic");
+    TTUP_REQUIRE(r.read(hdr, sizeof hdr), TTUP_EFORMAT, "wasb blob: truncated header");
+    const int n = hdr[0];
+    *in_ch = hdr[1]; *head_out = hdr[2];
+    TTUP_REQUIRE(n == 72, TTUP_EFORMAT, "wasb blob: expected 72 convs, got %d", n);
+    for (int i = 0; i < n; ++i) {
+        int h[8];
+        TTUP_REQUIRE(r.read(h, sizeof h), TTUP_EFORMAT, "wasb blob: truncated at conv %d", i);
+        FoldedConv c; c.cout = h[0]; c.cin = h[1]; c.k = h[2]; c.stride = h[3];
+        const int has_bn = h[4], has_bias = h[5];
+        TTUP_REQUIRE(c.cout > 0 && c.cout <= 128 && c.cin > 0 && c.cin <= 128 && (c.k == 1 || c.k == 3), TTUP_EFORMAT,
+                     "wasb blob: conv %d has unsupported shape %dx%dx%d", i, c.cout, c.cin, c.k);
+        const size_t nw = (size_t)c.cout * c.cin * c.k * c.k;
+        c.w.resize(nw); c.bias.assign(c.cout, 0.f);
+        TTUP_REQUIRE(r.read(c.w.data(), nw * 4), TTUP_EFORMAT, "wasb blob: truncated weights of conv %d", i);
+        if (has_bias) TTUP_REQUIRE(r.read(c.bias.data(), c.cout * 4), TTUP_EFORMAT, "wasb blob: truncated bias of conv %d", i);
+        if (has_bn) {
+            std::vector<float> bn(4 * c.cout);
+            TTUP_REQUIRE(r.read(bn.data(), bn.size() * 4), TTUP_EFORMAT, "wasb blob: truncated BN of conv %d", i);
+            const float *gamma = bn.data(), *beta = gamma + c.cout, *mean = beta + c.cout, *var = mean + c.cout;
+            const size_t per = (size_t)c.cin * c.k * c.k;
+            for (int o = 0; o < c.cout; ++o) {
+                // y = (conv(x)+b - mean) * gamma / sqrt(var + eps) + beta, eps = 1e-5 (nn.BatchNorm2d default)
+                const double s = (double)gamma[o] / sqrt((double)var[o] + 1e-5);
+                for (size_t j = 0; j < per; ++j) c.w[o * per + j] = (float)((double)c.w[o * per + j] * s);
+                c.bias[o] = (float)(((double)c.bias[o] - (double)mean[o]) * s + (double)beta[o]);
+            }
+        }
+        out->push_back(std::move(c));
+    }
+    TTUP_REQUIRE(r.left == 0, TTUP_EFORMAT, "wasb blob: %zu trailing bytes", r.left);
+    const FoldedConv& head = out->back();
+    TTUP_REQUIRE(head.k == 1 && head.cin == 16 && head.cout == *head_out, TTUP_EFORMAT, "wasb blob: unexpected head shape");
+    *head_w = head.w; *head_b = head.bias;
+    return TTUP_OK;
+}
+
+struct Builder {
+    ttup_wasb* net;
+    const std::vector<FoldedConv>* folded;
+    size_t cursor = 0;     // next folded conv in reference order
+    int rc = TTUP_OK;
+
+    int new_tensor(int c, int h, int w) {
+        Tensor t; t.c = c; t.h = h; t.w = w;
+        const size_t bytes = (size_t)net->micro * h * w * c * net->esize();
+        if (hipMalloc(&t.ptr, bytes) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); rc = TTUP_ENOMEM; t.ptr = nullptr; }
+        net->tensors.push_back(t);
+        return (int)net->tensors.size() - 1;
+    }
+    const FoldedConv& next(int cout, int cin, int k, int stride) {
+        const FoldedConv& f = (*folded)[cursor++];
+        if (f.cout != cout || f.cin != cin || f.k != k || f.stride != stride) {
+            set_error("wasb blob: conv %zu is %dx%dx%d/s%d, architecture expects %dx%dx%d/s%d", cursor - 1, f.cout, f.cin, f.k, f.stride, cout, cin, k, stride);
+            rc = TTUP_EFORMAT;
+        }
+        return f;
+    }
+    int pack(const FoldedConv& a, const FoldedConv* b, int cin_pad) {
+        PackedConv p;
+        if (rc == TTUP_OK) { const int e = pack_conv(a, b, cin_pad, net->dtype, &p); if (e) rc = e; }
+        net->convs.push_back(p);
+        return (int)net->convs.size() - 1;
+    }
+    // conv op on tensor `src` -> new tensor
+    int conv(int src, int cout, int k, int stride, int relu, int residual = -1, int dst = -1) {
+        const Tensor s = net->tensors[src];
+        const FoldedConv& f = next(cout, s.c, k, stride);
+        const int pc = pack(f, nullptr, s.c);
+        if (dst < 0) dst = new_tensor(cout, (s.h + stride - 1) / stride, (s.w + stride - 1) / stride);
+        Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = src; op.residual = residual; op.dst = dst; op.relu = relu;
+        net->ops.push_back(op);
+        return dst;
+    }
+    int basic_block(int x) {       // wasb.py:48-64
+        const int c = net->tensors[x].c;
+        const int t = conv(x, c, 3, 1, 1);
+        return conv(t, c, 3, 1, 1, /*residual*/ x);
+    }
+    // HighResolutionModule (wasb.py:227-245); returns fused outputs 0..n_out-1
+    std::vector<int> stage(std::vector<int> xs, int n_out) {
+        const int nb = (int)xs.size();
+        for (int b = 0; b < nb; ++b) { xs[b] = basic_block(xs[b]); xs[b] = basic_block(xs[b]); }
+        // reference order of the fuse convs in the state_dict: i major, j minor, chain index k
+        struct Term { int i, j; std::vector<const FoldedConv*> chain; };
+        std::vector<Term> terms;
+        for (int i = 0; i < nb; ++i)
+            for (int j = 0; j < nb; ++j) {
+                if (j == i) continue;
+                Term t; t.i = i; t.j = j;
+                if (j > i) t.chain.push_back(&next(STAGE_CH[i], STAGE_CH[j], 1, 1));
+                else for (int k = 0; k < i - j; ++k) t.chain.push_back(&next(k == i - j - 1 ? STAGE_CH[i] : STAGE_CH[j], STAGE_CH[j], 3, 2));
+                terms.push_back(t);
+            }
+        std::vector<int> outs;
+        for (int i = 0; i < n_out; ++i) {
+            const Tensor xi = net->tensors[xs[i]];
+            // running sum: starts at x_i (identity term) or at the j=0 chain for i>0, in reference order
+            int acc = -1;
+            bool acc_is_xi = false;
+            std::vector<int> up_t; std::vector<int> up_s;
+            for (int j = 0; j < nb; ++j) {
+                if (j == i) {
+                    if (acc < 0) { acc = xs[i]; acc_is_xi = true; }
+                    else {
+                        // x_i enters the sum after at least one chain term: fold it in as the residual of ... nothing to
+                        // run, so add it through an UPSUM term with shift 0 below
+                        up_t.push_back(xs[i]); up_s.push_back(0);
+                    }
+                    continue;
+                }
+                const Term* tm = nullptr;
+                for (auto& t : terms) if (t.i == i && t.j == j) tm = &t;
+                if (j > i) {        // 1x1 conv + BN at the low resolution, upsampled when summed
+                    const int pc = pack(*tm->chain[0], nullptr, 0);
+                    const Tensor sj = net->tensors[xs[j]];
+                    const int dst = new_tensor(STAGE_CH[i], sj.h, sj.w);
+                    Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = xs[j]; op.dst = dst; op.relu = 0;
+                    net->ops.push_back(op);
+                    up_t.push_back(dst); up_s.push_back(j - i);
+                } else {            // chain of stride-2 3x3 convs; the last one adds the running sum
+                    int cur = xs[j];
+                    for (size_t k = 0; k < tm->chain.size(); ++k) {
+                        const bool last = k + 1 == tm->chain.size();
+                        const FoldedConv& f = *tm->chain[k];
+                        const int pc = pack(f, nullptr, 0);
+                        const Tensor sc = net->tensors[cur];
+                        const int dst = new_tensor(f.cout, (sc.h + 1) / 2, (sc.w + 1) / 2);
+                        Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = cur; op.dst = dst; op.relu = last ? 0 : 1;
+                        if (last && acc >= 0) op.residual = acc;
+                        net->ops.push_back(op);
+                        cur = dst;
+                    }
+                    acc = cur; acc_is_xi = false;
+                }
+            }
+            (void)acc_is_xi;
+            // y = relu(acc + sum of upsampled / late identity terms)
+            const int dst = new_tensor(xi.c, xi.h, xi.w);
+            Op op; op.kind = Op::UPSUM; op.src0 = acc; op.dst = dst; op.n_terms = (int)up_t.size();
+            if (up_t.size() > 3) { set_error("fuse: more than 3 upsample terms"); rc = TTUP_EINVAL; }
+            for (size_t k = 0; k < up_t.size() && k < 3; ++k) { op.terms[k] = up_t[k]; op.shifts[k] = up_s[k]; }
+            net->ops.push_back(op);
+            outs.push_back(dst);
+        }
+        // convs of dead fused outputs (i >= n_out) are skipped but stay consumed from the cursor
+        return outs;
+    }
+};
+
+int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
+    Builder b; b.net = net; b.folded = &folded;
+    const int H = net->H, W = net->W;
+    net->t_input = b.new_tensor(16, H, W);
+    // stem (wasb.py:446-451)
+    int x;
+    {
+        const FoldedConv& f = b.next(64, net->in_ch, 3, 1);
+        const int pc = b.pack(f, nullptr, 16);
+        const int dst = b.new_tensor(64, H, W);
+        Op op; op.conv = pc; op.src0 = net->t_input; op.dst = dst; op.relu = 1; net->ops.push_back(op);
+        x = dst; net->taps["stem1"] = x;
+    }
+    x = b.conv(x, 64, 3, 1, 1); net->taps["stem2"] = x;
+    // layer1: Bottleneck(64 -> 32 -> 128) (wasb.py:85-105), conv3 + downsample fused into one two-source 1x1 conv
+    {
+        const int a1 = b.conv(x, 32, 1, 1, 1);
+        const int a2 = b.conv(a1, 32, 3, 1, 1);
+        const FoldedConv& c3 = b.next(128, 32, 1, 1);
+        const FoldedConv& ds = b.next(128, 64, 1, 1);
+        const int pc = b.pack(c3, &ds, 0);
+        const int dst = b.new_tensor(128, H, W);
+        Op op; op.conv = pc; op.src0 = a2; op.src1 = x; op.dst = dst; op.relu = 1; net->ops.push_back(op);
+        x = dst; net->taps["layer1"] = x;
+    }
+    // transition1 (wasb.py:454-459)
+    std::vector<int> xs(2);
+    xs[0] = b.conv(x, 16, 3, 1, 1); net->taps["trans1_0"] = xs[0];
+    xs[1] = b.conv(x, 32, 3, 2, 1); net->taps["trans1_1"] = xs[1];
+    std::vector<int> ys = b.stage(xs, 2);
+    net->taps["stage2_0"] = ys[0]; net->taps["stage2_1"] = ys[1];
+    // transition2: new branch from the last output (wasb.py:462-467)
+    xs = {ys[0], ys[1], b.conv(ys[1], 64, 3, 2, 1)};
+    ys = b.stage(xs, 3);
+    net->taps["stage3_0"] = ys[0]; net->taps["stage3_1"] = ys[1]; net->taps["stage3_2"] = ys[2];
+    xs = {ys[0], ys[1], ys[2], b.conv(ys[2], 128, 3, 2, 1)};
+    ys = b.stage(xs, 1);
+    net->taps["stage4_0"] = ys[0];
+    net->t_out = ys[0];
+    if (b.rc) return b.rc;
+    TTUP_REQUIRE(b.cursor == folded.size() - 1, TTUP_EFORMAT, "wasb: consumed %zu of %zu convs", b.cursor, folded.size() - 1);
+    return TTUP_OK;
+}
+
+int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
+    for (const Op& op : net->ops) {
+        if (op.kind == Op::CONV) {
+            const Tensor& s = net->tensors[op.src0];
+            ConvLaunch l;
+            l.src0 = s.ptr; l.src1 = op.src1 >= 0 ? net->tensors[op.src1].ptr : nullptr;
+            l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
+            l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
+            const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
+            if (rc) return rc;
+        } else {
+            const Tensor& d = net->tensors[op.dst];
+            const void* terms[3] = {nullptr, nullptr, nullptr};
+            for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
+            const int rc = launch_upsum(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, d.ptr, mb, d.h, d.w, d.c, net->dtype, st);
+            if (rc) return rc;
+        }
+    }
+    return TTUP_OK;
+}
+
+int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                 int batch, float* heat_dev, int64_t* argmax_dev, float* win_dev, hipStream_t st) {
+    const int H = net->H, W = net->W;
+    const size_t hw = (size_t)H * W;
+    for (int b0 = 0; b0 < batch; b0 += net->micro) {
+        const int mb = batch - b0 < net->micro ? batch - b0 : net->micro;
+        int rc;
+        if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
+        else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, st);
+        if (rc) return rc;
+        rc = run_ops(net, mb, st);
+        if (rc) return rc;
+        float* heat = heat_dev ? heat_dev + (size_t)b0 * hw : net->heat_scratch;
+        rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_bias, heat, mb, H, W, 16, net->dtype, st);
+        if (rc) return rc;
+        if (argmax_dev || win_dev) {
+            long long* am = argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch;
+            float* wn = win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch;
+            rc = refine_argmax(heat, mb, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
+            if (rc) return rc;
+        }
+    }
+    net->last_batch = batch < net->micro ? batch : net->micro;
+    return TTUP_OK;
+}
+
+}  // namespace
+
+extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, ttup_wasb** out) {
+    TTUP_REQUIRE(blob && out, TTUP_EINVAL, "ttup_wasb_create: null pointer");
+    TTUP_REQUIRE(height > 0 && width > 0 && height % 8 == 0 && width % 8 == 0, TTUP_EINVAL,
+                 "ttup_wasb_create: input size %dx%d must be positive multiples of 8", height, width);
+    TTUP_REQUIRE(max_batch > 0, TTUP_EINVAL, "ttup_wasb_create: max_batch must be positive");
+    TTUP_REQUIRE(dtype == TTUP_DTYPE_BF16 || dtype == TTUP_DTYPE_F32, TTUP_EINVAL, "ttup_wasb_create: unknown dtype %d", dtype);
+    int ndev = 0;
+    TTUP_HIP_CHECK(hipGetDeviceCount(&ndev));
+    TTUP_REQUIRE(ndev > 0, TTUP_EHIP, "ttup_wasb_create: no HIP device");
+    std::vector<FoldedConv> folded;
+    std::vector<float> head_w, head_b;
+    int in_ch = 0, head_out = 0;
+    int rc = parse_blob(blob, blob_bytes, &folded, &in_ch, &head_out, &head_w, &head_b);
+    if (rc) return rc;
+    TTUP_REQUIRE(in_ch == 9 && head_out == 3, TTUP_EFORMAT, "wasb blob: in_ch=%d head_out=%d unsupported (ball detector is 9/3)", in_ch, head_out);
+    std::unique_ptr<ttup_wasb> net(new ttup_wasb);
+    net->H = height; net->W = width; net->max_batch = max_batch; net->dtype = dtype; net->in_ch = in_ch;
+    // micro-batch: enough tiles to fill 256 CUs, small enough that layer outputs stay cache-friendly
+    const char* env = getenv("TTUP_MICRO_BATCH");
+    int micro = env ? atoi(env) : 4;
+    if (micro < 1) micro = 1;
+    net->micro = micro < max_batch ? micro : max_batch;
+    rc = build(net.get(), folded);
+    if (rc) return rc;
+    // head: keep only channel 1 of the 3 (wasb.py:606)
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->head_w_dev, 16 * sizeof(float)));
+    TTUP_HIP_CHECK(hipMemcpy(net->head_w_dev, head_w.data() + 16, 16 * sizeof(float), hipMemcpyHostToDevice));
+    net->head_bias = head_b[1];
+    const size_t hw = (size_t)height * width;
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->heat_scratch, (size_t)net->micro * hw * sizeof(float)));
+    net->refine_ws_bytes = ttup_refine_workspace_bytes(net->micro, height, width);
+    TTUP_HIP_CHECK(hipMalloc(&net->refine_ws, net->refine_ws_bytes));
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->argmax_scratch, (size_t)net->micro * sizeof(long long)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->win_scratch, (size_t)net->micro * 9 * sizeof(float)));
+    TTUP_HIP_CHECK(hipDeviceSynchronize());
+    *out = net.release();
+    return TTUP_OK;
+}
+
+extern "C" void ttup_wasb_destroy(ttup_wasb* net) {
+    if (!net) return;
+    (void)hipDeviceSynchronize();
+    delete net;
+}
+
+extern "C" int ttup_wasb_forward(ttup_wasb* net, const float* x_dev, int batch, float* heat_dev, int64_t* argmax_dev, float* win_dev, void* stream) {
+    TTUP_REQUIRE(net && x_dev, TTUP_EINVAL, "ttup_wasb_forward: null pointer");
+    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_forward: batch %d outside [0,%d]", batch, net->max_batch);
+    return forward_impl(net, x_dev, nullptr, 0, 0, 0, batch, heat_dev, argmax_dev, win_dev, (hipStream_t)stream);
+}
+
+extern "C" int ttup_wasb_forward_frames(ttup_wasb* net, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                                        float* heat_dev, int64_t* argmax_dev, float* win_dev, void* stream) {
+    TTUP_REQUIRE(net && frames_dev, TTUP_EINVAL, "ttup_wasb_forward_frames: null pointer");
+    TTUP_REQUIRE(n_frames >= 3 && src_h > 0 && src_w > 0, TTUP_EINVAL, "ttup_wasb_forward_frames: need at least 3 frames");
+    const int batch = n_frames - 2;
+    TTUP_REQUIRE(batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_forward_frames: %d triples exceed max_batch %d", batch, net->max_batch);
+    return forward_impl(net, nullptr, frames_dev, n_frames, src_h, src_w, batch, heat_dev, argmax_dev, win_dev, (hipStream_t)stream);
+}
+
+extern "C" int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_dev, int* c, int* h, int* w, void* stream) {
+    TTUP_REQUIRE(net && name, TTUP_EINVAL, "ttup_wasb_read_tap: null pointer");
+    auto it = net->taps.find(name);
+    TTUP_REQUIRE(it != net->taps.end(), TTUP_EINVAL, "ttup_wasb_read_tap: unknown tap '%s'", name);
+    const Tensor& t = net->tensors[it->second];
+    if (c) *c = t.c; if (h) *h = t.h; if (w) *w = t.w;
+    if (!out_dev) return TTUP_OK;
+    TTUP_REQUIRE(batch > 0 && batch <= net->micro, TTUP_EINVAL, "ttup_wasb_read_tap: batch %d exceeds the micro-batch %d held in memory", batch, net->micro);
+    return launch_nhwc_to_nchw(t.ptr, out_dev, batch, t.c, t.h, t.w, net->dtype, (hipStream_t)stream);
+}
+
+extern "C" int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
+                                       float* out_dev, void* stream) {
+    TTUP_REQUIRE(frames_dev && out_dev, TTUP_EINVAL, "ttup_preprocess_triples: null pointer");
+    TTUP_REQUIRE(n_frames >= 3 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, TTUP_EINVAL, "ttup_preprocess_triples: bad shape");
+    return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames - 2, (hipStream_t)stream);
+}

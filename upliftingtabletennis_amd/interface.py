@@ -1,0 +1,151 @@
+"""Drop-in boundary: the classes of the reference's ``interface.py`` (:83-312) for the ball-detection ->
+refine -> uplift path, same constructor arguments, method names, argument meaning, return types and errors.
+
+Differences forced by the environment (documented in DESIGN.md):
+  * no network: weights come from ``TTUP_WEIGHTS`` (a directory laid out like the reference's weight zip:
+    inference_balldetection/<name>/model.pt, inference_uplifting/ours/model.pt) or, when absent, from the
+    seeded generators in ``weights.py`` (``TTUP_SYNTHETIC_WEIGHTS=1`` makes that explicit);
+  * only the in-tree WASB/HRNet detector is built; 'segformerpp_*' needs the un-vendored
+    KieDani/SegformerPlusPlus hub repo and raises NotImplementedError;
+  * the table detector is out of scope this round: ``TableTennisPipeline.predict`` takes the
+    13 table keypoints as an optional argument instead of running a second CNN.
+Quirks kept on purpose: BGR frames are fed to the detector as they come (interface.py:96,104-110); the
+*table* variant of the refine is used on the hub surface (interface.py:116); visibility is always 1.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, glue, refine, uplift, wasb, weights
+
+HEIGHT, WIDTH = 1080, 1920
+KEYPOINT_VISIBLE = 1
+
+
+def _weights_dir():
+    return os.environ.get('TTUP_WEIGHTS', '')
+
+
+def _load_ball_checkpoint(model_name):
+    """-> (state_dict, resolution (W,H), in_frames).  Reference: inference_balldetection.load_model :40-61."""
+    path = os.path.join(_weights_dir(), 'inference_balldetection', model_name, 'model.pt')
+    if _weights_dir() and os.path.exists(path):
+        sd, info = weights.load_checkpoint_state_dict(path)
+        return sd, tuple(info.get('image_resolution', wasb.RESOLUTIONS['wasb'])), int(info.get('in_frames', 3))
+    if _weights_dir():
+        raise RuntimeError('Failed to load weights: %s not found' % path)
+    return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')), planted=True), wasb.RESOLUTIONS['wasb'], 3
+
+
+def _load_uplift_checkpoint():
+    """-> (state_dict, size, transform_mode).  Reference: inference_uplifting.load_model :33-58."""
+    path = os.path.join(_weights_dir(), 'inference_uplifting', 'ours', 'model.pt')
+    if _weights_dir() and os.path.exists(path):
+        sd, info = weights.load_checkpoint_state_dict(path)
+        if info.get('name', 'connectstage') != 'connectstage' or info.get('tabletoken_mode', 'dynamic') != 'dynamic':
+            raise ValueError('only connectstage/dynamic uplift checkpoints are supported')
+        return sd, info.get('size', 'large'), info.get('transform_mode', 'global')
+    if _weights_dir():
+        raise RuntimeError('Failed to load weights: %s not found' % path)
+    return weights.random_uplift_state_dict(int(os.environ.get('TTUP_SEED', '0')), 'large'), 'large', 'global'
+
+
+class BallDetector:
+    def __init__(self, model_name='wasb', max_batch=32, dtype='bf16'):
+        if 'segformerpp' in model_name or model_name == 'vitpose':
+            raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference "
+                                      "(KieDani/SegformerPlusPlus / mmcv); only 'wasb' is built" % model_name)
+        _lib.require_gpu()
+        self.device = torch.device('cuda')
+        self.resolution = (WIDTH, HEIGHT)
+        sd, res, in_frames = _load_ball_checkpoint(model_name)
+        self.model = wasb.get_model(model_name, in_frames=in_frames, resolution=res, pretraining=False, state_dict=sd,
+                                    max_batch=max_batch, dtype=dtype)
+        self.model_resolution = res
+        self.max_batch = max_batch
+
+    def predict(self, images):
+        """images: list (length B) of [prev, curr, next] BGR uint8 HWC arrays.
+        Returns (pred_pos (B,3) float64 [x, y, confidence] in 1920x1080 px, preds (B,1,H,W) float32)."""
+        pred_pos, preds = [], []
+        w, h = self.model_resolution
+        for b0 in range(0, len(images), self.max_batch):
+            chunk = images[b0:b0 + self.max_batch]
+            xs = []
+            for imgs in chunk:
+                fr = torch.from_numpy(np.stack([np.asarray(i) for i in imgs])).to(self.device)   # (3,h,w,3) uint8
+                xs.append(wasb.preprocess_triples(fr, (w, h)))
+            x = torch.cat(xs)
+            heat, _ = self.model(x)
+            pos = refine.extract_position_table(heat, self.resolution[0], self.resolution[1])   # table variant, interface.py:116
+            pred_pos.append(pos[:, 0])
+            preds.append(heat.cpu().numpy())
+        if not pred_pos:
+            return np.zeros((0, 3)), np.zeros((0, 1, h, w), np.float32)
+        return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
+
+    def filter_trajectory(self, ball_positions, ball_positions_aux, fps):
+        return glue.filter_trajectory_ball(ball_positions, ball_positions_aux, fps)
+
+
+class UpliftingModel:
+    def __init__(self, max_len=128):
+        _lib.require_gpu()
+        self.device = torch.device('cuda')
+        sd, size, self.transform_mode = _load_uplift_checkpoint()
+        self.model = uplift.get_model('connectstage', size, 'dynamic', 'new', state_dict=sd, max_batch=64, max_len=max_len)
+
+    def transform(self, data):
+        """NormalizeImgCoords (uplifting/transformations.py:252-266): divide by the uplift resolution 2560x1440."""
+        r_img, table_img = data['r_img'], data['table_img']
+        r_img = r_img / np.array([2560, 1440])
+        table_img[..., :2] = table_img[..., :2] / np.array([2560, 1440])
+        data['r_img'], data['table_img'] = r_img, table_img
+        return data
+
+    def predict(self, ball_coords, table_coords, times):
+        data = self.transform({'r_img': ball_coords, 'table_img': table_coords})
+        ball_coords, table_coords = data['r_img'], data['table_img']
+        mask = np.zeros((ball_coords.shape[0] + 1,), dtype=np.float32)
+        mask[:-1] = 1.0
+        return self.predict_without_normalization(ball_coords, table_coords, torch.tensor(mask).to(self.device), times)
+
+    def predict_without_normalization(self, ball_coords, table_coords, mask, times):
+        ball_coords, table_coords, mask, times = [torch.as_tensor(a).to(self.device, torch.float32) for a in (ball_coords, table_coords, mask, times)]
+        if ball_coords.dim() == 2:      # (N,2) -> pad to the mask length like the reference's callers do
+            n = mask.shape[-1]
+            b = torch.zeros((1, n, 2), device=self.device); b[0, :ball_coords.shape[0]] = ball_coords
+            t = torch.zeros((1, n), device=self.device); t[0, :times.shape[0]] = times
+            ball_coords, times, mask, table_coords = b, t, mask.reshape(1, n), table_coords.reshape(1, 13, 3)
+        pred_rotation, pred_position = self.model(ball_coords, table_coords, mask, times)
+        if self.transform_mode == 'global':
+            pred_rotation_local = uplift.transform_rotationaxes(pred_rotation, pred_position.clone())
+        else:
+            pred_rotation_local = pred_rotation
+        t_prime = int(mask.sum().item())
+        pred_position = pred_position[:, :t_prime, :].cpu().numpy()
+        return pred_rotation_local.squeeze(0), pred_position.squeeze(0)
+
+
+class TableTennisPipeline:
+    def __init__(self, max_batch=32):
+        _lib.require_gpu()
+        self.device = torch.device('cuda')
+        self.ball_detector = BallDetector(model_name='wasb', max_batch=max_batch)
+        self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
+        self.uplifting_model = UpliftingModel()
+        self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
+
+    def predict(self, images, fps, table_keypoints=None):
+        """images: list of BGR frames of one rally; fps: frame rate.  table_keypoints: (13,3) [x,y,vis] in 1920x1080 px
+        (the reference detects them with a second CNN, interface.py:281-283 -- out of scope here).
+        Returns (pred_spin torch (3,), pred_pos_3d numpy (T',3))."""
+        if table_keypoints is None:
+            raise ValueError('table_keypoints (13,3) must be supplied: the table detector is not part of this build')
+        image_triples = [(images[i - 1], images[i], images[i + 1]) for i in range(1, len(images) - 1)]
+        ball_positions, _ = self.ball_detector.predict(image_triples)
+        ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict(image_triples)[0]
+        filtered, _, times_ball = self.ball_detector.filter_trajectory(ball_positions, ball_positions_aux, fps)
+        ball_coords, table_coords, times, mask = glue._uplifting_transform(filtered, np.asarray(table_keypoints, dtype=np.float64), times_ball)
+        return self.uplifting_model.predict_without_normalization(ball_coords, table_coords, mask, times)

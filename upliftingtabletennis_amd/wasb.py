@@ -1,0 +1,118 @@
+"""a2: drop-in for the reference's ``WASBNet`` module behind ``self.model(x)`` (interface.py:115,
+inference/utils.py:57): ``model(x) -> (heatmap (B,1,H,W) float32, None)`` with x (B,9,H,W) float32.
+
+Reference: balldetection/models/wasb.py:510-608 (WASBNet), factory balldetection/train.py:249-271,
+loader inference/inference_balldetection.py:40-61.  The forward runs in libttup.so (csrc/wasb_net.hip,
+csrc/conv.hip); this class only owns the handle and the torch-side buffers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+RESOLUTIONS = {'wasb': (1280, 704)}     # balldetection/config.py:84-85 (width, height)
+
+
+class WASBNet:
+    """Callable like the reference nn.Module.  ``resolution`` is (W, H) as in the reference."""
+
+    def __init__(self, state_dict, resolution=(1280, 704), in_frames=3, max_batch=64, dtype='bf16', device='cuda:0'):
+        _lib.require_gpu()
+        if in_frames != 3:
+            raise ValueError('only in_frames=3 (9 input channels) is built')
+        self.device = torch.device(device)
+        self.W, self.H = int(resolution[0]), int(resolution[1])
+        self.max_batch = int(max_batch)
+        self.dtype = dtype
+        self._lib = _lib.load()
+        blob = weights.pack_wasb_blob(state_dict)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._lib.ttup_wasb_create(blob, len(blob), self.H, self.W, self.max_batch,
+                                            _lib.DTYPE_F32 if dtype == 'f32' else _lib.DTYPE_BF16, ctypes.byref(self._handle))
+        _lib.check(rc)
+
+    # nn.Module surface used by the reference call sites
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __del__(self):
+        h, self._handle = getattr(self, '_handle', None), None
+        if h:
+            self._lib.ttup_wasb_destroy(h)
+
+    def forward(self, x, want_heatmap=True, want_peaks=False):
+        if x.dim() != 4 or x.shape[1] != 9 or x.shape[2] != self.H or x.shape[3] != self.W:
+            raise ValueError('expected input (B,9,%d,%d), got %s' % (self.H, self.W, tuple(x.shape)))
+        x = x.to(self.device, torch.float32).contiguous()
+        b = x.shape[0]
+        outs = []
+        for b0 in range(0, b, self.max_batch):
+            xb = x[b0:b0 + self.max_batch]
+            nb = xb.shape[0]
+            heat = torch.empty((nb, 1, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
+            idx = torch.empty((nb,), dtype=torch.int64, device=self.device) if want_peaks else None
+            win = torch.empty((nb, 9), dtype=torch.float32, device=self.device) if want_peaks else None
+            with torch.cuda.device(self.device):
+                rc = self._lib.ttup_wasb_forward(self._handle, _lib.ptr(xb), nb, _lib.ptr(heat), _lib.ptr(idx), _lib.ptr(win), _lib.stream_ptr())
+            _lib.check(rc)
+            outs.append((heat, idx, win))
+        heat = torch.cat([o[0] for o in outs]) if want_heatmap else None
+        if want_peaks:
+            return heat, torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs])
+        return heat, None
+
+    __call__ = forward
+
+    def forward_frames(self, frames_u8, want_heatmap=False):
+        """Fast path: (N,h,w,3) uint8 device tensor -> peaks of the N-2 triples (pre-processing fused in).
+        Returns (heat or None, argmax (N-2,) int64, windows (N-2,9) float32)."""
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3:
+            raise ValueError('frames must be uint8 (N,h,w,3)')
+        frames_u8 = frames_u8.to(self.device).contiguous()
+        n = frames_u8.shape[0]
+        nb = n - 2
+        if nb > self.max_batch:
+            raise ValueError('%d triples exceed max_batch %d' % (nb, self.max_batch))
+        heat = torch.empty((nb, 1, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
+        idx = torch.empty((nb,), dtype=torch.int64, device=self.device)
+        win = torch.empty((nb, 9), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.ttup_wasb_forward_frames(self._handle, _lib.ptr(frames_u8), n, frames_u8.shape[1], frames_u8.shape[2],
+                                                    _lib.ptr(heat), _lib.ptr(idx), _lib.ptr(win), _lib.stream_ptr())
+        _lib.check(rc)
+        return heat, idx, win
+
+    def read_tap(self, name, batch=1):
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.ttup_wasb_read_tap(self._handle, name.encode(), batch, None, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w), None))
+        out = torch.empty((batch, c.value, h.value, w.value), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_read_tap(self._handle, name.encode(), batch, _lib.ptr(out), ctypes.byref(c), ctypes.byref(h), ctypes.byref(w), _lib.stream_ptr()))
+        return out
+
+
+def get_model(model_name, in_frames, resolution, pretraining=False, state_dict=None, **kw):
+    """Mirror of balldetection/train.py:249-271 for the in-tree CNN."""
+    if model_name != 'wasb':
+        raise ValueError('Model %s not implemented (only the in-tree WASB/HRNet detector is built; see DESIGN.md)' % model_name)
+    if state_dict is None:
+        raise ValueError('a state_dict is required (no weights can be downloaded offline)')
+    return WASBNet(state_dict, resolution=resolution, in_frames=in_frames, **kw)
+
+
+def preprocess_triples(frames_u8, dst_wh):
+    """a1 on the GPU: (N,h,w,3) uint8 -> (N-2,9,H,W) float32, the tensor interface.py:104-112 builds."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    frames_u8 = frames_u8.contiguous()
+    n, h, w, _ = frames_u8.shape
+    out = torch.empty((n - 2, 9, dst_wh[1], dst_wh[0]), dtype=torch.float32, device=frames_u8.device)
+    with torch.cuda.device(frames_u8.device):
+        _lib.check(lib.ttup_preprocess_triples(_lib.ptr(frames_u8), n, h, w, dst_wh[1], dst_wh[0], _lib.ptr(out), _lib.stream_ptr()))
+    return out

@@ -113,6 +113,8 @@ def pack_uplift_blob(state_dict, size='large'):
     d, depth, heads = arch.UPLIFT_SIZES[size]
     pos, first, second = arch.uplift_layers(size)
     parts = [UPLIFT_MAGIC, struct.pack('<8i', d, heads, len(pos), len(first), len(second), 13, 0, 0)]
+    inv = _np(state_dict[(pos + first + second)[0] + '.attn.rotary_emb.inv_freq'])   # identical in every layer (model.py:51)
+    parts += [struct.pack('<i', inv.size), inv.tobytes()]
     for k, shape in arch.uplift_schema(size):
         if k.endswith('inv_freq') or k.startswith('embed.'):
             continue
