@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s end-to-end (detect + refine + uplift) on synthetic 1280x720 video.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one stream batch that is already resident in HBM:
+  258 uint8 frames (1280x720x3)  -> 256 triples -> fused pre-processing (cv2-style resize to 1280x704 +
+  normalise) -> WASB/HRNet CNN (bf16 MFMA) -> heatmap argmax + 3x3 window -> L-BFGS-B Gaussian refine
+  (table variant, as on the hub surface) -> two-detector filter + uplift transform on the host (as in the
+  reference) -> uplift transformer on 8 trajectories of 32 detections (padded to 50) -> spin frame change.
+Every rank processes its own stream (independent units); the only collective is the final gather of
+the per-frame (x,y,v) records and the per-trajectory (spin, positions) records.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant CNN kernel,
+HIP-event timed inside this process) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_SRC, W_SRC = 720, 1280
+W_NET, H_NET = 1280, 704
+TRIPLES = int(os.environ.get('TTUP_BENCH_TRIPLES', '256'))
+TRAJ_LEN = 32
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+GFLOP_PER_FRAME_EXECUTED = 331.3   # 344.07 minus the elided stage-4 fuse outputs 1..3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+class Pipeline:
+    """Per-rank detect -> refine -> uplift worker."""
+
+    def __init__(self, device, seed):
+        from upliftingtabletennis_amd import glue, refine, synth, uplift, wasb, weights, _lib
+        self.glue, self.refine, self.uplift, self.lib = glue, refine, uplift, _lib
+        self.device = device
+        self.net = wasb.WASBNet(weights.random_wasb_state_dict(0, planted=True), resolution=(W_NET, H_NET), max_batch=TRIPLES, dtype='bf16', device=device)
+        self.up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=weights.random_uplift_state_dict(0, 'large'),
+                                   max_batch=64, max_len=50, device=device)
+        # synthetic clip: 34 distinct frames tiled to TRIPLES+2 (keeps generation time low; content still varies per frame)
+        base, track = synth.synth_frames(TRAJ_LEN + 2, H_SRC, W_SRC, seed=seed)
+        reps = (TRIPLES + 2 + len(base) - 1) // len(base)
+        clip = np.concatenate([base] * reps)[:TRIPLES + 2]
+        self.frames = torch.from_numpy(clip).to(device)
+        _, table, _, _ = synth.synth_trajectories(1, 4, seed=seed)
+        self.table_px = np.array(table[0], dtype=np.float64)
+        self.table_px[:, 0] *= 1920
+        self.table_px[:, 1] *= 1080
+        self.fps = 60.0
+
+    def step(self):
+        _, idx, win = self.net.forward_frames(self.frames, want_heatmap=False)
+        xyv = self.refine.refine_windows_device(idx, win, H_NET, W_NET, 1920, 1080, self.lib.REFINE_TABLE)
+        pos = xyv.cpu().numpy()                                   # (TRIPLES,3) float64 -- the record the reference returns
+        balls, tables, times, masks = [], [], [], []
+        for s in range(0, TRIPLES, TRAJ_LEN):
+            seg = pos[s:s + TRAJ_LEN]
+            filt, _, t = self.glue.filter_trajectory_ball(seg, seg, self.fps)
+            b, tb, tm, mk = self.glue._uplifting_transform(filt, self.table_px, t)
+            balls.append(b); tables.append(tb); times.append(tm); masks.append(mk)
+        rot, p3 = self.up(torch.cat(balls), torch.cat(tables), torch.cat(masks), torch.cat(times))
+        spin = self.uplift.transform_rotationaxes(rot, p3)
+        return xyv, spin, p3
+
+
+def roofline(pipe):
+    """Per-op HIP-event timing of the CNN inside the library; dominant op -> roofline object."""
+    from upliftingtabletennis_amd import wasb
+    ops = wasb.time_ops(pipe.net, reps=5)
+    conv = [o for o in ops if o['kind'] == 'conv']
+    dom = max(conv, key=lambda o: o['ms'])
+    tot_ms = sum(o['ms'] for o in ops)
+    tot_fl = sum(o['flops'] for o in conv)
+    achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+         'kernel': 'conv_mfma_kernel %dx%d k%d s%d @%dx%d (op %d)' % (dom['cin'], dom['cout'], dom['k'], dom['stride'], dom['h'], dom['w'], dom['index']),
+         'launch_ms': round(dom['ms'], 4), 'micro_batch': dom['batch'],
+         'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                         'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+    return r, ops
+
+
+def heatmap_roofline(device):
+    """HBM roofline of the standalone argmax/window kernel (the extract_position seam): 256 fp32 heatmaps."""
+    from upliftingtabletennis_amd import refine, _lib
+    n = 256            # 923 MB of fp32 heatmaps: well past the 256 MiB Infinity Cache
+    heat = torch.randn((n, H_NET, W_NET), device=device)
+    refine.refine_device(heat, 1920, 1080, _lib.REFINE_BALL)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    ws_bytes = lib.ttup_refine_workspace_bytes(n, H_NET, W_NET)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
+    idx = torch.empty((n,), dtype=torch.int64, device=device)
+    win = torch.empty((n, 9), dtype=torch.float32, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.ttup_refine(_lib.ptr(heat), n, H_NET, W_NET, 1920, 1080, 0, None, _lib.ptr(idx), _lib.ptr(win), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = n * H_NET * W_NET * 4 / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+            'traffic': None, 'kernel': 'argmax_partial_kernel + argmax_finish_kernel', 'launch_ms': round(ms, 4), 'heatmaps': n}
+
+
+def cpu_baseline():
+    """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload: 2 triples through
+    the CNN + refine, one 32-point trajectory through the uplift net."""
+    from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
+    from upliftingtabletennis_amd import synth, weights
+    n = 2
+    frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
+    sd = weights.random_wasb_state_dict(0, planted=True)
+    usd = weights.random_uplift_state_dict(0, 'large')
+    t0 = time.time()
+    x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
+    heat = wasb_ref.wasb_forward(x, sd).numpy()
+    pos = refine_ref.extract_position_table(heat, 1920, 1080)[:, 0]
+    ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=50 - TRAJ_LEN)
+    rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
+    uplift_ref.transform_rotationaxes(rot, p3)
+    dt = time.time() - t0
+    return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d triples 1280x720 (resize+normalise, CNN fp32, refine) + 1 trajectory of %d points; %.1f s' % (n, TRAJ_LEN, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (there is no CPU fallback); the CPU oracle is only the baseline leg')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    pipe = Pipeline(device, seed=rank)
+    for _ in range(a.warmup):
+        pipe.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        xyv, spin, p3 = pipe.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # final gather of the small per-frame / per-trajectory records (the only collective on the path)
+    if dist is not None:
+        rec = torch.cat([xyv.reshape(-1).float(), spin.reshape(-1), p3.reshape(-1)])
+        out = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+        dist.gather(rec, out, dst=0)
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    frames = TRIPLES * a.steps * world
+    line = {'metric': 'frames/sec end-to-end (detect+uplift), 1280x720', 'value': round(frames / dt, 2), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'full detect->uplift pipeline: %d triples of 1280x720 uint8 frames per step per GPU (WASB/HRNet @1280x704, '
+                                   'table-variant refine), %d trajectories x %d detections through the uplift transformer; random-init weights'
+                                   % (TRIPLES, TRIPLES // TRAJ_LEN, TRAJ_LEN),
+                       'frames_per_step_per_gpu': TRIPLES, 'parallelism': 'stream-per-gpu x%d, final gather' % world}}
+    if rank == 0:
+        if not a.no_roofline:
+            r, ops = roofline(pipe)
+            line['roofline'] = r
+            line['roofline_heatmap'] = heatmap_roofline(device)
+            line['cnn_gflop_per_frame'] = GFLOP_PER_FRAME_EXECUTED
+            line['cnn_tflops_end_to_end'] = round(frames / dt * GFLOP_PER_FRAME_EXECUTED / 1e3, 2)
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'bench_ops.json'), 'w') as f:
+                json.dump(ops, f, indent=1)
+        if not a.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -94,6 +94,11 @@ int ttup_wasb_forward_frames(ttup_wasb* net, const uint8_t* frames_dev, int n_fr
  * "stage4_0") of the last forward as float32 NCHW into out_dev; *c,*h,*w receive its shape. */
 int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_dev, int* c, int* h, int* w, void* stream);
 
+/* measurement aid (bench.py): per-op timing of the CNN graph with HIP events on `stream`; see csrc/wasb_net.hip */
+int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
+/* micro-batch the handle was created with (TTUP_MICRO_BATCH) */
+int ttup_wasb_micro_batch(ttup_wasb* net);
+
 /* ---------------------------------------------------------------- a3/a4: heatmap argmax + refine
  * Replaces extract_position_torch_gaussian (ball: helper_balldetection.py:29-110, called at
  * inference/utils.py:59; table: helper_tabledetection.py:50-156, called at interface.py:116).

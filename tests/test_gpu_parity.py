@@ -89,7 +89,7 @@ def test_wasb_fullsize_planted_argmax_and_refine(golden):
     heat2, idx2, win2 = net.forward(x, want_peaks=True)
     assert torch.equal(idx, idx2) and torch.equal(heat, heat2)
     sub = heat.cpu().numpy()[:, :, ::16, ::16]
-    assert np.abs(sub - g['sub16']).max() <= 4e-2 * (g['sub16'].max() - g['sub16'].min())
+    assert np.abs(sub - g['sub16']).max() <= 4e-2 * float(g['top2'].max())       # 4% of the peak height
     for variant, key in ((_lib.REFINE_BALL, 'ball'), (_lib.REFINE_TABLE, 'table')):
         xyv = refine.refine_windows_device(idx, win, h, w, 1920, 1080, variant).cpu().numpy()
         ref = g[key].reshape(b, 3)
@@ -128,9 +128,11 @@ def test_refine_matches_reference_goldens(golden):
         got = fn(torch.from_numpy(heat), 1920, 1080)
         ref = g[key]
         assert got.shape == ref.shape and got.dtype == np.float64
-        err = np.abs(got - ref).reshape(n, -1).max(1)
+        # error in heatmap pixels (the goldens were scaled to 1920x1080 from a 12x14 map: 137x / 90x)
+        hm = np.abs(got - ref).reshape(n, -1)[:, :2] / np.array([1920 / heat.shape[3], 1080 / heat.shape[2]])
+        err = hm.max(1)
         # same L-BFGS-B iteration in fp64; flat-valley cases amplify last-bit exp() differences
-        assert np.median(err) < 1e-5 and (err < 2e-3).mean() > 0.8 and err.max() < 1.0, err
+        assert np.median(err) < 1e-6 and (err < 1e-3).mean() > 0.8 and err.max() < 0.6, err
         assert np.array_equal(got[..., 2], ref[..., 2])
     got = refine.extract_position_table(torch.from_numpy(g['mc']), 1920, 1080)
     assert got.shape == g['table_mc'].shape
@@ -198,8 +200,14 @@ def test_uplift_matches_reference(golden, name):
     rref, pref = g[name + '/rot'], g[name + '/pos']
     assert np.abs(rot.cpu().numpy() - rref).max() <= 1e-4 * np.abs(rref).max()
     assert np.abs(pos.cpu().numpy() - pref).max() <= 1e-4 * np.abs(pref).max()
+    # a7 on the reference's own (rot, pos): isolates the frame-change kernel
+    loc = uplift.transform_rotationaxes(torch.from_numpy(rref).cuda(), torch.from_numpy(pref).cuda()).cpu().numpy()
+    assert np.abs(loc - g[name + '/rot_local']).max() <= 1e-5 * np.abs(g[name + '/rot_local']).max()
+    # chained on our own outputs: e_x = normalise(pos[1]-pos[0]) is a difference of close points, so the 1e-4
+    # position tolerance is amplified by |pos| / |pos[1]-pos[0]|
     loc = uplift.transform_rotationaxes(rot, pos.clone()).cpu().numpy()
-    assert np.abs(loc - g[name + '/rot_local']).max() <= 2e-4 * np.abs(g[name + '/rot_local']).max()
+    amp = (np.abs(pref[:, :2]).max(axis=(1, 2)) / np.linalg.norm(pref[:, 1, :2] - pref[:, 0, :2], axis=1)).max()
+    assert np.abs(loc - g[name + '/rot_local']).max() <= 4e-4 * amp * np.abs(g[name + '/rot_local']).max()
     # single-trajectory form (3,), (T,3)
     one = uplift.transform_rotationaxes(rot[0], pos[0]).cpu().numpy()
     np.testing.assert_allclose(one, loc[0], rtol=1e-6, atol=1e-7)

@@ -389,9 +389,54 @@ extern "C" int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, f
     return launch_nhwc_to_nchw(t.ptr, out_dev, batch, t.c, t.h, t.w, net->dtype, (hipStream_t)stream);
 }
 
+// Profiling aid for bench.py: time every op of the graph separately with HIP events on `stream`
+// (micro-batch `batch`, `reps` back-to-back launches per op).  info_out: 8 ints per op
+// {kind(0 conv,1 upsum), cin_algorithmic, cout, k, stride, out_h, out_w, cin_padded}.
+extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream) {
+    TTUP_REQUIRE(net && ms_out && info_out && n_ops_out, TTUP_EINVAL, "ttup_wasb_time_ops: null pointer");
+    TTUP_REQUIRE(batch > 0 && batch <= net->micro && reps > 0, TTUP_EINVAL, "ttup_wasb_time_ops: batch must be in [1,%d]", net->micro);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)net->ops.size();
+    TTUP_REQUIRE(n <= max_ops, TTUP_EINVAL, "ttup_wasb_time_ops: %d ops exceed max_ops %d", n, max_ops);
+    hipEvent_t e0, e1;
+    TTUP_HIP_CHECK(hipEventCreate(&e0));
+    TTUP_HIP_CHECK(hipEventCreate(&e1));
+    int rc = TTUP_OK;
+    for (int i = 0; i < n && rc == TTUP_OK; ++i) {
+        const Op& op = net->ops[i];
+        std::vector<Op> one(1, op);
+        std::swap(net->ops, one);
+        rc = run_ops(net, batch, st);                       // warm-up launch of this op
+        if (rc == TTUP_OK) {
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && rc == TTUP_OK; ++r) rc = run_ops(net, batch, st);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            ms_out[i] = ms / reps;
+        }
+        std::swap(net->ops, one);
+        int* o = info_out + 8 * i;
+        const Tensor& d = net->tensors[op.dst];
+        if (op.kind == Op::CONV) {
+            const PackedConv& pc = net->convs[op.conv];
+            o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
+        } else {
+            o[0] = 1; o[1] = op.n_terms; o[2] = d.c; o[3] = 0; o[4] = 0; o[5] = d.h; o[6] = d.w; o[7] = d.c;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *n_ops_out = n;
+    return rc;
+}
+
 extern "C" int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
                                        float* out_dev, void* stream) {
     TTUP_REQUIRE(frames_dev && out_dev, TTUP_EINVAL, "ttup_preprocess_triples: null pointer");
     TTUP_REQUIRE(n_frames >= 3 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, TTUP_EINVAL, "ttup_preprocess_triples: bad shape");
     return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames - 2, (hipStream_t)stream);
 }
+
+extern "C" int ttup_wasb_micro_batch(ttup_wasb* net) { return net ? net->micro : 0; }

@@ -116,3 +116,25 @@ def preprocess_triples(frames_u8, dst_wh):
     with torch.cuda.device(frames_u8.device):
         _lib.check(lib.ttup_preprocess_triples(_lib.ptr(frames_u8), n, h, w, dst_wh[1], dst_wh[0], _lib.ptr(out), _lib.stream_ptr()))
     return out
+
+
+def time_ops(net, batch=None, reps=5):
+    """Per-op timing of the CNN graph (HIP events inside the library, on the current stream).
+    Returns a list of dicts {kind, cin, cout, k, stride, h, w, ms, flops} for one micro-batch."""
+    import numpy as _np
+    lib = net._lib
+    micro = lib.ttup_wasb_micro_batch(net._handle)
+    batch = micro if batch is None else min(batch, micro)
+    ms = _np.zeros(256, _np.float32)
+    info = _np.zeros((256, 8), _np.int32)
+    n = ctypes.c_int()
+    with torch.cuda.device(net.device):
+        _lib.check(lib.ttup_wasb_time_ops(net._handle, batch, reps, 256, ms.ctypes.data_as(ctypes.c_void_p),
+                                          info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), _lib.stream_ptr()))
+    ops = []
+    for i in range(n.value):
+        kind, cin, cout, k, stride, h, w, cpad = [int(v) for v in info[i]]
+        flops = 2.0 * batch * h * w * cout * cin * k * k if kind == 0 else 0.0
+        ops.append(dict(index=i, kind='conv' if kind == 0 else 'upsum', cin=cin, cout=cout, k=k, stride=stride, h=h, w=w,
+                        cin_padded=cpad, ms=float(ms[i]), flops=flops, batch=batch))
+    return ops
