@@ -86,14 +86,15 @@ def roofline(pipe):
     """Per-op HIP-event timing of the CNN inside the library; dominant op -> roofline object."""
     from upliftingtabletennis_amd import wasb
     ops = wasb.time_ops(pipe.net, reps=5)
-    conv = [o for o in ops if o['kind'] == 'conv']
+    conv = [o for o in ops if o['kind'] != 'upsum']
     dom = max(conv, key=lambda o: o['ms'])
     tot_ms = sum(o['ms'] for o in ops)
     tot_fl = sum(o['flops'] for o in conv)
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
     r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
          'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-         'kernel': 'conv_mfma_kernel %dx%d k%d s%d @%dx%d (op %d)' % (dom['cin'], dom['cout'], dom['k'], dom['stride'], dom['h'], dom['w'], dom['index']),
+         'kernel': ('bneck_trans_kernel (1x1 96->128 + 3x3 128->16 + 3x3/s2 128->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'bneck_trans' else
+                   'conv_mfma_kernel %dx%d k%d s%d @%dx%d (op %d)' % (dom['cin'], dom['cout'], dom['k'], dom['stride'], dom['h'], dom['w'], dom['index']),
          'launch_ms': round(dom['ms'], 4), 'micro_batch': dom['batch'],
          'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                          'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}

@@ -160,6 +160,179 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ fused Bottleneck tail + transition1
+// One workgroup (8 waves) produces an 8x32 tile of transition1[0] (3x3 s1 128->16) and the matching 4x16 tile of
+// transition1[1] (3x3 s2 128->32) without the 128-channel layer1 tensor ever leaving the CU:
+//   phase 1  layer1 = relu(conv3(A2) + downsample(T2) + b) on the 10x34 halo tile (1x1, K = 32+64, 128 couts),
+//            rounded to bf16 into LDS exactly as the unfused path rounds it into HBM (results are bit-identical);
+//   phase 2a 3x3 s1 over the LDS tile -> B0;   phase 2b 3x3 s2 over the same tile -> B1.
+// Reference: wasb.py:96-105 (conv3/bn3 + downsample + add + relu), :454-459 (transition1).
+struct FusedArgs {
+    const bf16_t* a2; const bf16_t* t2;           // (B,H,W,32), (B,H,W,64)
+    const bf16_t* w1; const float* b1;            // two-source 1x1 -> 128 (3 chunks)
+    const bf16_t* w5; const float* b5;            // 3x3 s1 128 -> 16 (4 chunks x 9 steps)
+    const bf16_t* w6; const float* b6;            // 3x3 s2 128 -> 32 (4 chunks x 9 steps x 2 m-tiles)
+    bf16_t* b0; bf16_t* b1o;
+    int H, W, tiles_x;
+};
+
+__device__ __forceinline__ int l1_off(int pix, int c8) { return pix * 128 + ((c8 ^ (pix & 15)) << 3); }
+__device__ __forceinline__ int st_off(int pix, int c8) { return pix * 32 + ((c8 ^ ((4 - ((pix >> 2) & 3)) & 3)) << 3); }
+
+__global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
+    constexpr int IH = 10, IW = 34, NPIX = IH * IW;            // 340 halo pixels
+    constexpr int NT1 = 22;                                     // 16-pixel groups covering the halo tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]           87,040 B
+    bf16_t* s_st = s_l1 + NPIX * 128;                           // [340][32]            21,760 B
+    bf16_t* s_w = s_st + NPIX * 32;                             // weights              36,864 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int oy0 = (tile / a.tiles_x) * 8, ox0 = (tile % a.tiles_x) * 32;
+    const int gy0 = oy0 - 1, gx0 = ox0 - 1;
+
+    // ---------------- phase 1: layer1 halo tile
+    {
+        f32x4 acc[3][8];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = tid; u < 3 * 8 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w1)[u];
+        for (int chunk = 0; chunk < 3; ++chunk) {
+            const bf16_t* src = chunk == 0 ? a.a2 : a.t2;
+            const int csrc = chunk == 0 ? 32 : 64, ch0 = chunk == 2 ? 32 : 0;
+            __syncthreads();
+            for (int u = tid; u < NPIX * 4; u += 512) {
+                const int c8 = u & 3, pix = u >> 2;
+                const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
+                *(u32x4*)(s_st + st_off(pix, c8)) = v;
+            }
+            __syncthreads();
+            bf16x8 af[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) af[m] = *(const bf16x8*)(s_w + ((chunk * 8 + m) * 64 + lane) * 8);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int j = wave + 8 * t;
+                if (j < NT1) {
+                    int pix = j * 16 + n;
+                    pix = pix < NPIX ? pix : NPIX - 1;
+                    const bf16x8 bfr = *(const bf16x8*)(s_st + st_off(pix, g));
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[t][m], 0, 0, 0);
+                }
+            }
+        }
+        float bias[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) bias[i] = a.b1[g * 32 + i];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int j = wave + 8 * t, pix = j * 16 + n;
+            if (j < NT1 && pix < NPIX) {
+                const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float x = acc[t][2 * q + (i >> 2)][i & 3] + bias[q * 8 + i];
+                        v[i] = (inside && x > 0.f) ? x : 0.f;
+                    }
+                    *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
+    for (int u = tid; u < 4 * 9 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w5)[u];
+    __syncthreads();
+    {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const bf16x8 af = *(const bf16x8*)(s_w + ((c * 9 + s) * 64 + lane) * 8);
+                const int dy = s / 3, dx = s % 3;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+                    const int pix = (r + dy) * IW + cg * 16 + n + dx;
+                    const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, c * 4 + g));
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
+            if (oy < a.H && ox < a.W) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float x = acc[t][r] + a.b5[g * 4 + r]; v[r] = x > 0.f ? x : 0.f; }
+                *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            }
+        }
+    }
+    // ---------------- phase 2b: 3x3 s2 128 -> 32; wave = (output row r, m-tile m); weights two chunks at a time
+    {
+        const int r = wave >> 1, m = wave & 1;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            for (int u = tid; u < 2 * 9 * 2 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w6)[half * (2 * 9 * 2 * 64) + u];
+            __syncthreads();
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    const bf16x8 af = *(const bf16x8*)(s_w + (((cc * 9 + s) * 2 + m) * 64 + lane) * 8);
+                    const int dy = s / 3, dx = s % 3;
+                    const int pix = (2 * r + dy) * IW + 2 * n + dx;
+                    const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, (half * 2 + cc) * 4 + g));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
+                }
+        }
+        const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
+        const int oy = (oy0 >> 1) + r, ox = (ox0 >> 1) + n;
+        if (oy < OH && ox < OW) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float x = acc[q] + a.b6[g * 8 + m * 4 + q]; v[q] = x > 0.f ? x : 0.f; }
+            *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+    }
+}
+
+int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedConv& p6, const void* a2, const void* t2,
+                       void* b0, void* b1, int batch, int h, int w, hipStream_t st) {
+    TTUP_REQUIRE(p1.cout == 128 && p1.cin_total == 96 && p1.c0 == 32 && p1.k == 1 && p1.ck == 32, TTUP_EINVAL, "bneck_trans: unexpected conv1 shape");
+    TTUP_REQUIRE(p5.cout == 16 && p5.cin_total == 128 && p5.k == 3 && p5.stride == 1 && p5.ck == 32, TTUP_EINVAL, "bneck_trans: unexpected conv5 shape");
+    TTUP_REQUIRE(p6.cout == 32 && p6.cin_total == 128 && p6.k == 3 && p6.stride == 2 && p6.ck == 32, TTUP_EINVAL, "bneck_trans: unexpected conv6 shape");
+    TTUP_REQUIRE(h % 2 == 0 && w % 2 == 0, TTUP_EINVAL, "bneck_trans: even input size required");
+    FusedArgs a;
+    a.a2 = (const bf16_t*)a2; a.t2 = (const bf16_t*)t2;
+    a.w1 = (const bf16_t*)p1.w_dev; a.b1 = p1.bias_dev; a.w5 = (const bf16_t*)p5.w_dev; a.b5 = p5.bias_dev;
+    a.w6 = (const bf16_t*)p6.w_dev; a.b6 = p6.bias_dev; a.b0 = (bf16_t*)b0; a.b1o = (bf16_t*)b1;
+    a.H = h; a.W = w; a.tiles_x = cdiv(w, 32);
+    constexpr size_t SMEM = (size_t)(340 * 128 + 340 * 32 + 4 * 9 * 64 * 8) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bneck_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(bneck_trans_kernel, dim3(a.tiles_x * cdiv(h, 8), batch), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 // ------------------------------------------------------------------ fp32 direct path (parity/debug)
 struct ConvFArgs {
     const float* src0; const float* src1; const float* w; const float* bias; const float* residual; float* dst;
@@ -347,6 +520,36 @@ __global__ void upsum_kernel(UpsumArgs a) {
     st((T*)a.dst + i, v > 0.f ? v : 0.f);
 }
 
+// bf16 fast path: one lane = 8 channels (16 bytes) of one pixel; low-resolution terms are re-read by the 2^shift
+// neighbours from L1/L2
+__global__ __launch_bounds__(256) void upsum_bf16x8_kernel(UpsumArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over b*h*w*(C/8)
+    if (i >= a.total) return;
+    const int c8n = a.C >> 3;
+    const int c8 = (int)(i % c8n);
+    long long p = i / c8n;
+    const int x = (int)(p % a.W); p /= a.W;
+    const int y = (int)(p % a.H);
+    const int b = (int)(p / a.H);
+    float v[8];
+    {
+        const u32x4 r = *((const u32x4*)a.base + i);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = bf16_to_f32((bf16_t)(w[k] & 0xffff)); v[2 * k + 1] = bf16_to_f32((bf16_t)(w[k] >> 16)); }
+    }
+    for (int t = 0; t < a.n; ++t) {
+        const int sh = a.shift[t], hh = a.H >> sh, ww = a.W >> sh;
+        const u32x4 r = *((const u32x4*)a.t[t] + ((size_t)(b * hh + (y >> sh)) * ww + (x >> sh)) * c8n + c8);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w[k] >> 16)); }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    *((u32x4*)a.dst + i) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
                  int batch, int h, int w, int c, int dtype, hipStream_t stream) {
     UpsumArgs a;
@@ -355,7 +558,10 @@ int launch_upsum(const void* base, const void* const* terms, const int* shifts, 
     a.total = (long long)batch * h * w * c;
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
     if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(upsum_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(upsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+    else if (c % 8 == 0) {
+        a.total /= 8;
+        hipLaunchKernelGGL(upsum_bf16x8_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
+    } else hipLaunchKernelGGL(upsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }

@@ -27,8 +27,9 @@ namespace {
 struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
 
 struct Op {
-    enum Kind { CONV, UPSUM } kind = CONV;
+    enum Kind { CONV, UPSUM, BNECK_TRANS } kind = CONV;
     int conv = -1;            // index into packed convs
+    int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output
     int src0 = -1, src1 = -1, residual = -1, dst = -1;
     int relu = 0;
     int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
@@ -239,21 +240,32 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
         x = dst; net->taps["stem1"] = x;
     }
     x = b.conv(x, 64, 3, 1, 1); net->taps["stem2"] = x;
-    // layer1: Bottleneck(64 -> 32 -> 128) (wasb.py:85-105), conv3 + downsample fused into one two-source 1x1 conv
+    // layer1: Bottleneck(64 -> 32 -> 128) (wasb.py:85-105), conv3 + downsample fused into one two-source 1x1 conv;
+    // transition1 (wasb.py:454-459).  bf16: both run in one kernel and the 128-channel tensor stays in LDS.
+    std::vector<int> xs(2);
     {
         const int a1 = b.conv(x, 32, 1, 1, 1);
         const int a2 = b.conv(a1, 32, 3, 1, 1);
         const FoldedConv& c3 = b.next(128, 32, 1, 1);
         const FoldedConv& ds = b.next(128, 64, 1, 1);
         const int pc = b.pack(c3, &ds, 0);
-        const int dst = b.new_tensor(128, H, W);
-        Op op; op.conv = pc; op.src0 = a2; op.src1 = x; op.dst = dst; op.relu = 1; net->ops.push_back(op);
-        x = dst; net->taps["layer1"] = x;
+        const bool fuse = net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE") && H % 2 == 0 && W % 2 == 0;
+        if (fuse) {
+            const int p5 = b.pack(b.next(16, 128, 3, 1), nullptr, 0);
+            const int p6 = b.pack(b.next(32, 128, 3, 2), nullptr, 0);
+            xs[0] = b.new_tensor(16, H, W);
+            xs[1] = b.new_tensor(32, H / 2, W / 2);
+            Op op; op.kind = Op::BNECK_TRANS; op.conv = pc; op.conv2 = p5; op.conv3 = p6; op.src0 = a2; op.src1 = x; op.dst = xs[0]; op.dst2 = xs[1];
+            net->ops.push_back(op);
+        } else {
+            const int dst = b.new_tensor(128, H, W);
+            Op op; op.conv = pc; op.src0 = a2; op.src1 = x; op.dst = dst; op.relu = 1; net->ops.push_back(op);
+            x = dst; net->taps["layer1"] = x;
+            xs[0] = b.conv(x, 16, 3, 1, 1);
+            xs[1] = b.conv(x, 32, 3, 2, 1);
+        }
+        net->taps["trans1_0"] = xs[0]; net->taps["trans1_1"] = xs[1];
     }
-    // transition1 (wasb.py:454-459)
-    std::vector<int> xs(2);
-    xs[0] = b.conv(x, 16, 3, 1, 1); net->taps["trans1_0"] = xs[0];
-    xs[1] = b.conv(x, 32, 3, 2, 1); net->taps["trans1_1"] = xs[1];
     std::vector<int> ys = b.stage(xs, 2);
     net->taps["stage2_0"] = ys[0]; net->taps["stage2_1"] = ys[1];
     // transition2: new branch from the last output (wasb.py:462-467)
@@ -278,6 +290,11 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
+            if (rc) return rc;
+        } else if (op.kind == Op::BNECK_TRANS) {
+            const Tensor& s = net->tensors[op.src0];
+            const int rc = launch_bneck_trans(net->convs[op.conv], net->convs[op.conv2], net->convs[op.conv3], s.ptr, net->tensors[op.src1].ptr,
+                                              net->tensors[op.dst].ptr, net->tensors[op.dst2].ptr, mb, s.h, s.w, st);
             if (rc) return rc;
         } else {
             const Tensor& d = net->tensors[op.dst];
@@ -419,7 +436,10 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
         std::swap(net->ops, one);
         int* o = info_out + 8 * i;
         const Tensor& d = net->tensors[op.dst];
-        if (op.kind == Op::CONV) {
+        if (op.kind == Op::BNECK_TRANS) {
+            // algorithmic MACs per output pixel of B0: 96*128 (1x1) + 1152*16 (3x3 s1) + 1152*32/4 (3x3 s2 at quarter density)
+            o[0] = 2; o[1] = 96 * 128 + 1152 * 16 + 1152 * 8; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
+        } else if (op.kind == Op::CONV) {
             const PackedConv& pc = net->convs[op.conv];
             o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
         } else {
