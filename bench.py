@@ -47,15 +47,13 @@ def parse():
 
 
 class Pipeline:
-    """Per-rank detect -> refine -> uplift worker."""
+    """Per-rank worker (upliftingtabletennis_amd.pipeline.StreamWorker) plus its resident synthetic clip."""
 
     def __init__(self, device, seed):
-        from upliftingtabletennis_amd import glue, refine, synth, uplift, wasb, weights, _lib
-        self.glue, self.refine, self.uplift, self.lib = glue, refine, uplift, _lib
-        self.device = device
-        self.net = wasb.WASBNet(weights.random_wasb_state_dict(0, planted=True), resolution=(W_NET, H_NET), max_batch=TRIPLES, dtype='bf16', device=device)
-        self.up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=weights.random_uplift_state_dict(0, 'large'),
-                                   max_batch=64, max_len=50, device=device)
+        from upliftingtabletennis_amd import pipeline, synth, weights
+        self.worker = pipeline.StreamWorker(device, weights.random_wasb_state_dict(0, planted=True), weights.random_uplift_state_dict(0, 'large'),
+                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=50)
+        self.net = self.worker.net
         # synthetic clip: 34 distinct frames tiled to TRIPLES+2 (keeps generation time low; content still varies per frame)
         base, track = synth.synth_frames(TRAJ_LEN + 2, H_SRC, W_SRC, seed=seed)
         reps = (TRIPLES + 2 + len(base) - 1) // len(base)
@@ -68,18 +66,7 @@ class Pipeline:
         self.fps = 60.0
 
     def step(self):
-        _, idx, win = self.net.forward_frames(self.frames, want_heatmap=False)
-        xyv = self.refine.refine_windows_device(idx, win, H_NET, W_NET, 1920, 1080, self.lib.REFINE_TABLE)
-        pos = xyv.cpu().numpy()                                   # (TRIPLES,3) float64 -- the record the reference returns
-        balls, tables, times, masks = [], [], [], []
-        for s in range(0, TRIPLES, TRAJ_LEN):
-            seg = pos[s:s + TRAJ_LEN]
-            filt, _, t = self.glue.filter_trajectory_ball(seg, seg, self.fps)
-            b, tb, tm, mk = self.glue._uplifting_transform(filt, self.table_px, t)
-            balls.append(b); tables.append(tb); times.append(tm); masks.append(mk)
-        rot, p3 = self.up(torch.cat(balls), torch.cat(tables), torch.cat(masks), torch.cat(times))
-        spin = self.uplift.transform_rotationaxes(rot, p3)
-        return xyv, spin, p3
+        return self.worker.process_clip(self.frames, self.table_px, self.fps)
 
 
 def roofline(pipe):
@@ -171,15 +158,14 @@ def main():
         torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
+    from upliftingtabletennis_amd import pipeline
     for _ in range(a.steps):
-        xyv, spin, p3 = pipe.step()
+        rec = pipe.step()
+        # final gather of the small per-frame / per-trajectory records (the only collective on the path)
+        gathered = pipeline.gather_records(rec, dist)
     barrier()
     dt = time.perf_counter() - t0
-    # final gather of the small per-frame / per-trajectory records (the only collective on the path)
     if dist is not None:
-        rec = torch.cat([xyv.reshape(-1).float(), spin.reshape(-1), p3.reshape(-1)])
-        out = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
-        dist.gather(rec, out, dst=0)
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())

@@ -1,0 +1,81 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding helpers and the single collective
+(gather of per-frame / per-trajectory records).  No compute runs here -- the HIP path has no CPU fallback."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from upliftingtabletennis_amd import pipeline
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 9, 256):
+        for world in (1, 2, 3, 8):
+            parts = [pipeline.shard_range(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pipeline.shard_range(4, 2, 2)
+
+
+def test_frame_ranges_cover_all_triples_with_halo():
+    n = 66
+    seen = []
+    for r in range(4):
+        f0, f1, t0, nt = pipeline.frame_range_with_halo(n, 4, r)
+        assert f1 - f0 == nt + 2 and f0 == t0
+        seen += list(range(t0, t0 + nt))
+    assert seen == list(range(n - 2))
+    assert pipeline.frame_range_with_halo(2, 2, 1)[3] == 0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_streams = 5
+        s0, s1 = pipeline.shard_range(n_streams, world, rank)
+        # fake per-stream records with the real record shapes: ragged number of frames / trajectories per rank
+        rng = np.random.default_rng(100 + rank)
+        nf = 10 * (s1 - s0) + rank
+        rec = {'xyv': torch.from_numpy(rng.uniform(0, 1920, (nf, 3))),
+               'spin': torch.from_numpy(rng.standard_normal((s1 - s0, 3)).astype(np.float32)),
+               'pos3d': torch.from_numpy(rng.standard_normal((s1 - s0, 50, 3)).astype(np.float32)),
+               'n_valid': torch.arange(s0, s1, dtype=torch.int64)}
+        got = pipeline.gather_records(rec, dist, dst=0)
+        if rank == 0:
+            assert got is not None and set(got) == set(rec)
+            assert [int(v.shape[0]) for v in got['spin']] == [pipeline.shard_range(n_streams, world, r)[1] - pipeline.shard_range(n_streams, world, r)[0] for r in range(world)]
+            assert torch.equal(torch.cat(got['n_valid']), torch.arange(n_streams))
+            assert torch.equal(got['xyv'][0], rec['xyv']) and got['xyv'][1].shape == (10 * (n_streams - s1) + 1, 3)
+            other = np.random.default_rng(101)
+            exp_xyv = other.uniform(0, 1920, (got['xyv'][1].shape[0], 3))
+            assert np.array_equal(got['xyv'][1].numpy(), exp_xyv)
+            open(os.path.join(out_dir, 'ok'), 'w').write('1')
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_records_world2_gloo(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok').exists()
+
+
+def test_gather_records_single_process():
+    rec = {'a': torch.arange(6).reshape(3, 2)}
+    got = pipeline.gather_records(rec, None)
+    assert torch.equal(got['a'][0], rec['a'])
