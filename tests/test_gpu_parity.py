@@ -251,3 +251,22 @@ def test_interface_surface():
     ball, table, mask, times = synth.synth_trajectories(1, 20, seed=1, pad=1)
     spin, p3 = up.predict_without_normalization(torch.from_numpy(ball), torch.from_numpy(table), torch.from_numpy(mask), torch.from_numpy(times))
     assert tuple(spin.shape) == (3,) and p3.shape == (20, 3)
+
+
+def test_fused_kernels_bit_identical_to_layerwise():
+    """The fused kernels (Bottleneck tail + transition1; BasicBlock chains) round every intermediate to bf16 exactly
+    where the layer-by-layer path stores it, so the two bf16 paths must agree bit for bit."""
+    h, w, b = 96, 160, 2
+    sd = weights.random_wasb_state_dict(17)
+    x = torch.from_numpy(np.random.default_rng(17).standard_normal((b, 9, h, w)).astype(np.float32))
+    fused = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    os.environ['TTUP_NO_FUSE'] = '1'
+    try:
+        plain = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    finally:
+        del os.environ['TTUP_NO_FUSE']
+    h1, _ = fused(x)
+    h2, _ = plain(x)
+    assert torch.equal(h1, h2)
+    for tap in ('trans1_0', 'trans1_1', 'stage2_0', 'stage2_1', 'stage3_2', 'stage4_0'):
+        assert torch.equal(fused.read_tap(tap, b), plain.read_tap(tap, b)), tap

@@ -32,8 +32,11 @@ struct ConvKArgs {
     int relu;
 };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two fp32 -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
 }
 
 // LDS offset (in bf16 elements) of 8-channel group c8 of tile pixel (iy, ix).
@@ -331,6 +334,186 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
     hipLaunchKernelGGL(bneck_trans_kernel, dim3(a.tiles_x * cdiv(h, 8), batch), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
+}
+
+// ------------------------------------------------------------------ fused BasicBlock chains
+// NB BasicBlocks (wasb.py:48-64: conv3x3+BN+ReLU, conv3x3+BN, +x, ReLU) of one HRNet branch in ONE kernel.
+// The input tile with a 2*NB-pixel halo is staged once; every intermediate (rounded to bf16 exactly like the unfused
+// path, and zeroed outside the image so that each conv sees its own zero padding) lives in LDS; only the final
+// TH x TW tile is written.  HBM traffic per block chain: one read + one write of the tensor instead of 5 passes per block.
+// Each wave keeps the conv's A fragments (weights) in registers and walks 16-pixel groups of the output region
+// (linear pixel index, so ragged region widths waste nothing).
+struct BBArgs {
+    const bf16_t* x; bf16_t* y;
+    const bf16_t* w[4]; const float* bias[4];
+    int H, W, tiles_x;
+};
+
+template <int C> __device__ __forceinline__ int bb_off(int pix, int c8) { return pix * C + (c8 << 3); }
+
+// One 3x3 conv of the chain.  Input buffer: row stride RWI pixels, region origin at (IOFF,IOFF).  Output region RHO x RWO.
+// SECOND: second conv of a BasicBlock -> adds the block input (buffer s_res, row stride RWR, origin offset ROFF) and the
+// result either overwrites that buffer in place (ORW = RWR, OOFF = ROFF: each pixel is read and written by the same lane)
+// or goes to global memory.  A wave owns whole output rows (y = wave, wave+8, ...); the 16-pixel groups of a row are
+// unrolled so every LDS address is a per-lane base plus an immediate.
+template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF>
+__device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
+                                        bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane) {
+    constexpr int MT = C / 16;
+    constexpr int KSTEPS = (C == 16) ? 5 : 9;
+    constexpr int XT = (RWO + 15) / 16;
+    const int n = lane & 15, g = lane >> 4;
+    bf16x8 af[KSTEPS][MT];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[s][m] = *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
+    float bias[4 * MT];
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) bias[i] = biasp[g * 4 * MT + i];
+    int koff[KSTEPS];                     // per-lane tap/channel offset of every k-step (elements)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        int dy, dx, c8;
+        if (C == 16) { int tap = 2 * s + (g >> 1); tap = tap > 8 ? 8 : tap; dy = tap / 3; dx = tap % 3; c8 = g & 1; }
+        else { dy = s / 3; dx = s % 3; c8 = g; }
+        koff[s] = (dy * RWI + dx) * C + c8 * 8;
+    }
+    // lane's pixel in the last (possibly ragged) group is clamped so that reads stay inside the buffer
+    constexpr int XLAST = (XT - 1) * 16;
+    const int nl = (XLAST + n < RWO) ? n : (RWO - 1 - XLAST);
+    const int ch_off = (C == 16) ? ((g >> 1) * 8 + (g & 1) * 4) : g * 8;      // lane's first output channel
+    for (int y = wave; y < RHO; y += 8) {
+        const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
+        const bf16_t* rp0 = row + n * C;
+        const bf16_t* rpl = row + (XLAST + nl) * C;
+        f32x4 acc[XT][MT];
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[xt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 bfr[XT];
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+                bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rp0 + koff[s] + xt * 16 * C) : *(const bf16x8*)(rpl + koff[s]);
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[xt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][m], bfr[xt], acc[xt][m], 0, 0, 0);
+        }
+        const int gy = gy0 + y;
+        const bool row_in = gy >= 0 && gy < H;
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            const int x = xt * 16 + n;
+            if (xt == XT - 1 && x >= RWO) continue;
+            float v[4 * MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r] + bias[m * 4 + r];
+            if (SECOND) {       // + block input; the lane's 4*MT channels start at g*4*MT
+                const bf16_t* rp = s_res + ((y + ROFF) * RWR + x + ROFF) * C + ch_off;
+                if (C == 16) {
+                    const u32x2 rv = *(const u32x2*)rp;
+                    v[0] += bf16_to_f32((bf16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(rv.x >> 16));
+                    v[2] += bf16_to_f32((bf16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(rv.y >> 16));
+                } else {
+                    const u32x4 rv = *(const u32x4*)rp;
+                    const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+                }
+            }
+            const int gx = gx0 + x;
+            const bool inside = row_in && gx >= 0 && gx < W;
+#pragma unroll
+            for (int i = 0; i < 4 * MT; ++i) v[i] = (inside && v[i] > 0.f) ? v[i] : 0.f;
+            if (GLOBAL_OUT) {
+                if (inside) {
+                    bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
+                    if (C == 16) *(u32x2*)o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                }
+            } else {
+                bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + ch_off;
+                if (C == 16) *(u32x2*)o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
+        }
+    }
+}
+
+template <int C, int NB, int TH, int TW>
+__global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
+    constexpr int L = 2 * NB;
+    constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
+    constexpr int SZ_A = R0H * R0W * C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* bufA = (bf16_t*)smem;              // block input region (later overwritten in place by the block output)
+    bf16_t* bufB = bufA + SZ_A;                // intermediate of the current block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
+    // stage the input region (zero outside the image)
+    for (int u = tid; u < R0H * R0W * (C / 8); u += 512) {
+        const int c8 = u % (C / 8), pix = u / (C / 8);
+        const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
+        *(u32x4*)(bufA + bb_off<C>(pix, c8)) = v;
+    }
+    __syncthreads();
+    if (NB == 1) {
+        bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+        __syncthreads();
+        bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, a.w[1], a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+    } else {
+        bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
+        __syncthreads();
+        bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
+        __syncthreads();
+        bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+        __syncthreads();
+        bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+    }
+}
+
+template <int C, int NB, int TH, int TW>
+static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
+    constexpr int L = 2 * NB;
+    constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done && SMEM > 64 * 1024) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bb_chain_kernel<C, NB, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
+    }
+    BBArgs k = a;
+    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW);
+    hipLaunchKernelGGL((bb_chain_kernel<C, NB, TH, TW>), dim3(k.tiles_x * cdiv(h, TH), batch), dim3(512), SMEM, st, k);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w, hipStream_t st) {
+    TTUP_REQUIRE(n_convs == 2 || n_convs == 4, TTUP_EINVAL, "bb_chain: 2 or 4 convs expected");
+    const int c = convs[0]->cout;
+    BBArgs a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y;
+    for (int i = 0; i < 4; ++i) { a.w[i] = nullptr; a.bias[i] = nullptr; }
+    for (int i = 0; i < n_convs; ++i) {
+        const PackedConv& p = *convs[i];
+        TTUP_REQUIRE(p.cout == c && p.cin_total == c && p.k == 3 && p.stride == 1 && p.ck == (c == 16 ? 16 : 32), TTUP_EINVAL, "bb_chain: unexpected conv shape");
+        a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
+    }
+    if (c == 16 && n_convs == 4) return launch_bb_t<16, 2, 16, 32>(a, batch, h, w, st);
+    if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
+    if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 8, 32>(a, batch, h, w, st);
+    set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
+    return TTUP_EINVAL;
 }
 
 // ------------------------------------------------------------------ fp32 direct path (parity/debug)

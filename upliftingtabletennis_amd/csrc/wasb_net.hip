@@ -27,7 +27,8 @@ namespace {
 struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
 
 struct Op {
-    enum Kind { CONV, UPSUM, BNECK_TRANS } kind = CONV;
+    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN } kind = CONV;
+    int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
     int conv = -1;            // index into packed convs
     int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output
     int src0 = -1, src1 = -1, residual = -1, dst = -1;
@@ -155,10 +156,24 @@ struct Builder {
         const int t = conv(x, c, 3, 1, 1);
         return conv(t, c, 3, 1, 1, /*residual*/ x);
     }
+    int bb_chain(int x, int n_convs) {      // n_convs/2 BasicBlocks fused (bf16 path)
+        const Tensor s = net->tensors[x];
+        Op op; op.kind = Op::BB_CHAIN; op.src0 = x; op.n_chain = n_convs;
+        for (int i = 0; i < n_convs; ++i) op.chain[i] = pack(next(s.c, s.c, 3, 1), nullptr, s.c);
+        op.dst = new_tensor(s.c, s.h, s.w);
+        net->ops.push_back(op);
+        return op.dst;
+    }
     // HighResolutionModule (wasb.py:227-245); returns fused outputs 0..n_out-1
     std::vector<int> stage(std::vector<int> xs, int n_out) {
         const int nb = (int)xs.size();
-        for (int b = 0; b < nb; ++b) { xs[b] = basic_block(xs[b]); xs[b] = basic_block(xs[b]); }
+        const bool fuse = net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE");
+        for (int b = 0; b < nb; ++b) {
+            const Tensor xt = net->tensors[xs[b]];
+            if (fuse && xt.c == 16) xs[b] = bb_chain(xs[b], 4);                       // both blocks in one kernel
+            else if (fuse && xt.c == 32) { xs[b] = bb_chain(xs[b], 2); xs[b] = bb_chain(xs[b], 2); }
+            else { xs[b] = basic_block(xs[b]); xs[b] = basic_block(xs[b]); }
+        }
         // reference order of the fuse convs in the state_dict: i major, j minor, chain index k
         struct Term { int i, j; std::vector<const FoldedConv*> chain; };
         std::vector<Term> terms;
@@ -290,6 +305,12 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
+            if (rc) return rc;
+        } else if (op.kind == Op::BB_CHAIN) {
+            const Tensor& s = net->tensors[op.src0];
+            const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int k = 0; k < op.n_chain; ++k) cv[k] = &net->convs[op.chain[k]];
+            const int rc = launch_bb_chain(cv, op.n_chain, s.ptr, net->tensors[op.dst].ptr, mb, s.h, s.w, st);
             if (rc) return rc;
         } else if (op.kind == Op::BNECK_TRANS) {
             const Tensor& s = net->tensors[op.src0];
@@ -436,7 +457,9 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
         std::swap(net->ops, one);
         int* o = info_out + 8 * i;
         const Tensor& d = net->tensors[op.dst];
-        if (op.kind == Op::BNECK_TRANS) {
+        if (op.kind == Op::BB_CHAIN) {
+            o[0] = 3; o[1] = op.n_chain * d.c * 9; o[2] = d.c; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = op.n_chain;
+        } else if (op.kind == Op::BNECK_TRANS) {
             // algorithmic MACs per output pixel of B0: 96*128 (1x1) + 1152*16 (3x3 s1) + 1152*32/4 (3x3 s2 at quarter density)
             o[0] = 2; o[1] = 96 * 128 + 1152 * 16 + 1152 * 8; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
         } else if (op.kind == Op::CONV) {
