@@ -10,6 +10,7 @@
 // 16-pixel NHWC runs.
 #include "conv.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace ttup {
 
@@ -28,7 +29,7 @@ struct ConvKArgs {
     int c0, c1;        // channels of the two sources
     int nchunk0, nchunk;  // chunks taken from src0, total chunks
     int H, W, OH, OW;
-    int tiles_x;
+    int tiles_x, tiles_per_img, total_tiles;
     int relu;
 };
 
@@ -40,11 +41,19 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 
 // LDS offset (in bf16 elements) of 8-channel group c8 of tile pixel (iy, ix).
+// CK=32 (64 B per pixel): the 16-byte chunk index is XOR-swizzled with bits 1..2 of the tile column, which makes a
+// 16-pixel ds_read_b128 conflict-free at every alignment (stride-1) and 2-way instead of 4-way at stride 2.
+// CK=16 (32 B per pixel) is conflict-free as is.
 template <int CK, int IW>
 __device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
+    if (CK == 32) return ((iy * IW + ix) * 4 + (c8 ^ ((ix >> 1) & 3))) * 8;
     return ((iy * IW + ix) * (CK / 8) + c8) * 8;
 }
 
+// Persistent, software-pipelined version: a workgroup walks work items (tile, channel chunk); the global loads of
+// item i+1 (halo tile chunk + that chunk's weight fragments) are issued into registers BEFORE the MFMA loop of item i
+// and written to LDS after it, so HBM/L2 latency hides behind the matrix work (single LDS buffer, two barriers per item).
+// Single-chunk convs keep their weights resident in LDS across all tiles of the workgroup.
 template <int CK, int COUT, int KS, int S, int TH, int TW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int MT = COUT / 16;
@@ -56,6 +65,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int IN_ELEMS = IH * IW * CK;
     constexpr int W_ELEMS = KSTEPS * MT * 64 * 8;
+    constexpr int IN_UNITS = IH * IW * (CK / 8), IN_PT = (IN_UNITS + 255) / 256;
+    constexpr int W_UNITS = W_ELEMS / 8, W_PT = (W_UNITS + 255) / 256;
     static_assert(TH * NTW % 4 == 0, "tile must split over 4 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,38 +75,64 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
-    const int gy0 = oy0 * S - PAD, gx0 = ox0 * S - PAD;
+    const int nchunk = a.nchunk;
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_items = my_tiles * nchunk;
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    u32x4 pin[IN_PT], pw[W_PT];
+    auto issue = [&](int item) {
+        const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * TH * S - PAD, gx0 = (t % a.tiles_x) * TW * S - PAD;
         const bool first = chunk < a.nchunk0;
         const bf16_t* src = first ? a.src0 : a.src1;
         const int csrc = first ? a.c0 : a.c1;
         const int ch0 = (first ? chunk : chunk - a.nchunk0) * CK;
-        __syncthreads();
-        // ---- stage the halo tile of this channel chunk (zero outside the image)
-        constexpr int UNITS = IH * IW * (CK / 8);
-        for (int u = tid; u < UNITS; u += 256) {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 256;
             const int c8 = u % (CK / 8), pix = u / (CK / 8);
-            const int iy = pix / IW, ix = pix % IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
-            *(u32x4*)(s_in + lds_off<CK, IW>(iy, ix, c8)) = v;
+            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            pin[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                pin[k] = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
         }
-        // ---- stage this chunk's weight fragments (already in fragment order)
-        const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
-        for (int u = tid; u < W_ELEMS / 8; u += 256) ((u32x4*)s_w)[u] = wsrc[u];
-        __syncthreads();
+        if (nchunk > 1 || item == 0) {
+            const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 256; if (u < W_UNITS) pw[k] = wsrc[u]; }
+        }
+    };
+    auto commit = [&](int item) {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 256;
+            if (u < IN_UNITS) { const int c8 = u % (CK / 8), pix = u / (CK / 8); *(u32x4*)(s_in + lds_off<CK, IW>(pix / IW, pix % IW, c8)) = pin[k]; }
+        }
+        if (nchunk > 1 || item == 0) {
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 256; if (u < W_UNITS) ((u32x4*)s_w)[u] = pw[k]; }
+        }
+    };
 
+    float bias[4 * MT];
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) bias[i] = a.bias[g * 4 * MT + i];
+
+    f32x4 acc[MT][NT];
+    if (n_items > 0) issue(0);
+    for (int item = 0; item < n_items; ++item) {
+        const int chunk = item % nchunk;
+        if (item > 0) __syncthreads();          // every wave finished reading the previous item's LDS image
+        commit(item);
+        __syncthreads();
+        if (item + 1 < n_items) issue(item + 1);
+        if (chunk == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             bf16x8 af[MT];
@@ -120,45 +157,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
             }
         }
-    }
-
-    // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
-    float bias[4 * MT];
+        if (chunk != nchunk - 1) continue;
+        // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
+        const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
 #pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) bias[i] = a.bias[g * 4 * MT + i];
+        for (int t = 0; t < NT; ++t) {
+            const int nt = wave * NT + t;
+            const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
+            if (oy >= a.OH || ox >= a.OW) continue;
+            const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + g * 4 * MT;
+            float v[4 * MT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nt = wave * NT + t;
-        const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
-        if (oy >= a.OH || ox >= a.OW) continue;
-        const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + g * 4 * MT;
-        float v[4 * MT];
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
+            if (a.residual) {
+                const u32x2* rp = (const u32x2*)(a.residual + o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
-        if (a.residual) {
-            const u32x2* rp = (const u32x2*)(a.residual + o);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x2 rv = rp[m];
-                v[m * 4 + 0] += bf16_to_f32((bf16_t)(rv.x & 0xffff));
-                v[m * 4 + 1] += bf16_to_f32((bf16_t)(rv.x >> 16));
-                v[m * 4 + 2] += bf16_to_f32((bf16_t)(rv.y & 0xffff));
-                v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
+                for (int m = 0; m < MT; ++m) {
+                    const u32x2 rv = rp[m];
+                    v[m * 4 + 0] += bf16_to_f32((bf16_t)(rv.x & 0xffff));
+                    v[m * 4 + 1] += bf16_to_f32((bf16_t)(rv.x >> 16));
+                    v[m * 4 + 2] += bf16_to_f32((bf16_t)(rv.y & 0xffff));
+                    v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
+                }
             }
-        }
-        if (a.relu) {
+            if (a.relu) {
 #pragma unroll
-            for (int i = 0; i < 4 * MT; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-        }
-        if (MT == 1) {
-            *(u32x2*)(a.dst + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-        } else {
+                for (int i = 0; i < 4 * MT; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            }
+            if (MT == 1) {
+                *(u32x2*)(a.dst + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            } else {
 #pragma unroll
-            for (int q = 0; q < MT / 2; ++q)
-                *(u32x4*)(a.dst + o + q * 8) = u32x4{pack2(v[q * 8 + 0], v[q * 8 + 1]), pack2(v[q * 8 + 2], v[q * 8 + 3]),
-                                                    pack2(v[q * 8 + 4], v[q * 8 + 5]), pack2(v[q * 8 + 6], v[q * 8 + 7])};
+                for (int q = 0; q < MT / 2; ++q)
+                    *(u32x4*)(a.dst + o + q * 8) = u32x4{pack2(v[q * 8 + 0], v[q * 8 + 1]), pack2(v[q * 8 + 2], v[q * 8 + 3]),
+                                                        pack2(v[q * 8 + 4], v[q * 8 + 5]), pack2(v[q * 8 + 6], v[q * 8 + 7])};
+            }
         }
     }
 }
@@ -349,7 +386,12 @@ struct BBArgs {
     int H, W, tiles_x;
 };
 
-template <int C> __device__ __forceinline__ int bb_off(int pix, int c8) { return pix * C + (c8 << 3); }
+// element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
+// with bits 1..2 of the column (conflict-free ds_read_b128, see lds_off)
+template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
+    if (C == 32) return pix * 32 + ((c8 ^ ((x >> 1) & 3)) << 3);
+    return pix * C + (c8 << 3);
+}
 
 // One 3x3 conv of the chain.  Input buffer: row stride RWI pixels, region origin at (IOFF,IOFF).  Output region RHO x RWO.
 // SECOND: second conv of a BasicBlock -> adds the block input (buffer s_res, row stride RWR, origin offset ROFF) and the
@@ -377,16 +419,19 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         int dy, dx, c8;
         if (C == 16) { int tap = 2 * s + (g >> 1); tap = tap > 8 ? 8 : tap; dy = tap / 3; dx = tap % 3; c8 = g & 1; }
         else { dy = s / 3; dx = s % 3; c8 = g; }
-        koff[s] = (dy * RWI + dx) * C + c8 * 8;
+        // the column swizzle depends only on (n + dx + IOFF) mod 8: 16-pixel groups start at multiples of 16
+        koff[s] = (dy * RWI + dx) * C + (C == 32 ? ((c8 ^ (((n + dx + IOFF) >> 1) & 3)) << 3) : c8 * 8);
     }
     // lane's pixel in the last (possibly ragged) group is clamped so that reads stay inside the buffer
     constexpr int XLAST = (XT - 1) * 16;
     const int nl = (XLAST + n < RWO) ? n : (RWO - 1 - XLAST);
-    const int ch_off = (C == 16) ? ((g >> 1) * 8 + (g & 1) * 4) : g * 8;      // lane's first output channel
+    const int ch_off = (C == 16) ? ((g >> 1) * 8 + (g & 1) * 4) : 0;          // lane's first output channel (C=32: chunk g, swizzled below)
+    const int res_ch = (C == 32) ? ((g ^ (((n + ROFF) >> 1) & 3)) << 3) : ch_off;
+    const int out_ch = (C == 32) ? ((g ^ (((n + OOFF) >> 1) & 3)) << 3) : ch_off;
     for (int y = wave; y < RHO; y += 8) {
         const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
         const bf16_t* rp0 = row + n * C;
-        const bf16_t* rpl = row + (XLAST + nl) * C;
+        const bf16_t* rpl = row + (XLAST + nl) * C;      // clamped lanes (x >= RWO) may read a wrong chunk of an in-bounds pixel: their results are discarded
         f32x4 acc[XT][MT];
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt)
@@ -415,7 +460,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r] + bias[m * 4 + r];
             if (SECOND) {       // + block input; the lane's 4*MT channels start at g*4*MT
-                const bf16_t* rp = s_res + ((y + ROFF) * RWR + x + ROFF) * C + ch_off;
+                const bf16_t* rp = s_res + ((y + ROFF) * RWR + x + ROFF) * C + res_ch;
                 if (C == 16) {
                     const u32x2 rv = *(const u32x2*)rp;
                     v[0] += bf16_to_f32((bf16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(rv.x >> 16));
@@ -438,7 +483,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                     else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
                 }
             } else {
-                bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + ch_off;
+                bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + out_ch;
                 if (C == 16) *(u32x2*)o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
                 else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             }
@@ -463,7 +508,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
-        *(u32x4*)(bufA + bb_off<C>(pix, c8)) = v;
+        *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v;
     }
     __syncthreads();
     if (NB == 1) {
@@ -591,7 +636,8 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, 
         return TTUP_OK;
     }
     TTUP_REQUIRE(c0 % 16 == 0 && c1 % 32 == 0, TTUP_EINVAL, "channel counts %d+%d unsupported", c0, c1);
-    const int ck = (c0 % 32 == 0) ? 32 : 16;
+    int ck = (c0 % 32 == 0) ? 32 : 16;
+    if (getenv("TTUP_FORCE_CK16") && k == 3 && c1 == 0 && a.stride == 1 && c0 == 64 && cout == 64) ck = 16;      // experiment: smaller LDS footprint, more workgroups per CU
     TTUP_REQUIRE(ck == 32 || (c1 == 0 && k == 3), TTUP_EINVAL, "16-channel chunks only for single-source 3x3");
     const int mt = cout / 16, ksteps = ck == 32 ? taps : (taps + 1) / 2, nchunk = cin_total / ck;
     std::vector<bf16_t> w((size_t)nchunk * ksteps * mt * 64 * 8);
@@ -631,14 +677,19 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     a.H = l.h; a.W = l.w; a.OH = (l.h + S - 1) / S; a.OW = (l.w + S - 1) / S;
     a.tiles_x = cdiv(a.OW, TW);
     a.relu = l.relu;
-    const int tiles = a.tiles_x * cdiv(a.OH, TH);
+    a.tiles_per_img = a.tiles_x * cdiv(a.OH, TH);
+    a.total_tiles = a.tiles_per_img * l.batch;
+    // persistent grid: as many workgroups as can be resident (LDS-limited), each walks its share of the tiles
+    const int per_cu = (int)((160 * 1024) / SMEM) > 4 ? 4 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
+    const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
         TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW>), dim3(tiles, l.batch), dim3(256), SMEM, st, a);
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW>), dim3(grid), dim3(256), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
