@@ -222,16 +222,48 @@ __device__ __forceinline__ int st_off(int pix, int c8) { return pix * 32 + ((c8 
 __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     constexpr int IH = 10, IW = 34, NPIX = IH * IW;            // 340 halo pixels
     constexpr int NT1 = 22;                                     // 16-pixel groups covering the halo tile
+    constexpr int W1_U = 3 * 8 * 64, W5_U = 4 * 9 * 64, W6H_U = 2 * 9 * 2 * 64;      // 16-byte units
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]           87,040 B
-    bf16_t* s_st = s_l1 + NPIX * 128;                           // [340][32]            21,760 B
-    bf16_t* s_w = s_st + NPIX * 32;                             // weights              36,864 B
+    bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]              87,040 B
+    bf16_t* s_w1 = s_l1 + NPIX * 128;                           // phase-1 weights         24,576 B
+    bf16_t* s_w = s_w1 + W1_U * 8;                              // phase-2 weights         36,864 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int oy0 = (tile / a.tiles_x) * 8, ox0 = (tile % a.tiles_x) * 32;
     const int gy0 = oy0 - 1, gx0 = ox0 - 1;
 
+    // ---------------- issue every global load of the tile up front: W1, the phase-1 pixel fragments (straight from
+    // global memory: a 1x1 conv needs no halo reuse, and 16 pixels x 64 B are contiguous in NHWC), W5 and half of W6
+    u32x4 pw1[3], pw5[5], pw6[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pw1[k] = ((const u32x4*)a.w1)[tid + k * 512];
+    u32x4 pb[3][3];
+    bool p_in[3];
+    int p_pix[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int j = wave + 8 * t;
+        int pix = j * 16 + n;
+        pix = pix < NPIX ? pix : NPIX - 1;
+        p_pix[t] = pix;
+        const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+        p_in[t] = j < NT1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const size_t gp = (size_t)(b * a.H + gy) * a.W + gx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pb[t][c] = u32x4{0u, 0u, 0u, 0u};
+            if (p_in[t]) pb[t][c] = (c == 0) ? *(const u32x4*)(a.a2 + gp * 32 + g * 8) : *(const u32x4*)(a.t2 + gp * 64 + (c - 1) * 32 + g * 8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W5_U) pw5[k] = ((const u32x4*)a.w5)[u]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) pw6[k] = ((const u32x4*)a.w6)[u]; }
+
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ((u32x4*)s_w1)[tid + k * 512] = pw1[k];
+    __syncthreads();
     // ---------------- phase 1: layer1 halo tile
     {
         f32x4 acc[3][8];
@@ -239,30 +271,15 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int u = tid; u < 3 * 8 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w1)[u];
+#pragma unroll
         for (int chunk = 0; chunk < 3; ++chunk) {
-            const bf16_t* src = chunk == 0 ? a.a2 : a.t2;
-            const int csrc = chunk == 0 ? 32 : 64, ch0 = chunk == 2 ? 32 : 0;
-            __syncthreads();
-            for (int u = tid; u < NPIX * 4; u += 512) {
-                const int c8 = u & 3, pix = u >> 2;
-                const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
-                *(u32x4*)(s_st + st_off(pix, c8)) = v;
-            }
-            __syncthreads();
             bf16x8 af[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) af[m] = *(const bf16x8*)(s_w + ((chunk * 8 + m) * 64 + lane) * 8);
+            for (int m = 0; m < 8; ++m) af[m] = *(const bf16x8*)(s_w1 + ((chunk * 8 + m) * 64 + lane) * 8);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int j = wave + 8 * t;
-                if (j < NT1) {
-                    int pix = j * 16 + n;
-                    pix = pix < NPIX ? pix : NPIX - 1;
-                    const bf16x8 bfr = *(const bf16x8*)(s_st + st_off(pix, g));
+                if (wave + 8 * t < NT1) {
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[t][m], 0, 0, 0);
                 }
@@ -275,8 +292,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t, pix = j * 16 + n;
             if (j < NT1 && pix < NPIX) {
-                const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
-                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool inside = p_in[t];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[8];
@@ -290,10 +306,14 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W5_U) ((u32x4*)s_w)[u] = pw5[k]; }
     __syncthreads();
+    // second half of W6 travels while phase 2a computes
+    u32x4 pw6b[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) pw6b[k] = ((const u32x4*)a.w6)[W6H_U + u]; }
     // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
-    for (int u = tid; u < 4 * 9 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w5)[u];
-    __syncthreads();
     {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -325,9 +345,11 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     {
         const int r = wave >> 1, m = wave & 1;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int half = 0; half < 2; ++half) {
             __syncthreads();
-            for (int u = tid; u < 2 * 9 * 2 * 64; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.w6)[half * (2 * 9 * 2 * 64) + u];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) ((u32x4*)s_w)[u] = half == 0 ? pw6[k] : pw6b[k]; }
             __syncthreads();
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
@@ -362,7 +384,7 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
     a.w1 = (const bf16_t*)p1.w_dev; a.b1 = p1.bias_dev; a.w5 = (const bf16_t*)p5.w_dev; a.b5 = p5.bias_dev;
     a.w6 = (const bf16_t*)p6.w_dev; a.b6 = p6.bias_dev; a.b0 = (bf16_t*)b0; a.b1o = (bf16_t*)b1;
     a.H = h; a.W = w; a.tiles_x = cdiv(w, 32);
-    constexpr size_t SMEM = (size_t)(340 * 128 + 340 * 32 + 4 * 9 * 64 * 8) * 2;
+    constexpr size_t SMEM = (size_t)(340 * 128 + 3 * 8 * 64 * 8 + 4 * 9 * 64 * 8) * 2;
     static bool attr_done = false;
     if (!attr_done) {
         TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bneck_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
