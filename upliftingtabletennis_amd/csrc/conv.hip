@@ -54,20 +54,21 @@ __device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
 // item i+1 (halo tile chunk + that chunk's weight fragments) are issued into registers BEFORE the MFMA loop of item i
 // and written to LDS after it, so HBM/L2 latency hides behind the matrix work (single LDS buffer, two barriers per item).
 // Single-chunk convs keep their weights resident in LDS across all tiles of the workgroup.
-template <int CK, int COUT, int KS, int S, int TH, int TW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
+template <int CK, int COUT, int KS, int S, int TH, int TW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
+    constexpr int NTHR = NW * 64;
     constexpr int MT = COUT / 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
     constexpr int TAPS = KS * KS;
     constexpr int KSTEPS = (CK == 32) ? TAPS : (TAPS + 1) / 2;
     constexpr int NTW = TW / 16;
-    constexpr int NT = TH * NTW / 4;          // N-tiles per wave
+    constexpr int NT = TH * NTW / NW;         // N-tiles per wave
     constexpr int PAD = KS / 2;
     constexpr int IN_ELEMS = IH * IW * CK;
     constexpr int W_ELEMS = KSTEPS * MT * 64 * 8;
-    constexpr int IN_UNITS = IH * IW * (CK / 8), IN_PT = (IN_UNITS + 255) / 256;
-    constexpr int W_UNITS = W_ELEMS / 8, W_PT = (W_UNITS + 255) / 256;
-    static_assert(TH * NTW % 4 == 0, "tile must split over 4 waves");
+    constexpr int IN_UNITS = IH * IW * (CK / 8), IN_PT = (IN_UNITS + NTHR - 1) / NTHR;
+    constexpr int W_UNITS = W_ELEMS / 8, W_PT = (W_UNITS + NTHR - 1) / NTHR;
+    static_assert(TH * NTW % NW == 0, "tile must split over the waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* s_in = (bf16_t*)smem;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
         const int ch0 = (first ? chunk : chunk - a.nchunk0) * CK;
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 256;
+            const int u = tid + k * NTHR;
             const int c8 = u % (CK / 8), pix = u / (CK / 8);
             const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
             pin[k] = u32x4{0u, 0u, 0u, 0u};
@@ -100,18 +101,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKArgs a) {
         if (nchunk > 1 || item == 0) {
             const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
 #pragma unroll
-            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 256; if (u < W_UNITS) pw[k] = wsrc[u]; }
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * NTHR; if (u < W_UNITS) pw[k] = wsrc[u]; }
         }
     };
     auto commit = [&](int item) {
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 256;
+            const int u = tid + k * NTHR;
             if (u < IN_UNITS) { const int c8 = u % (CK / 8), pix = u / (CK / 8); *(u32x4*)(s_in + lds_off<CK, IW>(pix / IW, pix % IW, c8)) = pin[k]; }
         }
         if (nchunk > 1 || item == 0) {
 #pragma unroll
-            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 256; if (u < W_UNITS) ((u32x4*)s_w)[u] = pw[k]; }
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * NTHR; if (u < W_UNITS) ((u32x4*)s_w)[u] = pw[k]; }
         }
     };
 
@@ -685,7 +686,7 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, 
 }
 
 // ------------------------------------------------------------------ launch
-template <int CK, int COUT, int KS, int S, int TH, int TW>
+template <int CK, int COUT, int KS, int S, int TH, int TW, int NW>
 static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     constexpr int MT = COUT / 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -706,23 +707,32 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW>,
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
         attr_done = true;
     }
     if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW>), dim3(grid), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW>), dim3(grid), dim3(NW * 64), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
 
 template <int CK, int KS, int S, int TH, int TW>
 static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
+    static const int nw = getenv("TTUP_CONV_WAVES") ? atoi(getenv("TTUP_CONV_WAVES")) : 8;
+    if (nw == 8) {
+        switch (p.cout) {
+            case 16: return launch_mfma<CK, 16, KS, S, TH, TW, 8>(p, l, st);
+            case 32: return launch_mfma<CK, 32, KS, S, TH, TW, 8>(p, l, st);
+            case 64: return launch_mfma<CK, 64, KS, S, TH, TW, 8>(p, l, st);
+            case 128: return launch_mfma<CK, 128, KS, S, TH, TW, 8>(p, l, st);
+        }
+    }
     switch (p.cout) {
-        case 16: return launch_mfma<CK, 16, KS, S, TH, TW>(p, l, st);
-        case 32: return launch_mfma<CK, 32, KS, S, TH, TW>(p, l, st);
-        case 64: return launch_mfma<CK, 64, KS, S, TH, TW>(p, l, st);
-        case 128: return launch_mfma<CK, 128, KS, S, TH, TW>(p, l, st);
+        case 16: return launch_mfma<CK, 16, KS, S, TH, TW, 4>(p, l, st);
+        case 32: return launch_mfma<CK, 32, KS, S, TH, TW, 4>(p, l, st);
+        case 64: return launch_mfma<CK, 64, KS, S, TH, TW, 4>(p, l, st);
+        case 128: return launch_mfma<CK, 128, KS, S, TH, TW, 4>(p, l, st);
     }
     set_error("conv: cout %d unsupported", p.cout);
     return TTUP_EINVAL;
