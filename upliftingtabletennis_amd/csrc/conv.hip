@@ -895,13 +895,14 @@ int launch_head(const void* src, const float* w_dev, float bias, float* heat, in
 // oracle/glue_ref.py for the algorithm statement.  Parity of the resize is unpinned (cv2 absent offline).
 struct PreArgs {
     const uint8_t* frames; void* out; int src_h, src_w, dst_h, dst_w, first_triple, n_triples, layout; long long total;
-    float scale_x, scale_y;
+    double scale_x, scale_y;
+    const float* lut;      // [3][256]: (v/255 - mean[c]) / std[c] evaluated in fp64 on the host, rounded to fp32
 };
 
 __device__ __forceinline__ int cv_round(float v) { return (int)rintf(v); }
 
-__device__ __forceinline__ void axis_tap_x(int d, float scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
-    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+__device__ __forceinline__ void axis_tap_x(int d, double scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
     if (s < 0) { f = 0.f; s = 0; }
@@ -909,8 +910,8 @@ __device__ __forceinline__ void axis_tap_x(int d, float scale, int src_n, int& i
     i0 = s; i1 = s + 1 < src_n ? s + 1 : src_n - 1;
     c1 = cv_round(f * 2048.f); c0 = cv_round((1.f - f) * 2048.f);
 }
-__device__ __forceinline__ void axis_tap_y(int d, float scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
-    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+__device__ __forceinline__ void axis_tap_y(int d, double scale, int src_n, int& i0, int& i1, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
     i0 = s < 0 ? 0 : (s > src_n - 1 ? src_n - 1 : s);
@@ -927,7 +928,6 @@ __global__ void preprocess_kernel(PreArgs a) {
     long long p = i / a.dst_w;
     const int y = (int)(p % a.dst_h);
     const int t = (int)(p / a.dst_h);
-    const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
     const bool same = a.src_h == a.dst_h && a.src_w == a.dst_w;
     int x0 = x, x1 = x, a0 = 2048, a1 = 0, y0 = y, y1 = y, b0 = 2048, b1 = 0;
     if (!same) {
@@ -947,7 +947,7 @@ __global__ void preprocess_kernel(PreArgs a) {
                 v = (((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2) >> 2;
                 v = v < 0 ? 0 : (v > 255 ? 255 : v);
             }
-            vals[f * 3 + c] = (float)(((double)v / 255.0 - mean[c]) / sd[c]);
+            vals[f * 3 + c] = a.lut[c * 256 + v];
         }
     }
     const size_t hw = (size_t)a.dst_h * a.dst_w, pix = (size_t)y * a.dst_w + x;
@@ -956,7 +956,13 @@ __global__ void preprocess_kernel(PreArgs a) {
         for (int c = 0; c < 9; ++c) o[c * hw] = vals[c];
     } else {
         T* o = (T*)a.out + ((size_t)t * hw + pix) * 16;
-        for (int c = 0; c < 16; ++c) st(o + c, c < 9 ? vals[c] : 0.f);
+        if (sizeof(T) == 2) {
+            u32x4* o4 = (u32x4*)o;
+            o4[0] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
+            o4[1] = u32x4{pack2(vals[8], 0.f), 0u, 0u, 0u};
+        } else {
+            for (int c = 0; c < 16; ++c) st(o + c, c < 9 ? vals[c] : 0.f);
+        }
     }
 }
 
@@ -967,8 +973,17 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     a.frames = frames; a.out = out; a.src_h = src_h; a.src_w = src_w; a.dst_h = dst_h; a.dst_w = dst_w;
     a.first_triple = first_triple; a.n_triples = n_triples; a.layout = out_layout;
     a.total = (long long)n_triples * dst_h * dst_w;
-    a.scale_x = (float)((double)src_w / dst_w); a.scale_y = (float)((double)src_h / dst_h);
+    a.scale_x = (double)src_w / dst_w; a.scale_y = (double)src_h / dst_h;
     if (a.total == 0) return TTUP_OK;
+    static float* lut_dev = nullptr;           // built once per process (per device 0 context; inputs are device-independent)
+    if (!lut_dev) {
+        const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+        float h[3 * 256];
+        for (int c = 0; c < 3; ++c) for (int v = 0; v < 256; ++v) h[c * 256 + v] = (float)(((double)v / 255.0 - mean[c]) / sd[c]);
+        TTUP_HIP_CHECK(hipMalloc((void**)&lut_dev, sizeof h));
+        TTUP_HIP_CHECK(hipMemcpy(lut_dev, h, sizeof h, hipMemcpyHostToDevice));
+    }
+    a.lut = lut_dev;
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
     if (dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32)
         hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);

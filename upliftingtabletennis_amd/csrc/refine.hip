@@ -120,6 +120,85 @@ __global__ void fit_kernel(const long long* __restrict__ argmax, const float* __
     out[(size_t)i * 3 + 2] = 1.0;      // visibility: always 1 (helper_balldetection.py:13,82 / helper_tabledetection.py:142)
 }
 
+// ---- fused tail of the CNN: y = relu(base + sum up(t_k)) (stage-4 fuse output 0, wasb.py:236-243), heat = w . bf16(y) + b
+// (final_layers[0] channel 1, wasb.py:484,606) and the per-workgroup argmax partial, in one pass over the pixels.
+// y is rounded to bf16 before the dot product exactly as the unfused path stores it, so heatmaps are bit-identical.
+struct UpsumHeadArgs {
+    const bf16_t* base; const bf16_t* t[3]; int shift[3]; int n;
+    const float* w; float bias;
+    float* heat; float* pv; long long* pi;
+    int H, W, nblk;
+};
+
+__device__ __forceinline__ void add8(float* v, const bf16_t* p) {
+    const uint4 r = *(const uint4*)p;
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w[k] >> 16)); }
+}
+
+__global__ __launch_bounds__(256) void upsum_head_kernel(UpsumHeadArgs a) {
+    const int map = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const long long hw = (long long)a.H * a.W;
+    const long long e = (long long)blk * 256 + tid;
+    Best b; b.v = -INFINITY; b.i = 0x7fffffffffffffffLL;
+    if (e < hw) {
+        const int y = (int)(e / a.W), x = (int)(e % a.W);
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        const bf16_t* bp = a.base + ((size_t)map * hw + e) * 16;
+        add8(v, bp); add8(v + 8, bp + 8);
+        for (int t = 0; t < a.n; ++t) {
+            const int sh = a.shift[t], hh = a.H >> sh, ww = a.W >> sh;
+            const bf16_t* tp = a.t[t] + (((size_t)map * hh + (y >> sh)) * ww + (x >> sh)) * 16;
+            add8(v, tp); add8(v + 8, tp + 8);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float r = v[k] > 0.f ? v[k] : 0.f;
+            acc = fmaf(bf16_to_f32(f32_to_bf16(r)), a.w[k], acc);
+        }
+        acc += a.bias;
+        a.heat[(size_t)map * hw + e] = acc;
+        b.v = acc; b.i = e;
+    }
+    b = wave_best(b);
+    __shared__ float sv[4];
+    __shared__ long long si[4];
+    if ((tid & 63) == 0) { sv[tid >> 6] = b.v; si[tid >> 6] = b.i; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k) if (better(sv[k], si[k], b.v, b.i)) { b.v = sv[k]; b.i = si[k]; }
+        a.pv[(size_t)map * a.nblk + blk] = b.v;
+        a.pi[(size_t)map * a.nblk + blk] = b.i;
+    }
+}
+
+// partials scratch needed by launch_upsum_head for `n_maps` heatmaps
+size_t upsum_head_ws_bytes(int n_maps, int H, int W) { return (size_t)n_maps * (((size_t)H * W + 255) / 256) * 12 + 64; }
+
+int launch_upsum_head(const void* base, const void* const* terms, const int* shifts, int n_terms, const float* w_dev, float bias,
+                      float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long long hw = (long long)H * W;
+    const int nblk = (int)((hw + 255) / 256);
+    TTUP_REQUIRE(ws && ws_bytes >= upsum_head_ws_bytes(n_maps, H, W), TTUP_EINVAL, "upsum_head: workspace too small");
+    UpsumHeadArgs a;
+    a.base = (const bf16_t*)base; a.n = n_terms;
+    for (int k = 0; k < 3; ++k) { a.t[k] = k < n_terms ? (const bf16_t*)terms[k] : nullptr; a.shift[k] = k < n_terms ? shifts[k] : 0; }
+    a.w = w_dev; a.bias = bias; a.heat = heat; a.H = H; a.W = W; a.nblk = nblk;
+    a.pi = (long long*)ws; a.pv = (float*)(a.pi + (size_t)n_maps * nblk);
+    hipLaunchKernelGGL(upsum_head_kernel, dim3(nblk, n_maps), dim3(256), 0, st, a);
+    TTUP_LAUNCH_CHECK();
+    if (argmax || win) {
+        TTUP_REQUIRE(argmax && win, TTUP_EINVAL, "upsum_head: argmax and window outputs come together");
+        hipLaunchKernelGGL(argmax_finish_kernel, dim3(n_maps), dim3(64), 0, st, heat, H, W, nblk, a.pv, a.pi, argmax, win);
+        TTUP_LAUNCH_CHECK();
+    }
+    return TTUP_OK;
+}
+
 static int pick_nblk(int n_maps, long long hw) {
     long long nblk = 2048 / (n_maps > 0 ? n_maps : 1);
     const long long cap = hw / 4096 > 0 ? hw / 4096 : 1;     // at least 16 KB per workgroup

@@ -17,6 +17,9 @@
 #include <vector>
 
 namespace ttup {
+size_t upsum_head_ws_bytes(int n_maps, int H, int W);
+int launch_upsum_head(const void* base, const void* const* terms, const int* shifts, int n_terms, const float* w_dev, float bias,
+                      float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
 int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
 }
 
@@ -27,7 +30,7 @@ namespace {
 struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
 
 struct Op {
-    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN } kind = CONV;
+    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD } kind = CONV;
     int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
     int conv = -1;            // index into packed convs
     int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output
@@ -57,6 +60,7 @@ struct ttup_wasb {
     void* refine_ws = nullptr; size_t refine_ws_bytes = 0;
     long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
     int last_batch = 0;
+    bool fused_head = false;      // last op computes the heatmap and the argmax partials itself (bf16 path)
 
     size_t esize() const { return dtype == TTUP_DTYPE_F32 ? 4 : 2; }
     ~ttup_wasb() {
@@ -289,8 +293,13 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     net->taps["stage3_0"] = ys[0]; net->taps["stage3_1"] = ys[1]; net->taps["stage3_2"] = ys[2];
     xs = {ys[0], ys[1], ys[2], b.conv(ys[2], 128, 3, 2, 1)};
     ys = b.stage(xs, 1);
-    net->taps["stage4_0"] = ys[0];
     net->t_out = ys[0];
+    if (net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE") && net->ops.back().kind == Op::UPSUM && net->ops.back().dst == ys[0]) {
+        net->ops.back().kind = Op::UPSUM_HEAD;        // stage-4 output 0 is consumed in registers and never stored
+        net->fused_head = true;
+    } else {
+        net->taps["stage4_0"] = ys[0];
+    }
     if (b.rc) return b.rc;
     TTUP_REQUIRE(b.cursor == folded.size() - 1, TTUP_EFORMAT, "wasb: consumed %zu of %zu convs", b.cursor, folded.size() - 1);
     return TTUP_OK;
@@ -306,6 +315,8 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
             if (rc) return rc;
+        } else if (op.kind == Op::UPSUM_HEAD) {
+            continue;       // launched by forward_impl, which knows the output buffers
         } else if (op.kind == Op::BB_CHAIN) {
             const Tensor& s = net->tensors[op.src0];
             const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -341,6 +352,18 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
         rc = run_ops(net, mb, st);
         if (rc) return rc;
         float* heat = heat_dev ? heat_dev + (size_t)b0 * hw : net->heat_scratch;
+        if (net->fused_head) {
+            const Op& op = net->ops.back();
+            const void* terms[3] = {nullptr, nullptr, nullptr};
+            for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
+            const bool peaks = argmax_dev || win_dev;
+            long long* am = peaks ? (argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch) : nullptr;
+            float* wn = peaks ? (win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch) : nullptr;
+            rc = launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, H, W,
+                                   am, wn, net->refine_ws, net->refine_ws_bytes, st);
+            if (rc) return rc;
+            continue;
+        }
         rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_bias, heat, mb, H, W, 16, net->dtype, st);
         if (rc) return rc;
         if (argmax_dev || win_dev) {
@@ -387,6 +410,7 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     const size_t hw = (size_t)height * width;
     TTUP_HIP_CHECK(hipMalloc((void**)&net->heat_scratch, (size_t)net->micro * hw * sizeof(float)));
     net->refine_ws_bytes = ttup_refine_workspace_bytes(net->micro, height, width);
+    if (upsum_head_ws_bytes(net->micro, height, width) > net->refine_ws_bytes) net->refine_ws_bytes = upsum_head_ws_bytes(net->micro, height, width);
     TTUP_HIP_CHECK(hipMalloc(&net->refine_ws, net->refine_ws_bytes));
     TTUP_HIP_CHECK(hipMalloc((void**)&net->argmax_scratch, (size_t)net->micro * sizeof(long long)));
     TTUP_HIP_CHECK(hipMalloc((void**)&net->win_scratch, (size_t)net->micro * 9 * sizeof(float)));
