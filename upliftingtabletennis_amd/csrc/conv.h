@@ -30,6 +30,8 @@ struct ConvLaunch {
     void* dst = nullptr;          // NHWC cout channels
     int batch = 0, h = 0, w = 0;  // input spatial size
     int relu = 0;
+    const PackedConv* follow = nullptr;   // bf16 only: fused 1x1 follower (64 -> 32, ReLU) applied to dst, written to dst2
+    void* dst2 = nullptr;
 };
 
 // host-side packing (called from ttup_wasb_create)

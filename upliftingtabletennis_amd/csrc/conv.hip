@@ -31,6 +31,8 @@ struct ConvKArgs {
     int H, W, OH, OW;
     int tiles_x, tiles_per_img, total_tiles;
     int relu;
+    // fused 1x1 follower (F11): dst11 = relu(W11 . dst + b11), 64 -> 32 channels
+    const bf16_t* w11; const float* bias11; bf16_t* dst11;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -54,7 +56,7 @@ __device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
 // item i+1 (halo tile chunk + that chunk's weight fragments) are issued into registers BEFORE the MFMA loop of item i
 // and written to LDS after it, so HBM/L2 latency hides behind the matrix work (single LDS buffer, two barriers per item).
 // Single-chunk convs keep their weights resident in LDS across all tiles of the workgroup.
-template <int CK, int COUT, int KS, int S, int TH, int TW, int NW>
+template <int CK, int COUT, int KS, int S, int TH, int TW, int NW, bool F11>
 __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int MT = COUT / 16;
@@ -119,6 +121,18 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
     float bias[4 * MT];
 #pragma unroll
     for (int i = 0; i < 4 * MT; ++i) bias[i] = a.bias[g * 4 * MT + i];
+
+    // fused follower: its 4 weight fragments (2 k-steps x 2 m-tiles) stay in registers for the whole kernel
+    bf16x8 af11[2][2];
+    float bias11[8];
+    if (F11) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af11[k][m] = *(const bf16x8*)(a.w11 + ((k * 2 + m) * 64 + lane) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bias11[i] = a.bias11[g * 8 + i];
+    }
 
     f32x4 acc[MT][NT];
     if (n_items > 0) issue(0);
@@ -196,6 +210,47 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                 for (int q = 0; q < MT / 2; ++q)
                     *(u32x4*)(a.dst + o + q * 8) = u32x4{pack2(v[q * 8 + 0], v[q * 8 + 1]), pack2(v[q * 8 + 2], v[q * 8 + 3]),
                                                         pack2(v[q * 8 + 4], v[q * 8 + 5]), pack2(v[q * 8 + 6], v[q * 8 + 7])};
+            }
+        }
+        if (F11) {
+            // ---- fused 1x1 follower on the tile just produced (Bottleneck conv1, wasb.py:88-90): the bf16 tile goes through
+            // LDS (pixel-major, 128 B per pixel, chunks XOR-swizzled by the pixel index) and comes back as the B operand
+            static_assert(!F11 || (COUT == 64 && TH * TW * 64 <= IN_ELEMS + W_ELEMS), "follower needs a 64-channel tile that fits the staging area");
+            bf16_t* s_t = s_in;
+            __syncthreads();                       // every wave is done with the staging area
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int nt = wave * NT + t;
+                const int p = (nt / NTW) * TW + (nt % NTW) * 16 + n;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float x = acc[2 * q + (i >> 2)][t][i & 3] + bias[q * 8 + i];
+                        v[i] = (a.relu && !(x > 0.f)) ? 0.f : x;
+                    }
+                    *(u32x4*)(s_t + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int nt = wave * NT + t;
+                const int p = (nt / NTW) * TW + (nt % NTW) * 16 + n;
+                f32x4 c11[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bf16x8 bfr = *(const bf16x8*)(s_t + p * 64 + (((4 * k + g) ^ (p & 7)) << 3));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) c11[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af11[k][m], bfr, c11[m], 0, 0, 0);
+                }
+                const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
+                if (oy >= a.OH || ox >= a.OW) continue;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float x = c11[i >> 2][i & 3] + bias11[i]; v[i] = x > 0.f ? x : 0.f; }
+                *(u32x4*)(a.dst11 + ((size_t)(b * a.OH + oy) * a.OW + ox) * 32 + g * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
             }
         }
     }
@@ -686,7 +741,7 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, 
 }
 
 // ------------------------------------------------------------------ launch
-template <int CK, int COUT, int KS, int S, int TH, int TW, int NW>
+template <int CK, int COUT, int KS, int S, int TH, int TW, int NW, bool F11 = false>
 static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     constexpr int MT = COUT / 16;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -700,6 +755,11 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     a.H = l.h; a.W = l.w; a.OH = (l.h + S - 1) / S; a.OW = (l.w + S - 1) / S;
     a.tiles_x = cdiv(a.OW, TW);
     a.relu = l.relu;
+    a.w11 = nullptr; a.bias11 = nullptr; a.dst11 = nullptr;
+    if (F11) {
+        TTUP_REQUIRE(l.follow && l.follow->cout == 32 && l.follow->cin_total == 64 && l.follow->k == 1 && l.follow->ck == 32 && l.dst2, TTUP_EINVAL, "conv: bad fused 1x1 follower");
+        a.w11 = (const bf16_t*)l.follow->w_dev; a.bias11 = l.follow->bias_dev; a.dst11 = (bf16_t*)l.dst2;
+    }
     a.tiles_per_img = a.tiles_x * cdiv(a.OH, TH);
     a.total_tiles = a.tiles_per_img * l.batch;
     // persistent grid: as many workgroups as can be resident (LDS-limited), each walks its share of the tiles
@@ -707,12 +767,12 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW>,
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
         attr_done = true;
     }
     if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW>), dim3(grid), dim3(NW * 64), SMEM, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>), dim3(grid), dim3(NW * 64), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -751,6 +811,10 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         hipLaunchKernelGGL(conv_direct_f32_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, a);
         TTUP_LAUNCH_CHECK();
         return TTUP_OK;
+    }
+    if (l.follow) {
+        TTUP_REQUIRE(p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64, TTUP_EINVAL, "conv: fused follower needs a 3x3 s1 conv with 64 outputs");
+        return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);
     }
     if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
     if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);

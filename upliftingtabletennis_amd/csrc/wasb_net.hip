@@ -33,7 +33,7 @@ struct Op {
     enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD } kind = CONV;
     int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
     int conv = -1;            // index into packed convs
-    int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output
+    int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output; CONV: fused 1x1 follower (conv2) -> dst2
     int src0 = -1, src1 = -1, residual = -1, dst = -1;
     int relu = 0;
     int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
@@ -258,12 +258,19 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
         Op op; op.conv = pc; op.src0 = net->t_input; op.dst = dst; op.relu = 1; net->ops.push_back(op);
         x = dst; net->taps["stem1"] = x;
     }
+    const bool fuse_c1 = net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE");
     x = b.conv(x, 64, 3, 1, 1); net->taps["stem2"] = x;
+    const size_t stem2_op = net->ops.size() - 1;
     // layer1: Bottleneck(64 -> 32 -> 128) (wasb.py:85-105), conv3 + downsample fused into one two-source 1x1 conv;
     // transition1 (wasb.py:454-459).  bf16: both run in one kernel and the 128-channel tensor stays in LDS.
     std::vector<int> xs(2);
     {
-        const int a1 = b.conv(x, 32, 1, 1, 1);
+        int a1;
+        if (fuse_c1) {       // Bottleneck conv1 (1x1 64->32 + ReLU) rides in the epilogue of stem conv2
+            const int pc1 = b.pack(b.next(32, 64, 1, 1), nullptr, 0);
+            a1 = b.new_tensor(32, H, W);
+            net->ops[stem2_op].conv2 = pc1; net->ops[stem2_op].dst2 = a1;
+        } else a1 = b.conv(x, 32, 1, 1, 1);
         const int a2 = b.conv(a1, 32, 3, 1, 1);
         const FoldedConv& c3 = b.next(128, 32, 1, 1);
         const FoldedConv& ds = b.next(128, 64, 1, 1);
@@ -313,6 +320,7 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             l.src0 = s.ptr; l.src1 = op.src1 >= 0 ? net->tensors[op.src1].ptr : nullptr;
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
+            if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
             if (rc) return rc;
         } else if (op.kind == Op::UPSUM_HEAD) {
@@ -398,7 +406,7 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     net->H = height; net->W = width; net->max_batch = max_batch; net->dtype = dtype; net->in_ch = in_ch;
     // micro-batch: enough tiles to fill 256 CUs, small enough that layer outputs stay cache-friendly
     const char* env = getenv("TTUP_MICRO_BATCH");
-    int micro = env ? atoi(env) : 4;
+    int micro = env ? atoi(env) : 8;
     if (micro < 1) micro = 1;
     net->micro = micro < max_batch ? micro : max_batch;
     rc = build(net.get(), folded);
