@@ -85,6 +85,18 @@ def roofline(pipe):
          'launch_ms': round(dom['ms'], 4), 'micro_batch': dom['batch'],
          'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                          'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    # runs, gfx950 correction; tools/pmc_traffic.py).  Only attached when kernel and launch geometry match.
+    try:
+        key = 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else ('bb_chain_kernel' if dom['kind'] == 'bb_chain' else 'conv_mfma_kernel')
+        tiles = ((dom['h'] + 7) // 8) * ((dom['w'] + 31) // 32) * dom['batch']
+        for e in json.load(open(os.path.join(ROOT, 'profiles', 'r1b_traffic.json'))):
+            if key in e['kernel'] and dom['kind'] == 'bneck_trans' and e['grid'] == tiles * 512:
+                r['traffic'] = e['hbm_bytes']
+                r['traffic_note'] = 'bytes per launch from profiles/r1b_traffic.json (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)'
+                break
+    except Exception:
+        pass
     return r, ops
 
 
