@@ -80,7 +80,7 @@ def roofline(pipe):
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
     r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
          'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-         'kernel': ('bneck_trans_kernel (1x1 96->128 + 3x3 128->16 + 3x3/s2 128->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'bneck_trans' else
+         'kernel': ('stem_kernel (3x3 9->64 + 3x3 64->64 + 1x1 64->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'stem' else ('bneck_trans_kernel (1x1 96->128 + 3x3 128->16 + 3x3/s2 128->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'bneck_trans' else
                    'conv_mfma_kernel %dx%d k%d s%d @%dx%d (op %d)' % (dom['cin'], dom['cout'], dom['k'], dom['stride'], dom['h'], dom['w'], dom['index']),
          'launch_ms': round(dom['ms'], 4), 'micro_batch': dom['batch'],
          'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
@@ -88,7 +88,7 @@ def roofline(pipe):
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
     # runs, gfx950 correction; tools/pmc_traffic.py).  Only attached when kernel and launch geometry match.
     try:
-        key = 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else ('bb_chain_kernel' if dom['kind'] == 'bb_chain' else 'conv_mfma_kernel')
+        key = 'stem_kernel' if dom['kind'] == 'stem' else 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else ('bb_chain_kernel' if dom['kind'] == 'bb_chain' else 'conv_mfma_kernel')
         tiles = ((dom['h'] + 7) // 8) * ((dom['w'] + 31) // 32) * dom['batch']
         for e in json.load(open(os.path.join(ROOT, 'profiles', 'r1b_traffic.json'))):
             if key in e['kernel'] and dom['kind'] == 'bneck_trans' and e['grid'] == tiles * 512:

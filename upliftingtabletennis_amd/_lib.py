@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libttup.so')
+LIB_PATH = os.environ.get('TTUP_LIB', os.path.join(_HERE, 'libttup.so'))     # TTUP_LIB: alternative build (ablation experiments)
 
 OK, EINVAL, EFORMAT, EHIP, ENOMEM, EMASK = 0, 1, 2, 3, 4, 5
 DTYPE_BF16, DTYPE_F32 = 0, 1

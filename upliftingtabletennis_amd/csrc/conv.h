@@ -40,6 +40,10 @@ void free_conv(PackedConv* p);
 
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t stream);
 
+// fused stem: conv1 + conv2 + Bottleneck conv1, bf16 only, persistent with all weights resident in LDS (csrc/conv.hip)
+int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
+                int batch, int h, int w, hipStream_t st);
+
 // fused Bottleneck tail (conv3 + downsample + add + relu) + both transition1 convs, bf16 only (csrc/conv.hip)
 int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedConv& p6, const void* a2, const void* t2,
                        void* b0, void* b1, int batch, int h, int w, hipStream_t st);

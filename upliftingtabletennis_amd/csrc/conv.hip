@@ -97,8 +97,10 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             const int c8 = u % (CK / 8), pix = u / (CK / 8);
             const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
             pin[k] = u32x4{0u, 0u, 0u, 0u};
+#ifndef TTUP_ABLATE_LOADS
             if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                 pin[k] = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
+#endif
         }
         if (nchunk > 1 || item == 0) {
             const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
@@ -134,6 +136,20 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
         for (int i = 0; i < 8; ++i) bias11[i] = a.bias11[g * 8 + i];
     }
 
+    // per-lane B-fragment bases: CK=32 -> one per tap column dx (k-step s = dy*KS+dx); CK=16 -> one per k-step (two taps)
+    constexpr int NBB = (CK == 32) ? KS : KSTEPS;
+    const bf16_t* bB[NBB];
+#pragma unroll
+    for (int k = 0; k < NBB; ++k) {
+        int dy = 0, dx = k, c8 = g;
+        if (CK != 32) {
+            int tap = 2 * k + (g >> 1);
+            if (tap > TAPS - 1) tap = TAPS - 1;     // padded k-group: weights are zero
+            dy = tap / KS; dx = tap % KS; c8 = g & 1;
+        }
+        bB[k] = s_in + lds_off<CK, IW>(dy, n * S + dx, c8);
+    }
+
     f32x4 acc[MT][NT];
     if (n_items > 0) issue(0);
     for (int item = 0; item < n_items; ++item) {
@@ -153,25 +169,28 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             bf16x8 af[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = *(const bf16x8*)(s_w + ((s * MT + m) * 64 + lane) * 8);
-            int dy, dx, c8;
-            if (CK == 32) {
-                dy = s / KS; dx = s % KS; c8 = g;
-            } else {
-                int tap = 2 * s + (g >> 1);
-                if (tap > TAPS - 1) tap = TAPS - 1;     // padded k-group: weights are zero
-                dy = tap / KS; dx = tap % KS; c8 = g & 1;
-            }
+            // lane-dependent part of the pixel-fragment address (tap column + channel chunk + swizzle) is precomputed in
+            // bB[]; the N-tile / tap-row part below is a compile-time immediate
+            const bf16_t* bp = (CK == 32) ? bB[s % KS] : bB[s];
+            const int dyc = (CK == 32) ? s / KS : 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int nt = wave * NT + t;
+                const int nt = wave * NT + t;        // wave-uniform
                 const int r = nt / NTW, cg = nt % NTW;
-                const int iy = r * S + dy, ix = (cg * 16 + n) * S + dx;
-                const bf16x8 bfr = *(const bf16x8*)(s_in + lds_off<CK, IW>(iy, ix, c8));
+                const bf16x8 bfr = *(const bf16x8*)(bp + ((r * S + dyc) * IW + cg * 16 * S) * CK);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) {
+#ifdef TTUP_ABLATE_MFMA
+                    asm volatile("" :: "v"(af[m]), "v"(bfr));
+#else
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+#endif
+                }
             }
         }
+#ifdef TTUP_ABLATE_EPILOGUE
+        if (chunk != nchunk - 1 || a.H > 0) continue;
+#endif
         if (chunk != nchunk - 1) continue;
         // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
@@ -254,6 +273,196 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ fused stem: conv1 + conv2 (+ Bottleneck conv1)
+// Persistent workgroups (8 waves) keep ALL weights of the stem in LDS (conv1 20 KB + conv2 73.7 KB) and walk 8x32 tiles:
+//   X0 halo tile (12x36 px, 16 ch, register-prefetched one tile ahead) -> conv1 3x3 9(16)->64 +ReLU on the 10x34 halo
+//   region, kept in LDS as bf16 (never written to HBM) -> conv2 3x3 64->64 +ReLU straight from LDS (18 k-steps without a
+//   barrier) -> T2 tile to HBM and through LDS into the 1x1 64->32 follower (Bottleneck conv1) -> A1 tile to HBM.
+// Reference: wasb.py:446-451 (stem), :88-90 (Bottleneck conv1).  Intermediates are rounded to bf16 where the layer-wise
+// path stores them, so results are bit-identical.
+struct StemArgs {
+    const bf16_t* x0;                 // (B,H,W,16)
+    const bf16_t* w1; const float* b1;      // conv1: CK=16 packing, 5 k-steps x 4 m-tiles
+    const bf16_t* w2; const float* b2;      // conv2: CK=32 packing, 2 chunks x 9 k-steps x 4 m-tiles
+    const bf16_t* w3; const float* b3;      // follower 1x1 64->32: 2 k-steps x 2 m-tiles
+    bf16_t* t2; bf16_t* a1;
+    int H, W, tiles_x, tiles_per_img, total_tiles;
+};
+
+__global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
+    constexpr int XH = 12, XW = 36, TH1 = 10, TW1 = 34, NP1 = TH1 * TW1;       // X0 region, conv1 output region
+    constexpr int W1_U = 5 * 4 * 64, W2_U = 2 * 9 * 4 * 64;                      // 16-byte units
+    constexpr int X_UNITS = XH * XW * 2;                                        // 864 units of 16 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_w1 = (bf16_t*)smem;                     // 20,480 B
+    bf16_t* s_w2 = s_w1 + W1_U * 8;                   // 73,728 B
+    bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2 chunks][340 px][32 ch]  43,520 B   (also the T2 tile of the follower)
+    bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 ch]            13,824 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
+    for (int u = tid; u < W2_U; u += 512) ((u32x4*)s_w2)[u] = ((const u32x4*)a.w2)[u];
+    bf16x8 af3[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + ((k * 2 + m) * 64 + lane) * 8);
+    float b1[16], b2[16], b3[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { b1[i] = a.b1[g * 16 + i]; b2[i] = a.b2[g * 16 + i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b3[i] = a.b3[g * 8 + i];
+    // conv1 per-lane tap offsets inside the X0 tile (CK=16: k-step s covers taps 2s and 2s+1)
+    int koff1[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) { int tap = 2 * s5 + (g >> 1); tap = tap > 8 ? 8 : tap; koff1[s5] = ((tap / 3) * XW + tap % 3) * 16 + (g & 1) * 8; }
+    // conv2 per-lane fragment bases inside one chunk plane of the T1 tile, one per tap column
+    const bf16_t* bB[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bB[dx] = s_t1 + lds_off<32, TW1>(0, n + dx, g);
+
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    u32x4 px[2];
+    auto issue = [&](int it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * 8 - 2, gx0 = (t % a.tiles_x) * 32 - 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u & 1, pix = u >> 1;
+            const int gy = gy0 + pix / XW, gx = gx0 + pix % XW;
+            px[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                px[k] = *(const u32x4*)(a.x0 + ((size_t)(b * a.H + gy) * a.W + gx) * 16 + c8 * 8);
+        }
+    };
+    if (my_tiles > 0) issue(0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k]; }
+        __syncthreads();
+        if (it + 1 < my_tiles) issue(it + 1);
+        // ---------------- conv1 on the 10x34 region (22 groups of 16 pixels, linear pixel index)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int j = wave + 8 * t;
+            if (j >= 22) continue;
+            const int p = j * 16 + n, pc = p < NP1 ? p : NP1 - 1;
+            const int y = pc / TW1, x = pc % TW1;
+            const bf16_t* xb = s_x + (y * XW + x) * 16;
+            f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                const bf16x8 bfr = *(const bf16x8*)(xb + koff1[s5]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x8 af = *(const bf16x8*)(s_w1 + ((s5 * 4 + m) * 64 + lane) * 8);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
+                }
+            }
+            if (p < NP1) {
+                const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float f = acc[2 * q + (i >> 2)][i & 3] + b1[q * 8 + i]; v[i] = (inside && f > 0.f) ? f : 0.f; }
+                    // lane's channels g*16 + q*8 .. +7  ->  chunk plane (g>>1), 16-byte chunk (g&1)*2+q
+                    *(u32x4*)(s_t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) =
+                        u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- conv2 on the 8x32 tile, both 32-channel planes straight from LDS
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w2 + (((c * 9 + s9) * 4 + m) * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+                    const bf16x8 bfr = *(const bf16x8*)(bB[s9 % 3] + c * (NP1 * 32) + ((r + s9 / 3) * TW1 + cg * 16) * 32);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+                }
+            }
+        __syncthreads();                      // every wave is done reading the T1 tile: it becomes the T2 tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+            const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
+            const int p = r * 32 + cg * 16 + n;
+            const bool ok = oy < a.H && ox < a.W;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = acc[2 * q + (i >> 2)][t][i & 3] + b2[q * 8 + i]; v[i] = f > 0.f ? f : 0.f; }
+                const u32x4 pk = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk;
+                *(u32x4*)(s_t1 + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = pk;
+            }
+        }
+        __syncthreads();
+        // ---------------- follower: A1 = relu(W3 . T2 + b3), 64 -> 32
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+            const int p = r * 32 + cg * 16 + n;
+            f32x4 c3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bf16x8 bfr = *(const bf16x8*)(s_t1 + p * 64 + (((4 * k + g) ^ (p & 7)) << 3));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], bfr, c3[m], 0, 0, 0);
+            }
+            const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
+            if (oy < a.H && ox < a.W) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = c3[i >> 2][i & 3] + b3[i]; v[i] = f > 0.f ? f : 0.f; }
+                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
+        }
+    }
+}
+
+int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
+                int batch, int h, int w, hipStream_t st) {
+    TTUP_REQUIRE(p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16, TTUP_EINVAL, "stem: unexpected conv1 shape");
+    TTUP_REQUIRE(p2.cout == 64 && p2.cin_total == 64 && p2.k == 3 && p2.stride == 1 && p2.ck == 32, TTUP_EINVAL, "stem: unexpected conv2 shape");
+    TTUP_REQUIRE(p3.cout == 32 && p3.cin_total == 64 && p3.k == 1 && p3.ck == 32, TTUP_EINVAL, "stem: unexpected follower shape");
+    StemArgs a;
+    a.x0 = (const bf16_t*)x0; a.w1 = (const bf16_t*)p1.w_dev; a.b1 = p1.bias_dev; a.w2 = (const bf16_t*)p2.w_dev; a.b2 = p2.bias_dev;
+    a.w3 = (const bf16_t*)p3.w_dev; a.b3 = p3.bias_dev; a.t2 = (bf16_t*)t2; a.a1 = (bf16_t*)a1;
+    a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
+    constexpr size_t SMEM = (size_t)(5 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * 340 * 32 + 432 * 16) * 2;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
+    }
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
 }
 
 // ------------------------------------------------------------------ fused Bottleneck tail + transition1

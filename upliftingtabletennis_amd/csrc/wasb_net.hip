@@ -30,7 +30,7 @@ namespace {
 struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
 
 struct Op {
-    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD } kind = CONV;
+    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD, STEM } kind = CONV;
     int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
     int conv = -1;            // index into packed convs
     int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output; CONV: fused 1x1 follower (conv2) -> dst2
@@ -251,22 +251,35 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     net->t_input = b.new_tensor(16, H, W);
     // stem (wasb.py:446-451)
     int x;
-    {
-        const FoldedConv& f = b.next(64, net->in_ch, 3, 1);
-        const int pc = b.pack(f, nullptr, 16);
-        const int dst = b.new_tensor(64, H, W);
-        Op op; op.conv = pc; op.src0 = net->t_input; op.dst = dst; op.relu = 1; net->ops.push_back(op);
-        x = dst; net->taps["stem1"] = x;
-    }
     const bool fuse_c1 = net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE");
-    x = b.conv(x, 64, 3, 1, 1); net->taps["stem2"] = x;
+    int stem_a1 = -1;
+    if (fuse_c1 && !getenv("TTUP_NO_STEM")) {
+        // conv1 + conv2 + Bottleneck conv1 in one persistent kernel; the first 64-channel tensor never reaches HBM
+        const int p1 = b.pack(b.next(64, net->in_ch, 3, 1), nullptr, 16);
+        const int p2 = b.pack(b.next(64, 64, 3, 1), nullptr, 0);
+        const int p3 = b.pack(b.next(32, 64, 1, 1), nullptr, 0);
+        x = b.new_tensor(64, H, W); net->taps["stem2"] = x;
+        stem_a1 = b.new_tensor(32, H, W);
+        Op op; op.kind = Op::STEM; op.conv = p1; op.conv2 = p2; op.conv3 = p3; op.src0 = net->t_input; op.dst = x; op.dst2 = stem_a1;
+        net->ops.push_back(op);
+    } else {
+        {
+            const FoldedConv& f = b.next(64, net->in_ch, 3, 1);
+            const int pc = b.pack(f, nullptr, 16);
+            const int dst = b.new_tensor(64, H, W);
+            Op op; op.conv = pc; op.src0 = net->t_input; op.dst = dst; op.relu = 1; net->ops.push_back(op);
+            x = dst; net->taps["stem1"] = x;
+        }
+        x = b.conv(x, 64, 3, 1, 1); net->taps["stem2"] = x;
+    }
     const size_t stem2_op = net->ops.size() - 1;
     // layer1: Bottleneck(64 -> 32 -> 128) (wasb.py:85-105), conv3 + downsample fused into one two-source 1x1 conv;
     // transition1 (wasb.py:454-459).  bf16: both run in one kernel and the 128-channel tensor stays in LDS.
     std::vector<int> xs(2);
     {
         int a1;
-        if (fuse_c1) {       // Bottleneck conv1 (1x1 64->32 + ReLU) rides in the epilogue of stem conv2
+        if (stem_a1 >= 0) a1 = stem_a1;
+        else if (fuse_c1) {       // Bottleneck conv1 (1x1 64->32 + ReLU) rides in the epilogue of stem conv2
             const int pc1 = b.pack(b.next(32, 64, 1, 1), nullptr, 0);
             a1 = b.new_tensor(32, H, W);
             net->ops[stem2_op].conv2 = pc1; net->ops[stem2_op].dst2 = a1;
@@ -322,6 +335,11 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
+            if (rc) return rc;
+        } else if (op.kind == Op::STEM) {
+            const Tensor& s = net->tensors[op.src0];
+            const int rc = launch_stem(net->convs[op.conv], net->convs[op.conv2], net->convs[op.conv3], s.ptr, net->tensors[op.dst].ptr,
+                                       net->tensors[op.dst2].ptr, mb, s.h, s.w, st);
             if (rc) return rc;
         } else if (op.kind == Op::UPSUM_HEAD) {
             continue;       // launched by forward_impl, which knows the output buffers
@@ -489,7 +507,9 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
         std::swap(net->ops, one);
         int* o = info_out + 8 * i;
         const Tensor& d = net->tensors[op.dst];
-        if (op.kind == Op::BB_CHAIN) {
+        if (op.kind == Op::STEM) {
+            o[0] = 4; o[1] = 9 * 9 * 64 + 9 * 64 * 64 + 64 * 32; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
+        } else if (op.kind == Op::BB_CHAIN) {
             o[0] = 3; o[1] = op.n_chain * d.c * 9; o[2] = d.c; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = op.n_chain;
         } else if (op.kind == Op::BNECK_TRANS) {
             // algorithmic MACs per output pixel of B0: 96*128 (1x1) + 1152*16 (3x3 s1) + 1152*32/4 (3x3 s2 at quarter density)

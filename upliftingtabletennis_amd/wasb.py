@@ -134,7 +134,7 @@ def time_ops(net, batch=None, reps=5):
     ops = []
     for i in range(n.value):
         kind, cin, cout, k, stride, h, w, cpad = [int(v) for v in info[i]]
-        flops = 2.0 * batch * h * w * cout * cin * k * k if kind in (0, 2, 3) else 0.0
-        ops.append(dict(index=i, kind={0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain'}[kind], cin=cin, cout=cout, k=k, stride=stride, h=h, w=w,
+        flops = 2.0 * batch * h * w * cout * cin * k * k if kind in (0, 2, 3, 4) else 0.0
+        ops.append(dict(index=i, kind={0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem'}[kind], cin=cin, cout=cout, k=k, stride=stride, h=h, w=w,
                         cin_padded=cpad, ms=float(ms[i]), flops=flops, batch=batch))
     return ops
