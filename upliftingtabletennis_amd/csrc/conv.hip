@@ -478,7 +478,7 @@ struct FusedArgs {
     const bf16_t* w5; const float* b5;            // 3x3 s1 128 -> 16 (4 chunks x 9 steps)
     const bf16_t* w6; const float* b6;            // 3x3 s2 128 -> 32 (4 chunks x 9 steps x 2 m-tiles)
     bf16_t* b0; bf16_t* b1o;
-    int H, W, tiles_x;
+    int H, W, tiles_x, tiles_per_img, total_tiles;
 };
 
 __device__ __forceinline__ int l1_off(int pix, int c8) { return pix * 128 + ((c8 ^ (pix & 15)) << 3); }
@@ -490,151 +490,153 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     constexpr int W1_U = 3 * 8 * 64, W5_U = 4 * 9 * 64, W6H_U = 2 * 9 * 2 * 64;      // 16-byte units
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]              87,040 B
-    bf16_t* s_w1 = s_l1 + NPIX * 128;                           // phase-1 weights         24,576 B
-    bf16_t* s_w = s_w1 + W1_U * 8;                              // phase-2 weights         36,864 B
+    bf16_t* s_w1 = s_l1 + NPIX * 128;                           // phase-1 weights         24,576 B (resident)
+    bf16_t* s_w = s_w1 + W1_U * 8;                              // phase-2 weights         36,864 B (W5 -> W6a -> W6b per tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int oy0 = (tile / a.tiles_x) * 8, ox0 = (tile % a.tiles_x) * 32;
-    const int gy0 = oy0 - 1, gx0 = ox0 - 1;
+    // Persistent workgroup: W1 stays in LDS; every other global load of a tile (pixel fragments of the 1x1 conv, W5, both
+    // halves of W6) is issued one phase ahead into registers so that its latency hides behind the matrix work.
+    for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
+    float* s_b1 = (float*)(s_w + W5_U * 8);                    // phase-1 bias, 512 B (kept out of the register file)
+    if (tid < 128) s_b1[tid] = a.b1[tid];
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
-    // ---------------- issue every global load of the tile up front: W1, the phase-1 pixel fragments (straight from
-    // global memory: a 1x1 conv needs no halo reuse, and 16 pixels x 64 B are contiguous in NHWC), W5 and half of W6
-    u32x4 pw1[3], pw5[5], pw6[5];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pw1[k] = ((const u32x4*)a.w1)[tid + k * 512];
-    u32x4 pb[3][3];
+    u32x4 pb[3][3], pw[5];          // pw: one weight block in flight at a time (W5 during phase 1, W6a during 2a, W6b during 2b/0)
     bool p_in[3];
-    int p_pix[3];
+    auto issue_pix = [&](int it) {      // phase-1 pixel fragments straight from global: 16 px x 64 B are contiguous in NHWC
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int gy0 = (tt / a.tiles_x) * 8 - 1, gx0 = (tt % a.tiles_x) * 32 - 1;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int j = wave + 8 * t;
-        int pix = j * 16 + n;
-        pix = pix < NPIX ? pix : NPIX - 1;
-        p_pix[t] = pix;
-        const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
-        p_in[t] = j < NT1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const size_t gp = (size_t)(b * a.H + gy) * a.W + gx;
+        for (int t = 0; t < 3; ++t) {
+            const int j = wave + 8 * t;
+            int pix = j * 16 + n;
+            pix = pix < NPIX ? pix : NPIX - 1;
+            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            p_in[t] = j < NT1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const size_t gp = (size_t)(b * a.H + gy) * a.W + gx;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            pb[t][c] = u32x4{0u, 0u, 0u, 0u};
-            if (p_in[t]) pb[t][c] = (c == 0) ? *(const u32x4*)(a.a2 + gp * 32 + g * 8) : *(const u32x4*)(a.t2 + gp * 64 + (c - 1) * 32 + g * 8);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W5_U) pw5[k] = ((const u32x4*)a.w5)[u]; }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) pw6[k] = ((const u32x4*)a.w6)[u]; }
-
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ((u32x4*)s_w1)[tid + k * 512] = pw1[k];
-    __syncthreads();
-    // ---------------- phase 1: layer1 halo tile
-    {
-        f32x4 acc[3][8];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int chunk = 0; chunk < 3; ++chunk) {
-            bf16x8 af[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) af[m] = *(const bf16x8*)(s_w1 + ((chunk * 8 + m) * 64 + lane) * 8);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (wave + 8 * t < NT1) {
-                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[t][m], 0, 0, 0);
-                }
+            for (int c = 0; c < 3; ++c) {
+                pb[t][c] = u32x4{0u, 0u, 0u, 0u};
+                if (p_in[t]) pb[t][c] = (c == 0) ? *(const u32x4*)(a.a2 + gp * 32 + g * 8) : *(const u32x4*)(a.t2 + gp * 64 + (c - 1) * 32 + g * 8);
             }
         }
-        float bias[32];
+    };
+    auto load_w = [&](u32x4* dst, const bf16_t* src, int units) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) bias[i] = a.b1[g * 32 + i];
+        for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < units) dst[k] = ((const u32x4*)src)[u]; }
+    };
+    auto store_w = [&](const u32x4* src, int units) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < units) ((u32x4*)s_w)[u] = src[k]; }
+    };
+    if (my_tiles > 0) issue_pix(0);
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();            // previous tile done with s_l1 / s_w (W1 visible on the first pass)
+        load_w(pw, a.w5, W5_U);     // in flight during phase 1
+        // ---------------- phase 1: layer1 halo tile (one 16-pixel group at a time keeps the accumulator footprint at 32 VGPRs)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t, pix = j * 16 + n;
-            if (j < NT1 && pix < NPIX) {
+            if (j >= NT1) continue;
+            f32x4 acc[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int chunk = 0; chunk < 3; ++chunk) {
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const bf16x8 af = *(const bf16x8*)(s_w1 + ((chunk * 8 + m) * 64 + lane) * 8);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
+                }
+            }
+            if (pix < NPIX) {
                 const bool inside = p_in[t];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[8];
+                    const f32x4 bq0 = *(const f32x4*)(s_b1 + g * 32 + q * 8), bq1 = *(const f32x4*)(s_b1 + g * 32 + q * 8 + 4);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float x = acc[t][2 * q + (i >> 2)][i & 3] + bias[q * 8 + i];
+                        const float x = acc[2 * q + (i >> 2)][i & 3] + (i < 4 ? bq0[i & 3] : bq1[i & 3]);
                         v[i] = (inside && x > 0.f) ? x : 0.f;
                     }
                     *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
                 }
             }
         }
-    }
+        store_w(pw, W5_U);
+        __syncthreads();
+        load_w(pw, a.w6, W6H_U);                                // first half of W6: in flight during phase 2a
+        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phases 2a/2b
+        // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
+#ifdef TTUP_ABLATE_P2A
+        if (a.H < 0)
+#endif
+        {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W5_U) ((u32x4*)s_w)[u] = pw5[k]; }
-    __syncthreads();
-    // second half of W6 travels while phase 2a computes
-    u32x4 pw6b[5];
+                for (int s9 = 0; s9 < 9; ++s9) {
+                    const bf16x8 af = *(const bf16x8*)(s_w + ((c * 9 + s9) * 64 + lane) * 8);
+                    const int dy = s9 / 3, dx = s9 % 3;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) pw6b[k] = ((const u32x4*)a.w6)[W6H_U + u]; }
-    // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
-    {
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                    for (int t = 0; t < 2; ++t) {
+                        const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+                        const int pix = (r + dy) * IW + cg * 16 + n + dx;
+                        const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, c * 4 + g));
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int t = 0; t < 2; ++t) {
+                const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
+                if (oy < a.H && ox < a.W) {
+                    float v[4];
 #pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const bf16x8 af = *(const bf16x8*)(s_w + ((c * 9 + s) * 64 + lane) * 8);
-                const int dy = s / 3, dx = s % 3;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
-                    const int pix = (r + dy) * IW + cg * 16 + n + dx;
-                    const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, c * 4 + g));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) { const float x = acc[t][r] + a.b5[g * 4 + r]; v[r] = x > 0.f ? x : 0.f; }
+                    *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
                 }
             }
+        }
+        // ---------------- phase 2b: 3x3 s2 128 -> 32; wave = (output row r, m-tile m); weights two chunks at a time
+#ifndef TTUP_ABLATE_P2B
+        {
+            const int r = wave >> 1, m = wave & 1;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
-            if (oy < a.H && ox < a.W) {
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();
+                store_w(pw, W6H_U);
+                __syncthreads();
+                if (half == 0) load_w(pw, a.w6 + (size_t)W6H_U * 8, W6H_U);      // second half: in flight during the first
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int s9 = 0; s9 < 9; ++s9) {
+                        const bf16x8 af = *(const bf16x8*)(s_w + (((cc * 9 + s9) * 2 + m) * 64 + lane) * 8);
+                        const int dy = s9 / 3, dx = s9 % 3;
+                        const int pix = (2 * r + dy) * IW + 2 * n + dx;
+                        const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, (half * 2 + cc) * 4 + g));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
+                    }
+            }
+            const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
+            const int oy = (oy0 >> 1) + r, ox = (ox0 >> 1) + n;
+            if (oy < OH && ox < OW) {
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float x = acc[t][r] + a.b5[g * 4 + r]; v[r] = x > 0.f ? x : 0.f; }
-                *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                for (int q = 0; q < 4; ++q) { const float x = acc[q] + a.b6[g * 8 + m * 4 + q]; v[q] = x > 0.f ? x : 0.f; }
+                *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
             }
         }
-    }
-    // ---------------- phase 2b: 3x3 s2 128 -> 32; wave = (output row r, m-tile m); weights two chunks at a time
-    {
-        const int r = wave >> 1, m = wave & 1;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < W6H_U) ((u32x4*)s_w)[u] = half == 0 ? pw6[k] : pw6b[k]; }
-            __syncthreads();
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    const bf16x8 af = *(const bf16x8*)(s_w + (((cc * 9 + s) * 2 + m) * 64 + lane) * 8);
-                    const int dy = s / 3, dx = s % 3;
-                    const int pix = (2 * r + dy) * IW + 2 * n + dx;
-                    const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, (half * 2 + cc) * 4 + g));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
-                }
-        }
-        const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
-        const int oy = (oy0 >> 1) + r, ox = (ox0 >> 1) + n;
-        if (oy < OH && ox < OW) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const float x = acc[q] + a.b6[g * 8 + m * 4 + q]; v[q] = x > 0.f ? x : 0.f; }
-            *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-        }
+#endif
     }
 }
 
@@ -648,14 +650,16 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
     a.a2 = (const bf16_t*)a2; a.t2 = (const bf16_t*)t2;
     a.w1 = (const bf16_t*)p1.w_dev; a.b1 = p1.bias_dev; a.w5 = (const bf16_t*)p5.w_dev; a.b5 = p5.bias_dev;
     a.w6 = (const bf16_t*)p6.w_dev; a.b6 = p6.bias_dev; a.b0 = (bf16_t*)b0; a.b1o = (bf16_t*)b1;
-    a.H = h; a.W = w; a.tiles_x = cdiv(w, 32);
-    constexpr size_t SMEM = (size_t)(340 * 128 + 3 * 8 * 64 * 8 + 4 * 9 * 64 * 8) * 2;
+    a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
+    constexpr size_t SMEM = (size_t)(340 * 128 + 3 * 8 * 64 * 8 + 4 * 9 * 64 * 8) * 2 + 512;
     static bool attr_done = false;
     if (!attr_done) {
         TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bneck_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
         attr_done = true;
     }
-    hipLaunchKernelGGL(bneck_trans_kernel, dim3(a.tiles_x * cdiv(h, 8), batch), dim3(512), SMEM, st, a);
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL(bneck_trans_kernel, dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
