@@ -674,7 +674,7 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
 struct BBArgs {
     const bf16_t* x; bf16_t* y;
     const bf16_t* w[4]; const float* bias[4];
-    int H, W, tiles_x;
+    int H, W, tiles_x, tiles_per_img, total_tiles;
 };
 
 // element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
@@ -782,18 +782,100 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     }
 }
 
+// Persistent: a workgroup walks tiles; the next tile's input region is prefetched into registers while the current one is
+// computed (C=32).  C=32 rotates one conv's weights (18 KB) at a time through a register-prefetched LDS slot; C=16 runs one tile
+// per workgroup with its 5 weight fragments per conv straight from L2 (persistent variants measured slower there).
 template <int C, int NB, int TH, int TW>
 __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     constexpr int L = 2 * NB;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
-    constexpr int SZ_A = R0H * R0W * C;
+    constexpr int SZ_A = R0H * R0W * C, SZ_B = (R0H - 2) * (R0W - 2) * C;
+    constexpr int KSTEPS = (C == 16) ? 5 : 9, MT = C / 16;
+    constexpr int W_UNITS = KSTEPS * MT * 64;                    // 16-byte units per conv
+    constexpr bool RESIDENT = false;                             // (all convs' weights resident in LDS: measured slower for C=16)
+    constexpr bool WGLOBAL = (C == 16);                          // C=16: one tile per workgroup, weight fragments straight from global/L2
+    constexpr int W_PT = (W_UNITS + 511) / 512;
+    constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* bufA = (bf16_t*)smem;              // block input region (later overwritten in place by the block output)
     bf16_t* bufB = bufA + SZ_A;                // intermediate of the current block
+    bf16_t* s_wt = bufB + SZ_B;                // weights: L slots (resident) or one rotating slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
-    // stage the input region (zero outside the image)
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    u32x4 pin[IN_PT], pwt[W_PT];
+    auto issue_in = [&](int it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int gy0 = (tt / a.tiles_x) * TH - L, gx0 = (tt % a.tiles_x) * TW - L;
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u % (C / 8), pix = u / (C / 8);
+            const int gy = gy0 + pix / R0W, gx = gx0 + pix % R0W;
+            pin[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) pin[k] = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
+        }
+    };
+    auto load_wt = [&](int conv) {
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) pwt[k] = ((const u32x4*)a.w[conv])[u]; }
+    };
+    auto store_wt = [&](int slot) {
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) ((u32x4*)(s_wt + slot * W_UNITS * 8))[u] = pwt[k]; }
+    };
+    if (!WGLOBAL && my_tiles > 0) load_wt(0);
+    if (my_tiles > 0) issue_in(0);
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+        __syncthreads();                       // previous tile fully consumed (resident weights visible on the first pass)
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            if (u < IN_UNITS) { const int c8 = u % (C / 8), pix = u / (C / 8); *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = pin[k]; }
+        }
+        if (!WGLOBAL) store_wt(0);
+        __syncthreads();
+        if (it + 1 < my_tiles) issue_in(it + 1);
+        if (!WGLOBAL) load_wt(1);
+        const bf16_t* w0 = WGLOBAL ? a.w[0] : s_wt;
+        const bf16_t* w1 = WGLOBAL ? a.w[1] : s_wt;
+        if (NB == 1) {
+            bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+            __syncthreads();
+            if (!WGLOBAL) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
+            bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+        } else {
+            static_assert(NB == 1 || WGLOBAL, "two-block chains read their weights from global memory");
+            bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
+            __syncthreads();
+            bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, w1, a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
+            __syncthreads();
+            bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+            __syncthreads();
+            bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+        }
+    }
+}
+
+// One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
+// Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
+    constexpr int L = 4;
+    constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
+    constexpr int SZ_A = R0H * R0W * C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* bufA = (bf16_t*)smem;
+    bf16_t* bufB = bufA + SZ_A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tl = blockIdx.x;
+    const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+    const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
     for (int u = tid; u < R0H * R0W * (C / 8); u += 512) {
         const int c8 = u % (C / 8), pix = u / (C / 8);
         const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
@@ -802,25 +884,38 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v;
     }
     __syncthreads();
-    if (NB == 1) {
-        bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
-        __syncthreads();
-        bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, a.w[1], a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
-    } else {
-        bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
-        __syncthreads();
-        bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
-        __syncthreads();
-        bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
-        __syncthreads();
-        bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+    bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
+    __syncthreads();
+    bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
+    __syncthreads();
+    bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+    __syncthreads();
+    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+}
+
+template <int C, int TH, int TW>
+static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
+    constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2;
+    static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
+    static bool attr_done = false;
+    if (!attr_done && SMEM > 64 * 1024) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bb_chain2_kernel<C, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
     }
+    BBArgs k = a;
+    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
+    if (k.total_tiles == 0) return TTUP_OK;
+    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW>), dim3(k.total_tiles), dim3(512), SMEM, st, k);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
 }
 
 template <int C, int NB, int TH, int TW>
 static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr int L = 2 * NB;
-    constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2;
+    constexpr int KSTEPS = (C == 16) ? 5 : 9, MT = C / 16;
+    constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2 +
+                            (size_t)(C == 16 ? 0 : 1) * KSTEPS * MT * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
@@ -828,8 +923,11 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
         attr_done = true;
     }
     BBArgs k = a;
-    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW);
-    hipLaunchKernelGGL((bb_chain_kernel<C, NB, TH, TW>), dim3(k.tiles_x * cdiv(h, TH), batch), dim3(512), SMEM, st, k);
+    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
+    const int per_cu = (int)((160 * 1024) / SMEM) > 2 ? 2 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
+    const int grid = (C == 16 || k.total_tiles < 256 * per_cu) ? k.total_tiles : 256 * per_cu;      // C=16: one tile per workgroup
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL((bb_chain_kernel<C, NB, TH, TW>), dim3(grid), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -845,7 +943,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         TTUP_REQUIRE(p.cout == c && p.cin_total == c && p.k == 3 && p.stride == 1 && p.ck == (c == 16 ? 16 : 32), TTUP_EINVAL, "bb_chain: unexpected conv shape");
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
-    if (c == 16 && n_convs == 4) return launch_bb_t<16, 2, 16, 32>(a, batch, h, w, st);
+    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 16, 32>(a, batch, h, w, st);
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 8, 32>(a, batch, h, w, st);
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
