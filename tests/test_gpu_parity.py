@@ -270,3 +270,24 @@ def test_fused_kernels_bit_identical_to_layerwise():
     assert torch.equal(h1, h2)
     for tap in ('trans1_0', 'trans1_1', 'stage2_0', 'stage2_1', 'stage3_2'):
         assert torch.equal(fused.read_tap(tap, b), plain.read_tap(tap, b)), tap
+
+
+@pytest.mark.parametrize('hw', [(72, 104), (40, 56), (8, 8), (136, 24)])
+def test_wasb_ragged_sizes_against_oracle(hw):
+    """Sizes that are multiples of 8 but not of the 8x32 / 16x32 tiles: every kernel's edge masking and zero padding."""
+    h, w = hw
+    sd = weights.random_wasb_state_dict(23)
+    x = np.random.default_rng(23).standard_normal((3, 9, h, w)).astype(np.float32)
+    ref = wasb_ref.wasb_forward(x, sd).numpy()
+    scale = ref.max() - ref.min()
+    for dtype, tol in (('f32', 2e-4), ('bf16', 4e-2)):
+        net = wasb.WASBNet(sd, resolution=(w, h), max_batch=2, dtype=dtype)       # batch 3 > max_batch 2: host-side chunking too
+        heat, idx, win = net.forward(torch.from_numpy(x), want_peaks=True)
+        got = heat.cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= tol * scale, (dtype, np.abs(got - ref).max(), scale)
+        assert np.array_equal(idx.cpu().numpy(), got.reshape(3, -1).argmax(1))
+    with pytest.raises(ValueError):
+        wasb.WASBNet(sd, resolution=(100, 64), max_batch=1)      # width not a multiple of 8
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 9, h + 8, w))
