@@ -2,7 +2,7 @@
 ``torch.hub.load('<this repo>', 'ball_detection', model_name='wasb', source='local')``."""
 dependencies = ['torch', 'numpy']
 
-from upliftingtabletennis_amd.interface import BallDetector, TableTennisPipeline, UpliftingModel  # noqa: E402,F401
+from upliftingtabletennis_amd.interface import BallDetector, TableDetector, TableTennisPipeline, UpliftingModel  # noqa: E402,F401
 
 
 def ball_detection(model_name='wasb', **kwargs):
@@ -11,7 +11,8 @@ def ball_detection(model_name='wasb', **kwargs):
 
 
 def table_detection(model_name='hrnet', **kwargs):
-    raise NotImplementedError('table detection is the next row of the scope table (SURVEY.md 8 f1) and is not built yet')
+    """Loads the table detection model.  Built here: 'hrnet' (the in-tree HRNet); 'segformerpp_*' raises."""
+    return TableDetector(model_name=model_name, **kwargs)
 
 
 def full_pipeline():

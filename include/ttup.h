@@ -64,6 +64,11 @@ int         ttup_device_count(void);
 int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
                             int dst_h, int dst_w, float* out_dev, void* stream);
 
+/* single frames (table detector, tabledetection/transforms.py:17-38 + NormalizeImage; interface.py:160-165):
+ * frames_dev (n,src_h,src_w,3) uint8 -> out_dev float32 (n,3,dst_h,dst_w) */
+int ttup_preprocess_frames(const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                           int dst_h, int dst_w, float* out_dev, void* stream);
+
 /* ---------------------------------------------------------------- a2: WASB / HRNet CNN
  * Replaces WASBNet.forward (balldetection/models/wasb.py:596-608) behind `self.model(x)`
  * (interface.py:115, inference/utils.py:57).
@@ -74,6 +79,9 @@ int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, 
  *   float w[cout][cin][k][k]; if has_bias float b[cout]; if has_bn float gamma,beta,mean,var [cout] each.
  * BN folding (eps 1e-5) and MFMA fragment packing happen inside create.
  * height/width: network input size (multiples of 8); max_batch: largest B accepted by forward.
+ * The same entry points serve the table-keypoint HRNet (tabledetection/models/hrnet.py:510-589): a blob with
+ * in_ch=3, head_out=13 gives a handle whose forward takes (B,3,H,W) and returns all 13 heatmap channels (B,13,H,W);
+ * argmax/win outputs then hold B*13 entries.  head_out=3 (ball) returns only channel 1, as WASBNet.forward does.
  */
 int  ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch,
                       int dtype, ttup_wasb** out);
@@ -98,6 +106,8 @@ int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_d
 int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
 /* micro-batch the handle was created with (TTUP_MICRO_BATCH) */
 int ttup_wasb_micro_batch(ttup_wasb* net);
+/* heatmap channels per sample returned by forward: 1 (ball) or 13 (table) */
+int ttup_wasb_out_channels(ttup_wasb* net);
 
 /* ---------------------------------------------------------------- a3/a4: heatmap argmax + refine
  * Replaces extract_position_torch_gaussian (ball: helper_balldetection.py:29-110, called at

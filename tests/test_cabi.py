@@ -117,3 +117,10 @@ def test_fit_solver_host_build_tracks_scipy(host_fit, golden):
         assert np.median(err) < 1e-6, np.median(err)
         assert (err < 1e-3).mean() > 0.8, err
         assert err.max() < 0.6, err.max()
+
+
+def test_filter_trajectory_table_matches_reference(golden):
+    g = golden('table.npz')
+    out = glue.filter_trajectory_table(g['filter/p1'], g['filter/p2'])
+    assert out.shape == (13, 3)
+    np.testing.assert_allclose(out, g['filter/out'], rtol=0, atol=1e-9)

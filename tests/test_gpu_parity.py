@@ -291,3 +291,45 @@ def test_wasb_ragged_sizes_against_oracle(hw):
         wasb.WASBNet(sd, resolution=(100, 64), max_batch=1)      # width not a multiple of 8
     with pytest.raises(ValueError):
         net(torch.zeros(1, 9, h + 8, w))
+
+
+# ------------------------------------------------------------------------------------------ f1: table detector
+@pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160'])
+def test_table_hrnet_matches_reference(golden, name):
+    g = golden('table.npz')
+    seed, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, in_ch=3, head_out=13)
+    x = torch.from_numpy(np.random.default_rng(seed).standard_normal((b, 3, h, w)).astype(np.float32))
+    ref = g[name + '/heat']
+    scale = ref.max() - ref.min()
+    for dtype, tol in (('f32', 2e-4), ('bf16', 4e-2)):
+        net = wasb.get_table_model('hrnet', resolution=(w, h), state_dict=sd, max_batch=b, dtype=dtype)
+        heat = net(x)
+        assert isinstance(heat, torch.Tensor) and heat.shape == (b, 13, h, w)
+        assert np.abs(heat.cpu().numpy() - ref).max() <= tol * scale, dtype
+    heat, idx, win = net.forward(x, want_peaks=True)
+    got = heat.cpu().numpy()
+    assert np.array_equal(idx.cpu().numpy(), got.reshape(b * 13, -1).argmax(1))
+    pos = refine.extract_position_table(heat, 1920, 1080)
+    ref_pos = refine_ref.extract_position_table(got, 1920, 1080)
+    assert pos.shape == (b, 13, 3)
+    hm = np.abs(pos - ref_pos)[..., :2] / np.array([1920 / w, 1080 / h])
+    assert np.median(hm) < 1e-5 and hm.max() < 0.6
+
+
+def test_table_detector_and_full_pipeline_surface():
+    from upliftingtabletennis_amd.interface import TableDetector, TableTennisPipeline
+    frames, track = synth.synth_frames(8, 720, 1280, seed=4)
+    det = TableDetector('hrnet', max_batch=4)
+    pos, heat = det.predict(list(frames[:5]))
+    assert pos.shape == (5, 13, 3) and pos.dtype == np.float64 and heat.shape == (5, 13, 704, 1280)
+    assert (pos[..., 2] == 1).all()
+    filt = det.filter_trajectory(pos, pos)
+    assert filt.shape == (13, 3)
+    with pytest.raises(NotImplementedError):
+        TableDetector('segformerpp_b2')
+    pipe = TableTennisPipeline(max_batch=8)
+    spin, p3 = pipe.predict(list(frames), 60.0)                  # table keypoints detected by the HRNet
+    assert tuple(spin.shape) == (3,) and p3.shape == (6, 3) and np.isfinite(p3).all()
+    spin2, p32 = pipe.predict(list(frames), 60.0, table_keypoints=filt)
+    assert p32.shape == (6, 3)

@@ -111,3 +111,17 @@ def test_resize_unpinned_self_consistency():
     ramp = np.tile(np.arange(72, dtype=np.uint8)[:, None, None] * 3, (1, 16, 3))
     r = glue_ref.resize_linear_u8(ramp, 16, 64).astype(int)
     assert (np.diff(r[:, 0, 0]) >= 0).all()
+
+
+@pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160'])
+def test_table_hrnet_oracle_matches_reference(golden, name):
+    """f1: the same oracle graph with 3 input / 13 output channels == reference MyHRNet (tabledetection/models/hrnet.py)."""
+    g = golden('table.npz')
+    seed, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, in_ch=3, head_out=13)
+    x = np.random.default_rng(seed).standard_normal((b, 3, h, w)).astype(np.float32)
+    with torch.no_grad():
+        heat = wasb_ref.hrnet_forward(torch.from_numpy(x), sd)[0].numpy()
+    assert heat.shape == (b, 13, h, w)
+    assert np.abs(heat - g[name + '/heat']).max() <= 1e-5 * np.abs(g[name + '/heat']).max()
+    assert [(k, tuple(s)) for k, s in arch.wasb_schema(in_ch=3, head_out=13)][0] == ('model.conv1.weight', (64, 3, 3, 3))

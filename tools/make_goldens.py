@@ -246,6 +246,53 @@ def gen_glue():
     print('glue: filter/transform/normalise goldens from', src)
 
 
+def gen_table():
+    """f1: table-keypoint HRNet (tabledetection/models/hrnet.py) on seeded weights + the DBSCAN keypoint filter."""
+    from tabledetection.models.hrnet import MyHRNet
+    from inference.utils import filter_trajectory_table
+    from upliftingtabletennis_amd import weights, arch
+    from oracle import wasb_ref
+    out = {}
+    orig = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        m = MyHRNet(resolution=(1280, 704))
+    finally:
+        torch.load = orig
+    ref_sd = {k: v for k, v in m.state_dict().items() if 'num_batches_tracked' not in k}
+    schema = [(k, list(v.shape)) for k, v in ref_sd.items()]
+    assert [(k, tuple(s)) for k, s in schema] == [(k, tuple(s)) for k, s in arch.wasb_schema(in_ch=3, head_out=13)], 'table schema mismatch'
+    for name, seed, (b, h, w) in [('noise_64x96', 51, (2, 64, 96)), ('noise_96x160', 52, (1, 96, 160))]:
+        sd = weights.random_wasb_state_dict(seed, in_ch=3, head_out=13)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected and all('num_batches_tracked' in k for k in missing)
+        m.eval()
+        x = np.random.default_rng(seed).standard_normal((b, 3, h, w)).astype(np.float32)
+        with torch.no_grad():
+            heat = m(torch.from_numpy(x)).numpy()
+        out[name + '/heat'] = heat
+        out[name + '/meta'] = np.array([seed, b, h, w], np.int64)
+        o = wasb_ref.hrnet_forward(torch.from_numpy(x), sd)[0]
+        print('table %-14s heat %s max|ref-oracle| = %.3e' % (name, heat.shape, float((o - torch.from_numpy(heat)).abs().max())))
+    # DBSCAN filter: 13 keypoints over 40 frames, two detectors, outliers / invisibles / too-few-detections cases
+    rng = np.random.default_rng(53)
+    T = 40
+    true = np.stack([rng.uniform(100, 1800, 13), rng.uniform(100, 1000, 13)], 1)
+    p1 = np.zeros((T, 13, 3)); p2 = np.zeros((T, 13, 3))
+    for t in range(T):
+        p1[t, :, :2] = true + rng.normal(0, 1.5, (13, 2)); p1[t, :, 2] = 1
+        p2[t, :, :2] = true + rng.normal(0, 1.5, (13, 2)); p2[t, :, 2] = 1
+    p1[::5, 3, :2] += 300            # outliers for keypoint 3
+    p2[:, 7, 2] = 0                  # keypoint 7 invisible in the second detector
+    p1[2:, 9, 2] = 0                 # keypoint 9: only two usable detections
+    p2[:, 11, :2] += 50              # detectors disagree on keypoint 11
+    p1[20:, 5, :2] += 60; p2[20:, 5, :2] += 60       # two clusters for keypoint 5
+    out['filter/p1'] = p1; out['filter/p2'] = p2
+    out['filter/out'] = filter_trajectory_table(p1, p2)
+    np.savez_compressed(os.path.join(OUT, 'table.npz'), **out)
+    print('table filter ->', out['filter/out'][[3, 5, 7, 9, 11]].tolist())
+
+
 def gen_fullsize():
     """One 704x1280 planted-peak run through the reference CNN + both refine variants."""
     from upliftingtabletennis_amd import weights, synth
@@ -278,6 +325,6 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full']
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table}[w_]()

@@ -60,12 +60,12 @@ int launch_nchw_to_nhwc(const float* src, void* dst, int batch, int cin, int cpa
 // NHWC (any dtype) -> float32 NCHW (debug taps)
 int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, int w, int dtype, hipStream_t stream);
 
-// head: 1x1 conv cin -> one selected output channel (+bias), float32 (B,1,H,W) out
-int launch_head(const void* src, const float* w_dev /*[cin]*/, float bias, float* heat, int batch, int h, int w, int cin,
+// head: 1x1 conv cin -> n_out output channels (+bias), float32 (B,n_out,H,W) out; w_dev [n_out][cin], bias_dev [n_out]
+int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin,
                 int dtype, hipStream_t stream);
 
 // uint8 frames -> normalised triples: see ttup_preprocess_triples.  out NCHW f32 or NHWC16 (dtype of the net)
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
-                      void* out, int out_layout, int dtype, int first_triple, int n_triples, hipStream_t stream);
+                      void* out, int out_layout, int dtype, int first_triple, int n_triples, int frames_per_sample, hipStream_t stream);
 
 }  // namespace ttup

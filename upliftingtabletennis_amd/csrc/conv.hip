@@ -1245,22 +1245,29 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, in
     return TTUP_OK;
 }
 
+// head: 1x1 conv 16 -> n_out selected output channels (+bias), fp32 NCHW (B, n_out, H, W) out
 template <typename T, int CIN>
-__global__ void head_kernel(const T* src, const float* w, float bias, float* heat, long long npix) {
+__global__ void head_kernel(const T* src, const float* w, const float* bias, int n_out, float* heat, long long hw, long long npix) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    float acc = 0.f;
+    float x[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) acc = fmaf(ld(src + i * CIN + c), w[c], acc);
-    heat[i] = acc + bias;
+    for (int c = 0; c < CIN; ++c) x[c] = ld(src + i * CIN + c);
+    const long long b = i / hw, pix = i % hw;
+    for (int k = 0; k < n_out; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc = fmaf(x[c], w[k * CIN + c], acc);
+        heat[(b * n_out + k) * hw + pix] = acc + bias[k];
+    }
 }
 
-int launch_head(const void* src, const float* w_dev, float bias, float* heat, int batch, int h, int w, int cin, int dtype, hipStream_t stream) {
+int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin, int dtype, hipStream_t stream) {
     TTUP_REQUIRE(cin == 16, TTUP_EINVAL, "head expects 16 input channels, got %d", cin);
-    const long long npix = (long long)batch * h * w;
+    const long long hw = (long long)h * w, npix = (long long)batch * hw;
     const unsigned blocks = (unsigned)((npix + 255) / 256);
-    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3(blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias, heat, npix);
-    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias, heat, npix);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3(blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias_dev, n_out, heat, hw, npix);
+    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias_dev, n_out, heat, hw, npix);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -1271,6 +1278,7 @@ int launch_head(const void* src, const float* w_dev, float bias, float* heat, in
 struct PreArgs {
     const uint8_t* frames; void* out; int src_h, src_w, dst_h, dst_w, first_triple, n_triples, layout; long long total;
     double scale_x, scale_y;
+    int nf;                // frames per sample: 3 (ball triples t,t+1,t+2) or 1 (table detector, single frame)
     const float* lut;      // [3][256]: (v/255 - mean[c]) / std[c] evaluated in fp64 on the host, rounded to fp32
 };
 
@@ -1296,7 +1304,7 @@ __device__ __forceinline__ void axis_tap_y(int d, double scale, int src_n, int& 
 
 template <typename T>
 __global__ void preprocess_kernel(PreArgs a) {
-    // one thread per (triple, y, x): produces the 9 channels of that pixel
+    // one thread per (sample, y, x): produces the 3*nf channels of that pixel
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
     const int x = (int)(i % a.dst_w);
@@ -1310,7 +1318,9 @@ __global__ void preprocess_kernel(PreArgs a) {
         axis_tap_y(y, a.scale_y, a.src_h, y0, y1, b0, b1);
     }
     float vals[9];
-    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vals[k] = 0.f;
+    for (int f = 0; f < a.nf; ++f) {
         const uint8_t* img = a.frames + (size_t)(a.first_triple + t + f) * a.src_h * a.src_w * 3;
         for (int c = 0; c < 3; ++c) {
             int v;
@@ -1327,8 +1337,8 @@ __global__ void preprocess_kernel(PreArgs a) {
     }
     const size_t hw = (size_t)a.dst_h * a.dst_w, pix = (size_t)y * a.dst_w + x;
     if (a.layout == TTUP_LAYOUT_NCHW_F32) {
-        float* o = (float*)a.out + (size_t)t * 9 * hw + pix;
-        for (int c = 0; c < 9; ++c) o[c * hw] = vals[c];
+        float* o = (float*)a.out + (size_t)t * 3 * a.nf * hw + pix;
+        for (int c = 0; c < 3 * a.nf; ++c) o[c * hw] = vals[c];
     } else {
         T* o = (T*)a.out + ((size_t)t * hw + pix) * 16;
         if (sizeof(T) == 2) {
@@ -1342,11 +1352,12 @@ __global__ void preprocess_kernel(PreArgs a) {
 }
 
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
-                      void* out, int out_layout, int dtype, int first_triple, int n_triples, hipStream_t stream) {
-    TTUP_REQUIRE(first_triple >= 0 && first_triple + n_triples + 2 <= n_frames, TTUP_EINVAL, "triple range outside the clip");
+                      void* out, int out_layout, int dtype, int first_triple, int n_triples, int frames_per_sample, hipStream_t stream) {
+    TTUP_REQUIRE(frames_per_sample == 1 || frames_per_sample == 3, TTUP_EINVAL, "frames_per_sample must be 1 or 3");
+    TTUP_REQUIRE(first_triple >= 0 && first_triple + n_triples + frames_per_sample - 1 <= n_frames, TTUP_EINVAL, "sample range outside the clip");
     PreArgs a;
     a.frames = frames; a.out = out; a.src_h = src_h; a.src_w = src_w; a.dst_h = dst_h; a.dst_w = dst_w;
-    a.first_triple = first_triple; a.n_triples = n_triples; a.layout = out_layout;
+    a.first_triple = first_triple; a.n_triples = n_triples; a.layout = out_layout; a.nf = frames_per_sample;
     a.total = (long long)n_triples * dst_h * dst_w;
     a.scale_x = (double)src_w / dst_w; a.scale_y = (double)src_h / dst_h;
     if (a.total == 0) return TTUP_OK;

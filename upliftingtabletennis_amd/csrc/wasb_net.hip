@@ -55,7 +55,8 @@ struct ttup_wasb {
     std::vector<Op> ops;
     std::map<std::string, int> taps;
     int t_input = -1, t_out = -1;
-    float* head_w_dev = nullptr; float head_bias = 0.f;
+    float* head_w_dev = nullptr; float* head_b_dev = nullptr; float head_bias = 0.f;
+    int n_out = 1;                      // heatmap channels returned: 1 (ball: channel 1 of 3, wasb.py:606) or all 13 (table, hrnet.py:586-589)
     float* heat_scratch = nullptr;      // (micro,H,W) when the caller does not want heatmaps
     void* refine_ws = nullptr; size_t refine_ws_bytes = 0;
     long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
@@ -67,6 +68,7 @@ struct ttup_wasb {
         for (auto& c : convs) free_conv(&c);
         for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
         if (head_w_dev) (void)hipFree(head_w_dev);
+        if (head_b_dev) (void)hipFree(head_b_dev);
         if (heat_scratch) (void)hipFree(heat_scratch);
         if (refine_ws) (void)hipFree(refine_ws);
         if (argmax_scratch) (void)hipFree(argmax_scratch);
@@ -314,7 +316,7 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     xs = {ys[0], ys[1], ys[2], b.conv(ys[2], 128, 3, 2, 1)};
     ys = b.stage(xs, 1);
     net->t_out = ys[0];
-    if (net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE") && net->ops.back().kind == Op::UPSUM && net->ops.back().dst == ys[0]) {
+    if (net->dtype == TTUP_DTYPE_BF16 && net->n_out == 1 && !getenv("TTUP_NO_FUSE") && net->ops.back().kind == Op::UPSUM && net->ops.back().dst == ys[0]) {
         net->ops.back().kind = Op::UPSUM_HEAD;        // stage-4 output 0 is consumed in registers and never stored
         net->fused_head = true;
     } else {
@@ -369,15 +371,16 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
                  int batch, float* heat_dev, int64_t* argmax_dev, float* win_dev, hipStream_t st) {
     const int H = net->H, W = net->W;
     const size_t hw = (size_t)H * W;
+    const int K = net->n_out;
     for (int b0 = 0; b0 < batch; b0 += net->micro) {
         const int mb = batch - b0 < net->micro ? batch - b0 : net->micro;
         int rc;
         if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
-        else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, st);
+        else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, net->in_ch / 3, st);
         if (rc) return rc;
         rc = run_ops(net, mb, st);
         if (rc) return rc;
-        float* heat = heat_dev ? heat_dev + (size_t)b0 * hw : net->heat_scratch;
+        float* heat = heat_dev ? heat_dev + (size_t)b0 * K * hw : net->heat_scratch;
         if (net->fused_head) {
             const Op& op = net->ops.back();
             const void* terms[3] = {nullptr, nullptr, nullptr};
@@ -390,12 +393,12 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
             if (rc) return rc;
             continue;
         }
-        rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_bias, heat, mb, H, W, 16, net->dtype, st);
+        rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st);
         if (rc) return rc;
         if (argmax_dev || win_dev) {
-            long long* am = argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch;
-            float* wn = win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch;
-            rc = refine_argmax(heat, mb, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
+            long long* am = argmax_dev ? (long long*)argmax_dev + (size_t)b0 * K : net->argmax_scratch;
+            float* wn = win_dev ? win_dev + (size_t)b0 * K * 9 : net->win_scratch;
+            rc = refine_argmax(heat, mb * K, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
             if (rc) return rc;
         }
     }
@@ -419,9 +422,10 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     int in_ch = 0, head_out = 0;
     int rc = parse_blob(blob, blob_bytes, &folded, &in_ch, &head_out, &head_w, &head_b);
     if (rc) return rc;
-    TTUP_REQUIRE(in_ch == 9 && head_out == 3, TTUP_EFORMAT, "wasb blob: in_ch=%d head_out=%d unsupported (ball detector is 9/3)", in_ch, head_out);
+    TTUP_REQUIRE((in_ch == 9 || in_ch == 3) && head_out >= 1 && head_out <= 16, TTUP_EFORMAT, "wasb blob: in_ch=%d head_out=%d unsupported (ball detector 9/3, table detector 3/13)", in_ch, head_out);
     std::unique_ptr<ttup_wasb> net(new ttup_wasb);
     net->H = height; net->W = width; net->max_batch = max_batch; net->dtype = dtype; net->in_ch = in_ch;
+    net->n_out = head_out == 3 ? 1 : head_out;       // ball detector keeps the middle of its 3 channels (wasb.py:606)
     // micro-batch: enough tiles to fill 256 CUs, small enough that layer outputs stay cache-friendly
     const char* env = getenv("TTUP_MICRO_BATCH");
     int micro = env ? atoi(env) : 8;
@@ -429,17 +433,23 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     net->micro = micro < max_batch ? micro : max_batch;
     rc = build(net.get(), folded);
     if (rc) return rc;
-    // head: keep only channel 1 of the 3 (wasb.py:606)
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->head_w_dev, 16 * sizeof(float)));
-    TTUP_HIP_CHECK(hipMemcpy(net->head_w_dev, head_w.data() + 16, 16 * sizeof(float), hipMemcpyHostToDevice));
-    net->head_bias = head_b[1];
+    // head weights of the returned channels: the ball detector keeps only channel 1 of its 3 (wasb.py:606), the table
+    // detector all 13 (tabledetection/models/hrnet.py:586-589)
+    {
+        const int first = head_out == 3 ? 1 : 0;
+        TTUP_HIP_CHECK(hipMalloc((void**)&net->head_w_dev, (size_t)net->n_out * 16 * sizeof(float)));
+        TTUP_HIP_CHECK(hipMemcpy(net->head_w_dev, head_w.data() + (size_t)first * 16, (size_t)net->n_out * 16 * sizeof(float), hipMemcpyHostToDevice));
+        TTUP_HIP_CHECK(hipMalloc((void**)&net->head_b_dev, (size_t)net->n_out * sizeof(float)));
+        TTUP_HIP_CHECK(hipMemcpy(net->head_b_dev, head_b.data() + first, (size_t)net->n_out * sizeof(float), hipMemcpyHostToDevice));
+        net->head_bias = head_b[first];
+    }
     const size_t hw = (size_t)height * width;
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->heat_scratch, (size_t)net->micro * hw * sizeof(float)));
-    net->refine_ws_bytes = ttup_refine_workspace_bytes(net->micro, height, width);
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->heat_scratch, (size_t)net->micro * net->n_out * hw * sizeof(float)));
+    net->refine_ws_bytes = ttup_refine_workspace_bytes(net->micro * net->n_out, height, width);
     if (upsum_head_ws_bytes(net->micro, height, width) > net->refine_ws_bytes) net->refine_ws_bytes = upsum_head_ws_bytes(net->micro, height, width);
     TTUP_HIP_CHECK(hipMalloc(&net->refine_ws, net->refine_ws_bytes));
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->argmax_scratch, (size_t)net->micro * sizeof(long long)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->win_scratch, (size_t)net->micro * 9 * sizeof(float)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->argmax_scratch, (size_t)net->micro * net->n_out * sizeof(long long)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&net->win_scratch, (size_t)net->micro * net->n_out * 9 * sizeof(float)));
     TTUP_HIP_CHECK(hipDeviceSynchronize());
     *out = net.release();
     return TTUP_OK;
@@ -460,8 +470,9 @@ extern "C" int ttup_wasb_forward(ttup_wasb* net, const float* x_dev, int batch, 
 extern "C" int ttup_wasb_forward_frames(ttup_wasb* net, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
                                         float* heat_dev, int64_t* argmax_dev, float* win_dev, void* stream) {
     TTUP_REQUIRE(net && frames_dev, TTUP_EINVAL, "ttup_wasb_forward_frames: null pointer");
-    TTUP_REQUIRE(n_frames >= 3 && src_h > 0 && src_w > 0, TTUP_EINVAL, "ttup_wasb_forward_frames: need at least 3 frames");
-    const int batch = n_frames - 2;
+    const int nf = net->in_ch / 3;       // 3 frames per sample for the ball detector, 1 for the table detector
+    TTUP_REQUIRE(n_frames >= nf && src_h > 0 && src_w > 0, TTUP_EINVAL, "ttup_wasb_forward_frames: need at least %d frames", nf);
+    const int batch = n_frames - (nf - 1);
     TTUP_REQUIRE(batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_forward_frames: %d triples exceed max_batch %d", batch, net->max_batch);
     return forward_impl(net, nullptr, frames_dev, n_frames, src_h, src_w, batch, heat_dev, argmax_dev, win_dev, (hipStream_t)stream);
 }
@@ -531,7 +542,15 @@ extern "C" int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, 
                                        float* out_dev, void* stream) {
     TTUP_REQUIRE(frames_dev && out_dev, TTUP_EINVAL, "ttup_preprocess_triples: null pointer");
     TTUP_REQUIRE(n_frames >= 3 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, TTUP_EINVAL, "ttup_preprocess_triples: bad shape");
-    return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames - 2, (hipStream_t)stream);
+    return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames - 2, 3, (hipStream_t)stream);
+}
+
+extern "C" int ttup_preprocess_frames(const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
+                                      float* out_dev, void* stream) {
+    TTUP_REQUIRE(frames_dev && out_dev, TTUP_EINVAL, "ttup_preprocess_frames: null pointer");
+    TTUP_REQUIRE(n_frames >= 1 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, TTUP_EINVAL, "ttup_preprocess_frames: bad shape");
+    return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames, 1, (hipStream_t)stream);
 }
 
 extern "C" int ttup_wasb_micro_batch(ttup_wasb* net) { return net ? net->micro : 0; }
+extern "C" int ttup_wasb_out_channels(ttup_wasb* net) { return net ? net->n_out : 0; }

@@ -1,5 +1,6 @@
-"""a5: host-side glue between the detector and the uplift network (tiny, per-trajectory, stays on the host as in
-the reference): ``filter_trajectory_ball`` (inference/utils.py:70-102) and ``_uplifting_transform`` (:268-309)."""
+"""a5: host-side glue between the detectors and the uplift network (tiny, per-trajectory, stays on the host as in
+the reference): ``filter_trajectory_ball`` (inference/utils.py:70-102), ``_uplifting_transform`` (:268-309) and, for
+the table detector (f1), ``filter_trajectory_table`` with its DBSCAN clustering (:137-232)."""
 import numpy as np
 import torch
 
@@ -44,3 +45,41 @@ def _uplifting_transform(ball_coords, table_coords, times, seq_len=SEQ_LEN):
         times = torch.tensor(np.asarray(times)[:seq_len], dtype=torch.float32).unsqueeze(0)
         mask = torch.ones((1, seq_len), dtype=torch.float32)
     return ball, table, times, mask
+
+
+KEYPOINT_VISIBLE, KEYPOINT_INVISIBLE = 1, 0
+
+
+def _filter_keypoints_with_dbscan(detections, eps=10, min_samples=5):
+    """Centroid of the largest DBSCAN cluster of one keypoint's detections over time (inference/utils.py:184-232)."""
+    from collections import Counter
+    from sklearn.cluster import DBSCAN
+    detections = np.asarray(detections)
+    if detections.shape[0] < min_samples:
+        return np.mean(detections, axis=0) if detections.shape[0] > 0 else None
+    labels = DBSCAN(eps=eps, min_samples=min_samples).fit(detections).labels_
+    valid = [l for l in labels if l != -1]
+    if not valid:
+        return np.mean(detections, axis=0)
+    largest = Counter(valid).most_common(1)[0][0]
+    return np.mean(detections[labels == largest], axis=0)
+
+
+def filter_trajectory_table(pred_positions1, pred_positions2):
+    """(T,13,3) x 2 -> (13,3): keep frames where both detectors see a keypoint within 10 px, cluster, take the centroid
+    (inference/utils.py:137-180)."""
+    threshold = 10
+    p1, p2 = np.asarray(pred_positions1), np.asarray(pred_positions2)
+    out = []
+    for n in range(p1.shape[1]):
+        vx, vy = [], []
+        for t in range(p1.shape[0]):
+            if p1[t, n, 2] == KEYPOINT_VISIBLE and p2[t, n, 2] == KEYPOINT_VISIBLE:
+                if np.linalg.norm([p1[t, n, 0] - p2[t, n, 0], p1[t, n, 1] - p2[t, n, 1]]) < threshold:
+                    vx.append(p1[t, n, 0]); vy.append(p1[t, n, 1])
+        if len(vx) < 3:
+            out.append([-1, -1, KEYPOINT_INVISIBLE])
+        else:
+            pt = _filter_keypoints_with_dbscan(np.stack([vx, vy], axis=1), eps=10, min_samples=3)
+            out.append([pt[0], pt[1], KEYPOINT_VISIBLE] if pt is not None else [-1, -1, KEYPOINT_INVISIBLE])
+    return np.array(out)

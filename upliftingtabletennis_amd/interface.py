@@ -7,8 +7,8 @@ Differences forced by the environment (documented in DESIGN.md):
     seeded generators in ``weights.py`` (``TTUP_SYNTHETIC_WEIGHTS=1`` makes that explicit);
   * only the in-tree WASB/HRNet detector is built; 'segformerpp_*' needs the un-vendored
     KieDani/SegformerPlusPlus hub repo and raises NotImplementedError;
-  * the table detector is out of scope this round: ``TableTennisPipeline.predict`` takes the
-    13 table keypoints as an optional argument instead of running a second CNN.
+  * table detection uses the in-tree HRNet ('hrnet'); when a detector's primary SegFormer++ model is unavailable the
+    auxiliary in-tree model stands in for both sides of the two-detector agreement filter.
 Quirks kept on purpose: BGR frames are fed to the detector as they come (interface.py:96,104-110); the
 *table* variant of the refine is used on the hub surface (interface.py:116); visibility is always 1.
 """
@@ -89,6 +89,48 @@ class BallDetector:
         return glue.filter_trajectory_ball(ball_positions, ball_positions_aux, fps)
 
 
+def _load_table_checkpoint(model_name):
+    """-> (state_dict, resolution (W,H)).  Reference: inference_tabledetection.load_model :40-57."""
+    path = os.path.join(_weights_dir(), 'inference_tabledetection', model_name, 'model.pt')
+    if _weights_dir() and os.path.exists(path):
+        sd, info = weights.load_checkpoint_state_dict(path)
+        return sd, tuple(info.get('image_resolution', (1280, 704)))
+    if _weights_dir():
+        raise RuntimeError('Failed to load weights: %s not found' % path)
+    return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')) + 1, planted=False, in_ch=3, head_out=13), (1280, 704)
+
+
+class TableDetector:
+    def __init__(self, model_name='hrnet', max_batch=8, dtype='bf16'):
+        if 'segformerpp' in model_name or model_name == 'vitpose':
+            raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference; only 'hrnet' is built" % model_name)
+        _lib.require_gpu()
+        self.device = torch.device('cuda')
+        self.resolution = (WIDTH, HEIGHT)
+        self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
+        sd, res = _load_table_checkpoint(model_name)
+        self.model = wasb.get_table_model(model_name, resolution=res, pretraining=False, state_dict=sd, max_batch=max_batch, dtype=dtype)
+        self.model_resolution = res
+        self.max_batch = max_batch
+
+    def predict(self, images):
+        """images: list (length B) of BGR uint8 HWC frames.
+        Returns (pred_pos (B,13,3) float64 [x, y, visibility] in 1920x1080 px, preds (B,13,H,W) float32)."""
+        pred_pos, preds = [], []
+        w, h = self.model_resolution
+        for b0 in range(0, len(images), self.max_batch):
+            fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[b0:b0 + self.max_batch]])).to(self.device)
+            heat = self.model(wasb.preprocess_frames(fr, (w, h)))
+            pred_pos.append(refine.extract_position_table(heat, self.resolution[0], self.resolution[1]))
+            preds.append(heat.cpu().numpy())
+        if not pred_pos:
+            return np.zeros((0, 13, 3)), np.zeros((0, 13, h, w), np.float32)
+        return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
+
+    def filter_trajectory(self, table_keypoints, table_keypoints_aux):
+        return glue.filter_trajectory_table(table_keypoints, table_keypoints_aux)
+
+
 class UpliftingModel:
     def __init__(self, max_len=128):
         _lib.require_gpu()
@@ -134,15 +176,19 @@ class TableTennisPipeline:
         self.device = torch.device('cuda')
         self.ball_detector = BallDetector(model_name='wasb', max_batch=max_batch)
         self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
+        self.table_detector = TableDetector(model_name='hrnet')
+        self.table_detector_aux = self.table_detector
         self.uplifting_model = UpliftingModel()
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
 
     def predict(self, images, fps, table_keypoints=None):
         """images: list of BGR frames of one rally; fps: frame rate.  table_keypoints: (13,3) [x,y,vis] in 1920x1080 px
-        (the reference detects them with a second CNN, interface.py:281-283 -- out of scope here).
+        (optional override; by default they are detected with the in-tree HRNet like interface.py:281-283).
         Returns (pred_spin torch (3,), pred_pos_3d numpy (T',3))."""
-        if table_keypoints is None:
-            raise ValueError('table_keypoints (13,3) must be supplied: the table detector is not part of this build')
+        if table_keypoints is None:        # 2. table detection (interface.py:281-283)
+            kp, _ = self.table_detector.predict(images)
+            kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict(images)[0]
+            table_keypoints = self.table_detector_aux.filter_trajectory(kp, kp_aux)
         image_triples = [(images[i - 1], images[i], images[i + 1]) for i in range(1, len(images) - 1)]
         ball_positions, _ = self.ball_detector.predict(image_triples)
         ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict(image_triples)[0]

@@ -17,17 +17,18 @@ RESOLUTIONS = {'wasb': (1280, 704)}     # balldetection/config.py:84-85 (width, 
 
 class WASBNet:
     """Callable like the reference nn.Module.  ``resolution`` is (W, H) as in the reference."""
+    IN_CH, HEAD_OUT, OUT_CH = 9, 3, 1
 
     def __init__(self, state_dict, resolution=(1280, 704), in_frames=3, max_batch=64, dtype='bf16', device='cuda:0'):
         _lib.require_gpu()
-        if in_frames != 3:
-            raise ValueError('only in_frames=3 (9 input channels) is built')
+        if in_frames * 3 != self.IN_CH:
+            raise ValueError('only in_frames=%d (%d input channels) is built' % (self.IN_CH // 3, self.IN_CH))
         self.device = torch.device(device)
         self.W, self.H = int(resolution[0]), int(resolution[1])
         self.max_batch = int(max_batch)
         self.dtype = dtype
         self._lib = _lib.load()
-        blob = weights.pack_wasb_blob(state_dict)
+        blob = weights.pack_wasb_blob(state_dict, in_ch=self.IN_CH, head_out=self.HEAD_OUT)
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             rc = self._lib.ttup_wasb_create(blob, len(blob), self.H, self.W, self.max_batch,
@@ -47,17 +48,18 @@ class WASBNet:
             self._lib.ttup_wasb_destroy(h)
 
     def forward(self, x, want_heatmap=True, want_peaks=False):
-        if x.dim() != 4 or x.shape[1] != 9 or x.shape[2] != self.H or x.shape[3] != self.W:
-            raise ValueError('expected input (B,9,%d,%d), got %s' % (self.H, self.W, tuple(x.shape)))
+        if x.dim() != 4 or x.shape[1] != self.IN_CH or x.shape[2] != self.H or x.shape[3] != self.W:
+            raise ValueError('expected input (B,%d,%d,%d), got %s' % (self.IN_CH, self.H, self.W, tuple(x.shape)))
         x = x.to(self.device, torch.float32).contiguous()
         b = x.shape[0]
         outs = []
         for b0 in range(0, b, self.max_batch):
             xb = x[b0:b0 + self.max_batch]
             nb = xb.shape[0]
-            heat = torch.empty((nb, 1, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
-            idx = torch.empty((nb,), dtype=torch.int64, device=self.device) if want_peaks else None
-            win = torch.empty((nb, 9), dtype=torch.float32, device=self.device) if want_peaks else None
+            k = self.OUT_CH
+            heat = torch.empty((nb, k, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
+            idx = torch.empty((nb * k,), dtype=torch.int64, device=self.device) if want_peaks else None
+            win = torch.empty((nb * k, 9), dtype=torch.float32, device=self.device) if want_peaks else None
             with torch.cuda.device(self.device):
                 rc = self._lib.ttup_wasb_forward(self._handle, _lib.ptr(xb), nb, _lib.ptr(heat), _lib.ptr(idx), _lib.ptr(win), _lib.stream_ptr())
             _lib.check(rc)
@@ -76,12 +78,13 @@ class WASBNet:
             raise ValueError('frames must be uint8 (N,h,w,3)')
         frames_u8 = frames_u8.to(self.device).contiguous()
         n = frames_u8.shape[0]
-        nb = n - 2
+        nb = n - (self.IN_CH // 3 - 1)
         if nb > self.max_batch:
-            raise ValueError('%d triples exceed max_batch %d' % (nb, self.max_batch))
-        heat = torch.empty((nb, 1, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
-        idx = torch.empty((nb,), dtype=torch.int64, device=self.device)
-        win = torch.empty((nb, 9), dtype=torch.float32, device=self.device)
+            raise ValueError('%d samples exceed max_batch %d' % (nb, self.max_batch))
+        k = self.OUT_CH
+        heat = torch.empty((nb, k, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
+        idx = torch.empty((nb * k,), dtype=torch.int64, device=self.device)
+        win = torch.empty((nb * k, 9), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self._lib.ttup_wasb_forward_frames(self._handle, _lib.ptr(frames_u8), n, frames_u8.shape[1], frames_u8.shape[2],
                                                     _lib.ptr(heat), _lib.ptr(idx), _lib.ptr(win), _lib.stream_ptr())
@@ -95,6 +98,43 @@ class WASBNet:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ttup_wasb_read_tap(self._handle, name.encode(), batch, _lib.ptr(out), ctypes.byref(c), ctypes.byref(h), ctypes.byref(w), _lib.stream_ptr()))
         return out
+
+
+class MyHRNet(WASBNet):
+    """Table-keypoint detector: reference tabledetection/models/hrnet.py:510-589 -- the same HRNet with a
+    3-channel single-frame input and 13 heatmap channels; ``model(x) -> heat (B,13,H,W)`` (a tensor, not a tuple)."""
+    IN_CH, HEAD_OUT, OUT_CH = 3, 13, 13
+
+    def __init__(self, state_dict, resolution=(1280, 704), max_batch=16, dtype='bf16', device='cuda:0'):
+        super().__init__(state_dict, resolution=resolution, in_frames=1, max_batch=max_batch, dtype=dtype, device=device)
+        self.number_output_channels = 13
+
+    def forward(self, x, want_peaks=False):
+        out = super().forward(x, want_heatmap=True, want_peaks=want_peaks)
+        return out if want_peaks else out[0]
+
+    __call__ = forward
+
+
+def get_table_model(model_name, resolution, pretraining=False, state_dict=None, **kw):
+    """Mirror of tabledetection/train.py:205-226 for the in-tree HRNet."""
+    if model_name != 'hrnet':
+        raise ValueError('Model %s not implemented (only the in-tree HRNet table detector is built)' % model_name)
+    if state_dict is None:
+        raise ValueError('a state_dict is required (no weights can be downloaded offline)')
+    return MyHRNet(state_dict, resolution=resolution, **kw)
+
+
+def preprocess_frames(frames_u8, dst_wh):
+    """Single-frame pre-processing on the GPU: (N,h,w,3) uint8 -> (N,3,H,W) float32 (interface.py:160-165)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    frames_u8 = frames_u8.contiguous()
+    n, h, w, _ = frames_u8.shape
+    out = torch.empty((n, 3, dst_wh[1], dst_wh[0]), dtype=torch.float32, device=frames_u8.device)
+    with torch.cuda.device(frames_u8.device):
+        _lib.check(lib.ttup_preprocess_frames(_lib.ptr(frames_u8), n, h, w, dst_wh[1], dst_wh[0], _lib.ptr(out), _lib.stream_ptr()))
+    return out
 
 
 def get_model(model_name, in_frames, resolution, pretraining=False, state_dict=None, **kw):
