@@ -11,8 +11,9 @@
 //   linear_kernel   out = [relu](LN?(x) W^T + b) [+ res] on v_mfma_f32_16x16x4_f32 (exact fp32 products,
 //                   fp32 accumulate).  W is the A operand (pre-packed per lane on the host), the token
 //                   tile is the B operand read from LDS, so a lane owns 4 consecutive outputs of one token.
-//   attention_kernel  per (sequence, head): RoPE(q,k) on load, additive {0,-inf} row+column mask, online
-//                   softmax in registers; a fully masked query row yields zeros (torch SDPA semantics).
+//   attention_kernel  per (sequence, head): RoPE(q,k) on load from a per-forward (cos,sin) table, additive {0,-inf}
+//                   row+column mask, online softmax in registers; a fully masked query row yields zeros (torch SDPA
+//                   semantics).  Short sequences (the 14-token table stage) share a wave four at a time.
 #include "common.h"
 #include <math.h>
 #include <string.h>
@@ -43,73 +44,118 @@ struct LinArgs {
 };
 
 // K permutation shared by the packed weights and the LDS image: MFMA k-step s, k-lane q  <->  k = q*(K/4) + s
-template <bool LN>
-__global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];      // [4][64][K/4 + 4]
-    const int K = a.K, KQ = K / 4, RS = KQ + 4, PLANE = 64 * RS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 128;
-    // ---- stage 64 token rows (LayerNorm applied on the way in)
-    for (int r = wave * 16; r < wave * 16 + 16; ++r) {
-        const int m = m0 + r;
-        if (m < a.M) {
-            const float* xr = a.x + (size_t)m * a.ldx;
-            float mean = 0.f, rstd = 1.f;
+// Workgroup tile: 64*MH token rows x 64*NTW outputs, 4*MH waves; wave (wm, wn) owns rows wm*64.. and N-tiles wn + 4t.
+template <bool LN, int NTW, int MH>
+__global__ __launch_bounds__(256 * MH) void linear_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [4][64*MH][K/4 + 4]
+    constexpr int BM = 64 * MH;
+    const int K = a.K, KQ = K / 4, RS = KQ + 4, PLANE = BM * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * NTW);
+    // ---- stage the token rows (LayerNorm applied on the way in): 16 lanes per row, float4 per lane per 64 features
+    {
+        const int grp = tid >> 4, l16 = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = grp + i * 16 * MH, m = m0 + r;
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (l16 + 16 * u);
+                v[u] = (m < a.M && k < K) ? *(const f32x4*)(a.x + (size_t)m * a.ldx + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (LN) {
-                float s = 0.f;
-                for (int k = lane; k < K; k += 64) s += xr[k];
-                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-                mean = s / (float)K;
-                float v = 0.f;
-                for (int k = lane; k < K; k += 64) { const float d = xr[k] - mean; v += d * d; }
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                rstd = 1.0f / sqrtf(v / (float)K + 1e-5f);
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                const float mean = sum / (float)K;
+                float var = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (4 * (l16 + 16 * u) >= K) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+                }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+                const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * (l16 + 16 * u);
+                    if (k >= K) continue;
+                    const f32x4 g = *(const f32x4*)(a.gamma + k), bt = *(const f32x4*)(a.beta + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + bt[e];
+                }
             }
-            for (int k = lane; k < K; k += 64) {
-                float v = xr[k];
-                if (LN) v = (v - mean) * rstd * a.gamma[k] + a.beta[k];
-                xs[(k / KQ) * PLANE + r * RS + (k % KQ)] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (l16 + 16 * u);
+                if (k < K) *(f32x4*)(xs + (k / KQ) * PLANE + r * RS + (k % KQ)) = v[u];
             }
-        } else {
-            for (int k = lane; k < K; k += 64) xs[(k / KQ) * PLANE + r * RS + (k % KQ)] = 0.f;
         }
     }
     __syncthreads();
     const int q = lane >> 4, c = lane & 15;
-    f32x4 acc[2][4];
+    f32x4 acc[NTW][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = (a.N + 15) / 16;
-    int nt_g[2]; bool nt_ok[2];
+    int nt_g[NTW]; bool nt_ok[NTW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { nt_g[t] = n0 / 16 + wave + 4 * t; nt_ok[t] = nt_g[t] < ntiles; }
+    for (int t = 0; t < NTW; ++t) { nt_g[t] = n0 / 16 + wn + 4 * t; nt_ok[t] = nt_g[t] < ntiles; }
     const int ks4 = K / 16;
+    const float* xw = xs + q * PLANE + (wm * 64 + c) * RS;
+    f32x4 wa[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+        wa[t] = nt_ok[t] ? *(const f32x4*)(a.w + (((size_t)nt_g[t] * ks4) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s4 = 0; s4 < ks4; ++s4) {
         f32x4 xb[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xb[mt] = *(const f32x4*)(xs + q * PLANE + (mt * 16 + c) * RS + s4 * 4);
-        f32x4 wa[2];
+        for (int mt = 0; mt < 4; ++mt) xb[mt] = *(const f32x4*)(xw + mt * 16 * RS + s4 * 4);
+        f32x4 wn_[NTW];
+        const int sn = s4 + 1 < ks4 ? s4 + 1 : s4;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            wa[t] = nt_ok[t] ? *(const f32x4*)(a.w + (((size_t)nt_g[t] * ks4 + s4) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t)
+            wn_[t] = nt_ok[t] ? *(const f32x4*)(a.w + (((size_t)nt_g[t] * ks4 + sn) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NTW; ++t)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][j], xb[mt][j], acc[t][mt], 0, 0, 0);
-    }
-    // ---- epilogue: lane holds outputs n = nt*16 + 4*q + {0..3} of token m = m0 + mt*16 + c
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTW; ++t) wa[t] = wn_[t];
+    }
+    // ---- epilogue: lane holds outputs n = nt*16 + 4*q + {0..3} of token m = m0 + wm*64 + mt*16 + c
+    const bool vec = (a.N % 4 == 0) && (a.ldo % 4 == 0) && (!a.res || a.ldr % 4 == 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
         if (!nt_ok[t]) continue;
         const int n = nt_g[t] * 16 + 4 * q;
+        if (vec) {
+            if (n >= a.N) continue;
+            const f32x4 b4 = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wm * 64 + mt * 16 + c;
+                if (m >= a.M) continue;
+                f32x4 v = acc[t][mt] + b4;
+                if (a.relu) v = f32x4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+                if (a.res) v += *(const f32x4*)(a.res + (size_t)m * a.ldr + n);
+                *(f32x4*)(a.out + (size_t)m * a.ldo + n) = v;
+            }
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + mt * 16 + c;
+            const int m = m0 + wm * 64 + mt * 16 + c;
             if (m >= a.M) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -136,97 +182,109 @@ __global__ void small_linear_kernel(const float* x, int ldx, const float* w, con
 }
 
 // ------------------------------------------------------------------ attention
+// rope[r][i] = (cos, sin)(round(t_r / 0.002) * inv_freq[i]) for every time stamp r           (model.py:62-80)
+__global__ void rope_table_kernel(const float* times, const float* inv_freq, float2* rope, int half, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float pos = rintf(times[i / half] / 0.002f);          // round(t / (1/MAX_FPS)), model.py:72
+    const float f = pos * inv_freq[i % half];
+    rope[i] = make_float2(cosf(f), sinf(f));
+}
+
 struct AttnArgs {
     const float* qkv;   // [n_seq*S][3D]
     float* out;         // [n_seq*S][D]
     const float* mask;  // additive, row = seq / mask_div, S entries
-    const float* times; // row = (seq / times_div) * times_stride, S - num_cls entries
-    const float* inv_freq;
+    const float2* rope; // (cos, sin) rows of hd/2; row of token j = (seq / times_div) * times_stride + j - num_cls
     int n_seq, S, D, heads, hd, num_cls, mask_div, times_div, times_stride;
     float scale;
 };
 
-// one workgroup = one (sequence, head); K and V of the head live in LDS, each lane owns query rows lane, lane+64, ...
-template <int HD>
-__global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
+// P threads per (sequence, head); a workgroup of blockDim.x threads serves blockDim.x / P sequences.  K (rotated) and V
+// of each sequence live in LDS, thread i0 owns query rows i0, i0+P, ...
+template <int HD, int P>
+__global__ void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int S = a.S;
-    float* ks = sm;                // [S][HD+1]
-    float* vs = ks + S * (HD + 1); // [S][HD+1]
-    float* ms = vs + S * (HD + 1); // [S] additive mask
-    const int seq = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
-    const float* trow = a.times + (size_t)(seq / a.times_div) * a.times_stride;
-    const size_t tok0 = (size_t)seq * S;
-    const int D3 = 3 * a.D;
-    for (int j = lane; j < S; j += 64) {
-        const float* kp = a.qkv + (tok0 + j) * D3 + a.D + h * HD;
-        const float* vp = kp + a.D;
-        ms[j] = mrow[j];
+    const int S = a.S, G = blockDim.x / P;
+    const int SEQ = 2 * S * HD + 16;                 // floats per sequence; the +16 words spreads the groups over LDS banks
+    float* ms = sm + G * SEQ;                        // [G][S] additive mask
+    const int h = blockIdx.y, tid = threadIdx.x;
+    const int D3 = 3 * a.D, HV = HD / 4;
+    // ---- stage K (RoPE applied) and V, one float4 per thread per step, 128 B rows read by HV consecutive threads
+    for (int u = tid; u < G * S * HV; u += blockDim.x) {
+        const int g = u / (S * HV), rem = u - g * (S * HV), j = rem / HV, part = rem - j * HV;
+        const int seq = blockIdx.x * G + g;
+        if (seq >= a.n_seq) continue;
+        const float* kp = a.qkv + ((size_t)seq * S + j) * D3 + a.D + h * HD + part * 4;
+        f32x4 k = *(const f32x4*)kp;
+        const f32x4 v = *(const f32x4*)(kp + a.D);
         if (j >= a.num_cls) {
-            const float pos = rintf(trow[j - a.num_cls] / 0.002f);     // round(t / (1/MAX_FPS)), model.py:72
-#pragma unroll
-            for (int i = 0; i < HD / 2; ++i) {
-                const float f = pos * a.inv_freq[i];
-                const float cs = cosf(f), sn = sinf(f);
-                const float x0 = kp[2 * i], x1 = kp[2 * i + 1];
-                ks[j * (HD + 1) + 2 * i] = x0 * cs - x1 * sn;
-                ks[j * (HD + 1) + 2 * i + 1] = x0 * sn + x1 * cs;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < HD; ++i) ks[j * (HD + 1) + i] = kp[i];
+            const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)(seq / a.times_div) * a.times_stride + (j - a.num_cls)) * (HD / 2) + part * 2);
+            k = f32x4{k[0] * cs[0] - k[1] * cs[1], k[0] * cs[1] + k[1] * cs[0], k[2] * cs[2] - k[3] * cs[3], k[2] * cs[3] + k[3] * cs[2]};
         }
-#pragma unroll
-        for (int i = 0; i < HD; ++i) vs[j * (HD + 1) + i] = vp[i];
+        *(f32x4*)(sm + g * SEQ + j * HD + part * 4) = k;
+        *(f32x4*)(sm + g * SEQ + S * HD + j * HD + part * 4) = v;
+    }
+    for (int u = tid; u < G * S; u += blockDim.x) {
+        const int seq = blockIdx.x * G + u / S;
+        ms[u] = seq < a.n_seq ? a.mask[(size_t)(seq / a.mask_div) * S + (u % S)] : -INFINITY;
     }
     __syncthreads();
-    for (int i = lane; i < S; i += 64) {
-        float q[HD];
-        const float* qp = a.qkv + (tok0 + i) * D3 + h * HD;
+    const int g = tid / P, i0 = tid - g * P;
+    const int seq = blockIdx.x * G + g;
+    if (seq >= a.n_seq) return;
+    const float* ks = sm + g * SEQ;
+    const float* vs = ks + S * HD;
+    const float* mg = ms + g * S;
+    for (int i = i0; i < S; i += P) {
+        f32x4 q[HV];
+        const float* qp = a.qkv + ((size_t)seq * S + i) * D3 + h * HD;
+#pragma unroll
+        for (int d = 0; d < HV; ++d) q[d] = *(const f32x4*)(qp + 4 * d);
         if (i >= a.num_cls) {
-            const float pos = rintf(trow[i - a.num_cls] / 0.002f);
+            const float2* rp = a.rope + ((size_t)(seq / a.times_div) * a.times_stride + (i - a.num_cls)) * (HD / 2);
 #pragma unroll
-            for (int d = 0; d < HD / 2; ++d) {
-                const float f = pos * a.inv_freq[d];
-                const float cs = cosf(f), sn = sinf(f);
-                const float x0 = qp[2 * d], x1 = qp[2 * d + 1];
-                q[2 * d] = x0 * cs - x1 * sn;
-                q[2 * d + 1] = x0 * sn + x1 * cs;
+            for (int d = 0; d < HV; ++d) {
+                const f32x4 cs = *(const f32x4*)(rp + 2 * d);
+                q[d] = f32x4{q[d][0] * cs[0] - q[d][1] * cs[1], q[d][0] * cs[1] + q[d][1] * cs[0],
+                             q[d][2] * cs[2] - q[d][3] * cs[3], q[d][2] * cs[3] + q[d][3] * cs[2]};
             }
-        } else {
-#pragma unroll
-            for (int d = 0; d < HD; ++d) q[d] = qp[d];
         }
-        float o[HD];
+        f32x4 o[HV];
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = 0.f;
+        for (int d = 0; d < HV; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
         float mx = -INFINITY, den = 0.f;
-        const float mi = ms[i];
-        if (mi == 0.f) {
+        if (mg[i] == 0.f) {
             for (int j = 0; j < S; ++j) {
-                if (ms[j] != 0.f) continue;             // -inf column
+                if (mg[j] != 0.f) continue;             // -inf column
                 float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(q[d], ks[j * (HD + 1) + d], s);
+                for (int d = 0; d < HV; ++d) {
+                    const f32x4 kk = *(const f32x4*)(ks + j * HD + 4 * d);
+                    s = fmaf(q[d][0], kk[0], s); s = fmaf(q[d][1], kk[1], s); s = fmaf(q[d][2], kk[2], s); s = fmaf(q[d][3], kk[3], s);
+                }
                 s *= a.scale;
                 if (s > mx) {
                     const float corr = expf(mx - s);
                     den *= corr;
 #pragma unroll
-                    for (int d = 0; d < HD; ++d) o[d] *= corr;
+                    for (int d = 0; d < HV; ++d) o[d] *= corr;
                     mx = s;
                 }
                 const float p = expf(s - mx);
                 den += p;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) o[d] = fmaf(p, vs[j * (HD + 1) + d], o[d]);
+                for (int d = 0; d < HV; ++d) {
+                    const f32x4 vv = *(const f32x4*)(vs + j * HD + 4 * d);
+                    o[d][0] = fmaf(p, vv[0], o[d][0]); o[d][1] = fmaf(p, vv[1], o[d][1]);
+                    o[d][2] = fmaf(p, vv[2], o[d][2]); o[d][3] = fmaf(p, vv[3], o[d][3]);
+                }
             }
         }
-        float* op = a.out + (tok0 + i) * a.D + h * HD;
+        float* op = a.out + ((size_t)seq * S + i) * a.D + h * HD;
         const float inv = den > 0.f ? 1.f / den : 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
+        for (int d = 0; d < HV; ++d) *(f32x4*)(op + 4 * d) = o[d] * inv;
     }
 }
 
@@ -311,6 +369,7 @@ struct ttup_uplift {
     Mlp2 ball_embed, table_embed;
     Head position_head, rotation_head;
     float* cls_dev = nullptr; float* inv_freq_dev = nullptr; float* table_times_dev = nullptr;
+    float2 *rope = nullptr, *table_rope = nullptr;      // (cos, sin) tables: [chunk*max_len][hd/2] per forward, [n_table][hd/2] fixed
     std::vector<void*> allocs;
     // scratch (sized for `chunk` trajectories of max_len tokens)
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *x2 = nullptr, *tok = nullptr, *ttok = nullptr, *h1 = nullptr;
@@ -417,28 +476,64 @@ int run_linear(const Linear& L, const float* x, int ldx, long long M, const floa
     LinArgs a;
     a.x = x; a.ldx = ldx; a.w = L.w_dev; a.bias = L.b_dev; a.gamma = gamma; a.beta = beta; a.res = res; a.ldr = ldr;
     a.out = out; a.ldo = ldo; a.M = (int)M; a.N = L.n; a.K = L.k; a.relu = relu;
-    const size_t smem = (size_t)4 * 64 * (L.k / 4 + 4) * sizeof(float);
-    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((L.n + 127) / 128));
-    if (gamma) hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), smem, st, a);
+    TTUP_REQUIRE(ldx % 4 == 0 && L.k <= 256, TTUP_EINVAL, "linear: row stride %d / K %d unsupported", ldx, L.k);
+    // 128-row tiles once there are enough rows to fill the chip twice over, 64-row tiles below that
+    const bool big = M >= 128 * 512;
+    const int ntw = L.n > 128 ? 3 : L.n > 64 ? 2 : 1;
+    const int bm = big ? 128 : 64;
+    const size_t smem = (size_t)4 * bm * (L.k / 4 + 4) * sizeof(float);
+    const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((L.n + 64 * ntw - 1) / (64 * ntw)));
+#define TTUP_LIN(LN_, NTW_, MH_)                                                                                              \
+    do {                                                                                                                      \
+        static bool attr_done = false;                                                                                        \
+        if (!attr_done) {                                                                                                     \
+            TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)linear_kernel<LN_, NTW_, MH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_done = true;                                                                                                 \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((linear_kernel<LN_, NTW_, MH_>), grid, dim3(256 * MH_), smem, st, a);                              \
+    } while (0)
+#define TTUP_LIN_N(LN_, MH_)                                          \
+    do {                                                              \
+        if (ntw == 3) TTUP_LIN(LN_, 3, MH_);                          \
+        else if (ntw == 2) TTUP_LIN(LN_, 2, MH_);                     \
+        else TTUP_LIN(LN_, 1, MH_);                                   \
+    } while (0)
+    if (gamma) { if (big) TTUP_LIN_N(true, 2); else TTUP_LIN_N(true, 1); }
+    else { if (big) TTUP_LIN_N(false, 2); else TTUP_LIN_N(false, 1); }
+#undef TTUP_LIN_N
+#undef TTUP_LIN
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
 
+template <int HD>
+void launch_attention(const AttnArgs& a, hipStream_t st) {
+    const int S = a.S;
+    const int P = S <= 16 ? 16 : S <= 32 ? 32 : S <= 64 ? 64 : 128;
+    const int threads = P == 128 ? 128 : 64, G = threads / P;
+    const size_t smem = ((size_t)G * (2 * S * HD + 16) + (size_t)G * S) * sizeof(float);
+    const dim3 grid((unsigned)((a.n_seq + G - 1) / G), a.heads);
+    switch (P) {
+        case 16: hipLaunchKernelGGL((attention_kernel<HD, 16>), grid, dim3(threads), smem, st, a); break;
+        case 32: hipLaunchKernelGGL((attention_kernel<HD, 32>), grid, dim3(threads), smem, st, a); break;
+        case 64: hipLaunchKernelGGL((attention_kernel<HD, 64>), grid, dim3(threads), smem, st, a); break;
+        default: hipLaunchKernelGGL((attention_kernel<HD, 128>), grid, dim3(threads), smem, st, a); break;
+    }
+}
+
 int run_attention(ttup_uplift* net, const float* qkv, float* out, int n_seq, int S, int num_cls, const float* mask, int mask_div,
-                  const float* times, int times_div, int times_stride, hipStream_t st) {
+                  const float2* rope, int times_div, int times_stride, hipStream_t st) {
     AttnArgs a;
-    a.qkv = qkv; a.out = out; a.mask = mask; a.times = times; a.inv_freq = net->inv_freq_dev;
+    a.qkv = qkv; a.out = out; a.mask = mask; a.rope = rope;
     a.n_seq = n_seq; a.S = S; a.D = net->D; a.heads = net->heads; a.hd = net->hd; a.num_cls = num_cls;
     a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
     a.scale = 1.0f / sqrtf((float)net->hd);
-    const size_t smem = ((size_t)2 * S * (net->hd + 1) + S) * sizeof(float);
-    const dim3 grid(n_seq, net->heads);
+    TTUP_REQUIRE(((size_t)2 * S * net->hd + 16 + S) * sizeof(float) <= 64 * 1024, TTUP_EINVAL, "attention: sequence length %d too long", S);
     switch (net->hd) {
-        case 8: hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(64), smem, st, a); break;
-        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(64), smem, st, a); break;
-        case 24: hipLaunchKernelGGL(attention_kernel<24>, grid, dim3(64), smem, st, a); break;
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), smem, st, a); break;
+        case 8: launch_attention<8>(a, st); break;
+        case 16: launch_attention<16>(a, st); break;
+        case 24: launch_attention<24>(a, st); break;
+        case 32: launch_attention<32>(a, st); break;
         default: set_error("attention: head_dim %d unsupported", net->hd); return TTUP_EINVAL;
     }
     TTUP_LAUNCH_CHECK();
@@ -447,11 +542,11 @@ int run_attention(ttup_uplift* net, const float* qkv, float* out, int n_seq, int
 
 // SimpleStaticLayer.forward (model.py:278-300) on x [n_seq*S][D] in place (x2 is scratch of the same size)
 int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int n_seq, int S, int num_cls,
-              const float* mask, int mask_div, const float* times, int times_div, int times_stride, hipStream_t st) {
+              const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
     const int D = net->D;
     int rc;
     if ((rc = run_linear(L.qkv, x, D, tokens, L.g1, L.b1, 0, nullptr, 0, net->qkv, 3 * D, st))) return rc;
-    if ((rc = run_attention(net, net->qkv, net->att, n_seq, S, num_cls, mask, mask_div, times, times_div, times_stride, st))) return rc;
+    if ((rc = run_attention(net, net->qkv, net->att, n_seq, S, num_cls, mask, mask_div, rope, times_div, times_stride, st))) return rc;
     if ((rc = run_linear(L.proj, net->att, D, tokens, nullptr, nullptr, 0, x, D, net->x2, D, st))) return rc;       // x2 = proj(att) + x
     if ((rc = run_linear(L.fc1, net->x2, D, tokens, L.g2, L.b2, 1, nullptr, 0, net->hid, D, st))) return rc;          // hid = relu(fc1(LN(x2)))
     return run_linear(L.fc2, net->hid, D, tokens, nullptr, nullptr, 0, net->x2, D, x, D, st);                       // x = fc2(hid) + x2
@@ -474,6 +569,11 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
         hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, table, net->m1, net->m2, net->tmask, net->txy, B, T, NT, net->flags_dev);
         TTUP_LAUNCH_CHECK();
     }
+    {
+        const long long n = (long long)B * T * (net->hd / 2);
+        hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, times, net->inv_freq_dev, net->rope, net->hd / 2, n);
+        TTUP_LAUNCH_CHECK();
+    }
     // embeddings
     if ((rc = run_linear(net->ball_embed.fc1, ball, 2, (long long)B * T, nullptr, nullptr, 1, nullptr, 0, net->h1, D, st))) return rc;
     if ((rc = run_linear(net->ball_embed.fc2, net->h1, D, (long long)B * T, nullptr, nullptr, 0, nullptr, 0, net->tok, D, st))) return rc;
@@ -487,7 +587,7 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
         TTUP_LAUNCH_CHECK();
     }
     for (const Layer& L : net->pos_layers)
-        if ((rc = run_layer(net, L, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_times_dev, 1, 0, st))) return rc;
+        if ((rc = run_layer(net, L, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st))) return rc;
     {
         const long long total = (long long)B * T * D;
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->x, net->tok, D, S1, total);
@@ -495,7 +595,7 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
     }
     // temporal stage (tok is [B*T][D])
     for (const Layer& L : net->layers)
-        if ((rc = run_layer(net, L, net->tok, (long long)B * T, B, T, 0, net->m1, 1, times, 1, T, st))) return rc;
+        if ((rc = run_layer(net, L, net->tok, (long long)B * T, B, T, 0, net->m1, 1, net->rope, 1, T, st))) return rc;
     if ((rc = run_head(net, net->position_head, net->tok, D, (long long)B * T, pos, st))) return rc;
     // spin stage
     {
@@ -504,7 +604,7 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
         TTUP_LAUNCH_CHECK();
     }
     for (const Layer& L : net->second)
-        if ((rc = run_layer(net, L, net->x, (long long)B * (T + 1), B, T + 1, 1, net->m2, 1, times, 1, T, st))) return rc;
+        if ((rc = run_layer(net, L, net->x, (long long)B * (T + 1), B, T + 1, 1, net->m2, 1, net->rope, 1, T, st))) return rc;
     // rotation head on the cls rows (row stride (T+1)*D)
     return run_head(net, net->rotation_head, net->x, (T + 1) * D, B, rot, st);
 }
@@ -551,10 +651,16 @@ extern "C" int ttup_uplift_create(const void* blob, size_t blob_bytes, int max_b
         std::vector<float> tt(net->n_table);
         for (int n = 0; n < net->n_table; ++n) tt[n] = (float)n / 100.0f;       // arange(13) / (MAX_FPS/5), model.py:367
         if ((rc = dev_copy(net.get(), tt, &net->table_times_dev))) return rc;
+        float* tr = nullptr;
+        if ((rc = dev_alloc(net.get(), (size_t)net->n_table * net->hd, &tr))) return rc;
+        net->table_rope = (float2*)tr;
+        const long long n = (long long)net->n_table * (net->hd / 2);
+        hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, net->table_times_dev, net->inv_freq_dev, net->table_rope, net->hd / 2, n);
+        TTUP_LAUNCH_CHECK();
     }
-    // scratch: chunk of trajectories such that the table stage holds at most ~512k tokens
+    // scratch: chunk of trajectories such that the table stage holds at most ~2M tokens (7 GB of fp32 scratch at D=128)
     const long long per_traj = (long long)max_len * (net->n_table + 1);
-    long long chunk = (512 * 1024) / per_traj;
+    long long chunk = (2048 * 1024) / per_traj;
     if (chunk < 1) chunk = 1;
     if (chunk > max_batch) chunk = max_batch;
     net->chunk = (int)chunk;
@@ -573,6 +679,8 @@ extern "C" int ttup_uplift_create(const void* blob, size_t blob_bytes, int max_b
     if ((rc = dev_alloc(net.get(), (size_t)chunk * (net->n_table + 1), &net->tmask))) return rc;
     if ((rc = dev_alloc(net.get(), (size_t)chunk * net->n_table * 2, &net->txy))) return rc;
     float* fl = nullptr;
+    if ((rc = dev_alloc(net.get(), bt * net->hd, &fl))) return rc;
+    net->rope = (float2*)fl;
     if ((rc = dev_alloc(net.get(), 4, &fl))) return rc;
     net->flags_dev = (int*)fl;
     TTUP_HIP_CHECK(hipDeviceSynchronize());
