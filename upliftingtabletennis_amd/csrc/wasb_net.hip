@@ -62,17 +62,40 @@ struct ttup_wasb {
     long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
     int last_batch = 0;
     bool fused_head = false;      // last op computes the heatmap and the argmax partials itself (bf16 path)
+    // Lanes: independent micro-batches alternate between `lanes.size()` internal streams, each with its own activation
+    // and scratch buffers, so one micro-batch's kernel tails and launch gaps are filled by the other's kernels.
+    // `tensors[i].ptr` and the scratch pointers above always alias the lane in use (use_lane).
+    struct Lane {
+        std::vector<void*> ptr;
+        float* heat_scratch = nullptr; void* refine_ws = nullptr; long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t fork = nullptr;
 
+    void use_lane(int l) {
+        const Lane& L = lanes[l];
+        for (size_t i = 0; i < tensors.size(); ++i) tensors[i].ptr = L.ptr[i];
+        heat_scratch = L.heat_scratch; refine_ws = L.refine_ws; argmax_scratch = L.argmax_scratch; win_scratch = L.win_scratch;
+    }
     size_t esize() const { return dtype == TTUP_DTYPE_F32 ? 4 : 2; }
     ~ttup_wasb() {
         for (auto& c : convs) free_conv(&c);
-        for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
+        if (lanes.empty()) {       // construction failed before the lanes were set up
+            for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
+        }
+        for (auto& L : lanes) {
+            for (void* q : L.ptr) if (q) (void)hipFree(q);
+            if (L.heat_scratch) (void)hipFree(L.heat_scratch);
+            if (L.refine_ws) (void)hipFree(L.refine_ws);
+            if (L.argmax_scratch) (void)hipFree(L.argmax_scratch);
+            if (L.win_scratch) (void)hipFree(L.win_scratch);
+            if (L.stream) (void)hipStreamDestroy(L.stream);
+            if (L.done) (void)hipEventDestroy(L.done);
+        }
+        if (fork) (void)hipEventDestroy(fork);
         if (head_w_dev) (void)hipFree(head_w_dev);
         if (head_b_dev) (void)hipFree(head_b_dev);
-        if (heat_scratch) (void)hipFree(heat_scratch);
-        if (refine_ws) (void)hipFree(refine_ws);
-        if (argmax_scratch) (void)hipFree(argmax_scratch);
-        if (win_scratch) (void)hipFree(win_scratch);
     }
 };
 
@@ -367,46 +390,72 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
     return TTUP_OK;
 }
 
-int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
-                 int batch, float* heat_dev, int64_t* argmax_dev, float* win_dev, hipStream_t st) {
+int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int batch, int b0,
+                  float* heat_dev, int64_t* argmax_dev, float* win_dev, int lane, hipStream_t st) {
     const int H = net->H, W = net->W;
     const size_t hw = (size_t)H * W;
     const int K = net->n_out;
-    for (int b0 = 0; b0 < batch; b0 += net->micro) {
-        const int mb = batch - b0 < net->micro ? batch - b0 : net->micro;
-        int rc;
-        if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
-        else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, net->in_ch / 3, st);
+    const int mb = batch - b0 < net->micro ? batch - b0 : net->micro;
+    net->use_lane(lane);
+    int rc;
+    if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
+    else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, net->in_ch / 3, st);
+    if (rc) return rc;
+    rc = run_ops(net, mb, st);
+    if (rc) return rc;
+    float* heat = heat_dev ? heat_dev + (size_t)b0 * K * hw : net->heat_scratch;
+    if (net->fused_head) {
+        const Op& op = net->ops.back();
+        const void* terms[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
+        const bool peaks = argmax_dev || win_dev;
+        long long* am = peaks ? (argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch) : nullptr;
+        float* wn = peaks ? (win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch) : nullptr;
+        rc = launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, H, W,
+                               am, wn, net->refine_ws, net->refine_ws_bytes, st);
         if (rc) return rc;
-        rc = run_ops(net, mb, st);
+        return TTUP_OK;
+    }
+    rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st);
+    if (rc) return rc;
+    if (argmax_dev || win_dev) {
+        long long* am = argmax_dev ? (long long*)argmax_dev + (size_t)b0 * K : net->argmax_scratch;
+        float* wn = win_dev ? win_dev + (size_t)b0 * K * 9 : net->win_scratch;
+        rc = refine_argmax(heat, mb * K, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
         if (rc) return rc;
-        float* heat = heat_dev ? heat_dev + (size_t)b0 * K * hw : net->heat_scratch;
-        if (net->fused_head) {
-            const Op& op = net->ops.back();
-            const void* terms[3] = {nullptr, nullptr, nullptr};
-            for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
-            const bool peaks = argmax_dev || win_dev;
-            long long* am = peaks ? (argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch) : nullptr;
-            float* wn = peaks ? (win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch) : nullptr;
-            rc = launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, H, W,
-                                   am, wn, net->refine_ws, net->refine_ws_bytes, st);
-            if (rc) return rc;
-            continue;
-        }
-        rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st);
-        if (rc) return rc;
-        if (argmax_dev || win_dev) {
-            long long* am = argmax_dev ? (long long*)argmax_dev + (size_t)b0 * K : net->argmax_scratch;
-            float* wn = win_dev ? win_dev + (size_t)b0 * K * 9 : net->win_scratch;
-            rc = refine_argmax(heat, mb * K, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
-            if (rc) return rc;
+    }
+    return TTUP_OK;
+}
+
+int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w,
+                 int batch, float* heat_dev, int64_t* argmax_dev, float* win_dev, hipStream_t st) {
+    const int n_micro = (batch + net->micro - 1) / net->micro;
+    const int n_lanes = n_micro < (int)net->lanes.size() ? (n_micro > 0 ? n_micro : 1) : (int)net->lanes.size();
+    const hipStream_t caller = st;
+    if (n_lanes > 1) {
+        TTUP_HIP_CHECK(hipEventRecord(net->fork, caller));
+        for (int l = 0; l < n_lanes; ++l) TTUP_HIP_CHECK(hipStreamWaitEvent(net->lanes[l].stream, net->fork, 0));
+    }
+    int rc_all = TTUP_OK, last_lane = 0;
+    for (int b0 = 0, i = 0; b0 < batch && rc_all == TTUP_OK; b0 += net->micro, ++i) {
+        rc_all = forward_micro(net, x_dev, frames_dev, n_frames, src_h, src_w, batch, b0, heat_dev, argmax_dev, win_dev,
+                               n_lanes > 1 ? i % n_lanes : 0, n_lanes > 1 ? net->lanes[i % n_lanes].stream : caller);
+        last_lane = n_lanes > 1 ? i % n_lanes : 0;
+    }
+    if (n_lanes > 1) {       // join even after an error so the caller's stream never runs ahead of enqueued work
+        for (int l = 0; l < n_lanes; ++l) {
+            (void)hipEventRecord(net->lanes[l].done, net->lanes[l].stream);
+            (void)hipStreamWaitEvent(caller, net->lanes[l].done, 0);
         }
     }
+    net->use_lane(last_lane);
+    if (rc_all) return rc_all;
     net->last_batch = batch < net->micro ? batch : net->micro;
     return TTUP_OK;
 }
 
 }  // namespace
+
 
 extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, ttup_wasb** out) {
     TTUP_REQUIRE(blob && out, TTUP_EINVAL, "ttup_wasb_create: null pointer");
@@ -444,12 +493,36 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
         net->head_bias = head_b[first];
     }
     const size_t hw = (size_t)height * width;
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->heat_scratch, (size_t)net->micro * net->n_out * hw * sizeof(float)));
     net->refine_ws_bytes = ttup_refine_workspace_bytes(net->micro * net->n_out, height, width);
     if (upsum_head_ws_bytes(net->micro, height, width) > net->refine_ws_bytes) net->refine_ws_bytes = upsum_head_ws_bytes(net->micro, height, width);
-    TTUP_HIP_CHECK(hipMalloc(&net->refine_ws, net->refine_ws_bytes));
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->argmax_scratch, (size_t)net->micro * net->n_out * sizeof(long long)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&net->win_scratch, (size_t)net->micro * net->n_out * 9 * sizeof(float)));
+    {
+        const char* le = getenv("TTUP_LANES");
+        int n_lanes = le ? atoi(le) : 2;
+        const int n_micro = (max_batch + net->micro - 1) / net->micro;
+        if (n_lanes > n_micro) n_lanes = n_micro;
+        if (n_lanes < 1) n_lanes = 1;
+        if (n_lanes > 4) n_lanes = 4;
+        net->lanes.resize(n_lanes);
+        for (int l = 0; l < n_lanes; ++l) {
+            ttup_wasb::Lane& L = net->lanes[l];
+            L.ptr.assign(net->tensors.size(), nullptr);
+            for (size_t i = 0; i < net->tensors.size(); ++i) {
+                const Tensor& t = net->tensors[i];
+                if (l == 0) { L.ptr[i] = t.ptr; continue; }      // lane 0 adopts the buffers the builder allocated
+                TTUP_HIP_CHECK(hipMalloc(&L.ptr[i], (size_t)net->micro * t.h * t.w * t.c * net->esize()));
+            }
+            TTUP_HIP_CHECK(hipMalloc((void**)&L.heat_scratch, (size_t)net->micro * net->n_out * hw * sizeof(float)));
+            TTUP_HIP_CHECK(hipMalloc(&L.refine_ws, net->refine_ws_bytes));
+            TTUP_HIP_CHECK(hipMalloc((void**)&L.argmax_scratch, (size_t)net->micro * net->n_out * sizeof(long long)));
+            TTUP_HIP_CHECK(hipMalloc((void**)&L.win_scratch, (size_t)net->micro * net->n_out * 9 * sizeof(float)));
+            if (n_lanes > 1) {
+                TTUP_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+                TTUP_HIP_CHECK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            }
+        }
+        if (n_lanes > 1) TTUP_HIP_CHECK(hipEventCreateWithFlags(&net->fork, hipEventDisableTiming));
+        net->use_lane(0);
+    }
     TTUP_HIP_CHECK(hipDeviceSynchronize());
     *out = net.release();
     return TTUP_OK;
