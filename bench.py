@@ -69,6 +69,9 @@ class Pipeline:
         return self.worker.process_clip(self.frames, self.table_px, self.fps)
 
 
+TRAFFIC_FILE = 'r1d_traffic.json'
+
+
 def roofline(pipe):
     """Per-op HIP-event timing of the CNN inside the library; dominant op -> roofline object."""
     from upliftingtabletennis_amd import wasb
@@ -88,12 +91,13 @@ def roofline(pipe):
     # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
     # runs, gfx950 correction; tools/pmc_traffic.py).  Only attached when kernel and launch geometry match.
     try:
-        key = 'stem_kernel' if dom['kind'] == 'stem' else 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else ('bb_chain_kernel' if dom['kind'] == 'bb_chain' else 'conv_mfma_kernel')
-        tiles = ((dom['h'] + 7) // 8) * ((dom['w'] + 31) // 32) * dom['batch']
-        for e in json.load(open(os.path.join(ROOT, 'profiles', 'r1b_traffic.json'))):
-            if key in e['kernel'] and dom['kind'] == 'bneck_trans' and e['grid'] == tiles * 512:
+        key = 'stem_kernel' if dom['kind'] == 'stem' else 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else None
+        # the persistent fused kernels launch one grid per micro-batch; the PMC passes (tools/prof_cnn.py) ran the same
+        # micro-batch of 8 triples at 1280x704, so the entry is matched by kernel name and micro-batch
+        for e in json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE))):
+            if key and key in e['kernel'] and dom['batch'] == 8 and (dom['h'], dom['w']) == (H_NET, W_NET):
                 r['traffic'] = e['hbm_bytes']
-                r['traffic_note'] = 'bytes per launch from profiles/r1b_traffic.json (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)'
+                r['traffic_note'] = 'bytes per launch from profiles/%s (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)' % TRAFFIC_FILE
                 break
     except Exception:
         pass
