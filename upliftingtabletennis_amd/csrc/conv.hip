@@ -922,7 +922,7 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
 template <int C, int TH, int TW>
 static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2;
-    static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
         TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bb_chain2_kernel<C, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -969,9 +969,29 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         TTUP_REQUIRE(p.cout == c && p.cin_total == c && p.k == 3 && p.stride == 1 && p.ck == (c == 16 ? 16 : 32), TTUP_EINVAL, "bb_chain: unexpected conv shape");
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
-    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 16, 32>(a, batch, h, w, st);
+    if (c == 16 && n_convs == 4) {
+        static const int tile = getenv("TTUP_BB16_TILE") ? atoi(getenv("TTUP_BB16_TILE")) : 3;
+        if (tile == 1) return launch_bb2_t<16, 24, 26>(a, batch, h, w, st);
+        if (tile == 2) return launch_bb2_t<16, 16, 26>(a, batch, h, w, st);
+        if (tile == 3) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
+        if (tile == 4) return launch_bb2_t<16, 26, 26>(a, batch, h, w, st);
+        if (tile == 5) return launch_bb2_t<16, 32, 32>(a, batch, h, w, st);
+        if (tile == 6) return launch_bb2_t<16, 24, 48>(a, batch, h, w, st);
+        if (tile == 7) return launch_bb2_t<16, 24, 42>(a, batch, h, w, st);
+        return launch_bb2_t<16, 16, 32>(a, batch, h, w, st);
+    }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
-    if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 8, 32>(a, batch, h, w, st);
+    if (c == 32 && n_convs == 2) {
+        static const int tile = getenv("TTUP_BB32_TILE") ? atoi(getenv("TTUP_BB32_TILE")) : 4;
+        if (tile == 1) return launch_bb_t<32, 1, 14, 30>(a, batch, h, w, st);
+        if (tile == 2) return launch_bb_t<32, 1, 16, 32>(a, batch, h, w, st);
+        if (tile == 3) return launch_bb_t<32, 1, 14, 32>(a, batch, h, w, st);
+        if (tile == 4) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);
+        if (tile == 5) return launch_bb_t<32, 1, 30, 30>(a, batch, h, w, st);
+        if (tile == 6) return launch_bb_t<32, 1, 30, 14>(a, batch, h, w, st);
+        if (tile == 7) return launch_bb_t<32, 1, 22, 38>(a, batch, h, w, st);
+        return launch_bb_t<32, 1, 8, 32>(a, batch, h, w, st);
+    }
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
     return TTUP_EINVAL;
 }
