@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 // Persistent workgroups (8 waves) keep ALL weights of the stem in LDS (conv1 20 KB + conv2 73.7 KB) and walk 8x32 tiles:
 //   X0 halo tile (12x36 px, 16 ch, register-prefetched one tile ahead) -> conv1 3x3 9(16)->64 +ReLU on the 10x34 halo
 //   region, kept in LDS as bf16 (never written to HBM) -> conv2 3x3 64->64 +ReLU straight from LDS (18 k-steps without a
-//   barrier) -> T2 tile to HBM and through LDS into the 1x1 64->32 follower (Bottleneck conv1) -> A1 tile to HBM.
+//   barrier) -> T2 tile to HBM and, still in registers, into the 1x1 64->32 follower (Bottleneck conv1) -> A1 tile to HBM.
 // Reference: wasb.py:446-451 (stem), :88-90 (Bottleneck conv1).  Intermediates are rounded to bf16 where the layer-wise
 // path stores them, so results are bit-identical.
 struct StemArgs {
@@ -307,17 +307,20 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* s_w1 = (bf16_t*)smem;                     // 20,480 B
     bf16_t* s_w2 = s_w1 + W1_U * 8;                   // 73,728 B
-    bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2 chunks][340 px][32 ch]  43,520 B   (also the T2 tile of the follower)
+    bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2 chunks][340 px][32 ch]  43,520 B
     bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 ch]            13,824 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
     for (int u = tid; u < W2_U; u += 512) ((u32x4*)s_w2)[u] = ((const u32x4*)a.w2)[u];
+    // Follower weights with the K order permuted to the conv2 accumulator layout: a lane owns channels g*16 .. g*16+15 of
+    // its pixel, so k-step k takes channels 16g + 8k + j from lane group g -- the bf16 pairs it has just packed -- and the
+    // T2 tile never goes through LDS.  In the standard packing those channels sit at k-step g>>1, lane group 2(g&1)+k.
     bf16x8 af3[2][2];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + ((k * 2 + m) * 64 + lane) * 8);
+        for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + (((g >> 1) * 2 + m) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
     // biases seed the accumulators (lane's channels g*16.. for the 64-channel convs, g*8.. for the follower)
     f32x4 b1[4], b2[4], b3[2];
 #pragma unroll
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             const int y = pc / TW1, x = pc % TW1;
             const bf16_t* xb = s_x + (y * XW + x) * 16;
             f32x4 acc[4] = {b1[0], b1[1], b1[2], b1[3]};
+#ifndef TTUP_ABLATE_S1
 #pragma unroll
             for (int s5 = 0; s5 < 5; ++s5) {
                 const bf16x8 bfr = *(const bf16x8*)(xb + koff1[s5]);
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
                 }
             }
+#endif
             if (p < NP1) {
                 const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
                 const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
+#ifndef TTUP_ABLATE_S2
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -413,42 +419,35 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                     for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
                 }
             }
-        __syncthreads();                      // every wave is done reading the T1 tile: it becomes the T2 tile
+#endif
+        // ---------------- T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
             const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
-            const int p = r * 32 + cg * 16 + n;
             const bool ok = oy < a.H && ox < a.W;
+            u32x4 pk[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                u32x4 pk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
-                if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk;
-                *(u32x4*)(s_t1 + p * 64 + (((2 * g + q) ^ (p & 7)) << 3)) = pk;
+                for (int i = 0; i < 4; ++i) pk[q][i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
+#ifndef TTUP_ABLATE_SG
+                if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk[q];
+#endif
             }
-        }
-        __syncthreads();
-        // ---------------- follower: A1 = relu(W3 . T2 + b3), 64 -> 32
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
-            const int p = r * 32 + cg * 16 + n;
+#ifndef TTUP_ABLATE_S3
             f32x4 c3[2] = {b3[0], b3[1]};
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const bf16x8 bfr = *(const bf16x8*)(s_t1 + p * 64 + (((4 * k + g) ^ (p & 7)) << 3));
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], bfr, c3[m], 0, 0, 0);
-            }
-            const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
-            if (oy < a.H && ox < a.W) {
-                u32x4 pk;
+                for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], __builtin_bit_cast(bf16x8, pk[k]), c3[m], 0, 0, 0);
+            if (ok) {
+                u32x4 po;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
-                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = pk;
+                for (int i = 0; i < 4; ++i) po[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
+                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = po;
             }
+#endif
         }
     }
 }
