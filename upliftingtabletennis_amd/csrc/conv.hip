@@ -556,6 +556,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             f32x4 acc[8];          // seeded with the bias of the lane's channels g*32 + 4m ..
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[m] = *(const f32x4*)(s_b1 + g * 32 + m * 4);
+#ifndef TTUP_ABLATE_P1
 #pragma unroll
             for (int chunk = 0; chunk < 3; ++chunk) {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
                 }
             }
+#endif
             if (pix < NPIX) {
                 const bool inside = p_in[t];
 #pragma unroll
