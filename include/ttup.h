@@ -142,6 +142,25 @@ int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* ta
  * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */
 int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream);
 
+/* ---------------------------------------------------------------- f2: synthetic-trajectory generator (BASELINE config 5)
+ * Replaces the per-seed work of find_valid_trajectories_worker (syntheticdataset/mujocosimulation.py:112-219):
+ *   ttup_trajgen_simulate  = _init_simulation (:54-109, CPython random.Random(seed) reproduced bit for bit) + the
+ *                            mj_step sampling loop with its out-of-bounds / out-of-image stops (:112-151);
+ *   ttup_trajgen_select    = _count_hits (helper.py:282-321) + every rejection and cut rule (:152-219).
+ * mode: 0 final_lose, 1 final_win, 2 intermediate, 3 first_good, 4 first_short, 5 first_long (OOB_DEFINITIONS order);
+ * direction: 0 left_to_right, 1 right_to_left.  substeps = RK4 steps per 1 ms MuJoCo timestep.
+ * cam_host: 25 doubles on the HOST, Mext (4x4 row major) then Mint (3x3), as _calc_cammatrices builds them.
+ * samples_dev: [n_labels][9][n_seeds] doubles (x y z vx vy vz wx wy wz; n_labels = ttup_trajgen_max_samples());
+ * n_saved_dev: valid samples per seed.  init_dev (optional): [9][n_seeds] initial states.
+ * n_keep_dev: 0 = rejected, else the number of samples the reference keeps; bounces_dev [n_seeds][4], n_bounces_dev.
+ * The fluid / contact arithmetic restates MuJoCo's documented model (MuJoCo itself is not available): parity unpinned. */
+int    ttup_trajgen_max_samples(void);
+size_t ttup_trajgen_workspace_bytes(int n_seeds);
+int ttup_trajgen_simulate(const int64_t* seeds_dev, int n_seeds, int mode, int direction, int substeps, const double* cam_host,
+                          double* samples_dev, int* n_saved_dev, double* init_dev, void* workspace, size_t workspace_bytes, void* stream);
+int ttup_trajgen_select(const double* samples_dev, const int* n_saved_dev, int n_seeds, int mode, int direction,
+                        int* n_keep_dev, double* bounces_dev, int* n_bounces_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

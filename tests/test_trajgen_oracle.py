@@ -1,0 +1,115 @@
+"""f2 (synthetic-trajectory generator): the oracle against the reference-generated goldens (CPU only).
+Sampling, camera, hit counting and selection are pinned by the reference's own code (tools/make_goldens.py trajgen);
+the physics is parity-unpinned (MuJoCo absent) and is checked for self-consistency only."""
+import numpy as np
+import pytest
+
+from oracle import trajgen_ref as T
+
+
+def test_init_state_matches_reference_sampler(golden):
+    g = golden('trajgen.npz')
+    seeds = g['init_seeds']
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS:
+            ref = g['init/%s/%s' % (mode, direction)]
+            got = np.stack([np.concatenate(T.init_state(int(s), mode, direction)) for s in seeds])
+            assert np.array_equal(got, ref), (mode, direction)
+
+
+def test_camera_matrices_match_reference(golden):
+    g = golden('trajgen.npz')
+    ex, mint = T.camera_matrices()
+    assert np.array_equal(ex, g['Mext']) and np.array_equal(mint, g['Mint'])
+
+
+def test_count_hits_matches_reference(golden):
+    g = golden('trajgen.npz')
+    n = int(g['hits/n'][0])
+    nonempty = 0
+    for j in range(n):
+        direction = T.DIRECTIONS[int(g['hits/%d/direction' % j][0])]
+        ho, hw, hg = T.count_hits(g['hits/%d/track' % j], direction)
+        assert np.array_equal(np.array(ho), g['hits/%d/opponent' % j])
+        assert np.array_equal(np.array(hw), g['hits/%d/own' % j])
+        assert np.array_equal(np.array(hg), g['hits/%d/ground' % j])
+        nonempty += bool(len(ho) + len(hw) + len(hg))
+    assert nonempty >= n // 3
+
+
+@pytest.mark.parametrize('mode', ['final_lose', 'intermediate'])
+def test_sampling_loop_and_selection_match_reference_worker(golden, mode):
+    """Oracle physics -> oracle sampling loop -> oracle selection == reference worker on the same physics."""
+    g = golden('trajgen.npz')
+    n_sel = min(int(g['n_sel'][0]), 24)          # bounded: the numpy integrator needs ~0.1 s per seed
+    times = T.save_times()
+    for direction in T.DIRECTIONS:
+        key = 'worker/%s/%s' % (mode, direction)
+        seeds = list(range(n_sel))
+        pos, vel, rot, ns = T.simulate(seeds, mode, direction)
+        got_seeds, got_n, got_b = [], [], []
+        for i, s in enumerate(seeds):
+            res = T.select(pos[i, :ns[i]], times, mode, direction)
+            if res is not None:
+                got_seeds.append(s); got_n.append(res[0]); got_b.append(res[1])
+        keep = g[key + '/seeds'] < n_sel
+        assert np.array_equal(np.array(got_seeds), g[key + '/seeds'][keep]), (mode, direction)
+        assert np.array_equal(np.array(got_n), g[key + '/n'][keep])
+        nb = g[key + '/n_bounces'][keep]
+        assert np.array_equal(np.concatenate(got_b) if got_b else np.zeros(0), g[key + '/bounces'][:int(nb.sum())])
+        if len(got_seeds) and got_seeds[0] == int(g[key + '/seeds'][0]):
+            i = seeds.index(got_seeds[0])
+            assert np.array_equal(pos[i, :got_n[0]], g[key + '/first_positions'])
+            assert np.array_equal(vel[i, :got_n[0]], g[key + '/first_velocities'])
+            assert np.array_equal(rot[i, :got_n[0]], g[key + '/first_rotations'])
+            assert np.array_equal(times[:got_n[0]], g[key + '/first_times'])
+
+
+def test_selection_on_all_modes_from_stored_tracks(golden):
+    """Every mode's selection branch on the stored accepted trajectory: re-selecting an accepted (already cut) track of a
+    mode that cuts at a bounce must not accept it with the same length unless no cut applies."""
+    g = golden('trajgen.npz')
+    times = T.save_times()
+    seen = 0
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS:
+            key = 'worker/%s/%s' % (mode, direction)
+            if key + '/first_positions' not in g:
+                continue
+            p = g[key + '/first_positions']
+            ho, hw, hg = T.count_hits(p, direction)
+            want = T.VALID_COUNTS[mode]
+            assert (len(ho), len(hw)) == want[:2] and len(ho) + len(hw) == int(g[key + '/n_bounces'][0])
+            seen += 1
+    assert seen >= 3
+
+
+def test_free_flight_rk4_is_fourth_order():
+    """Self-consistency of the unpinned physics: halving the step divides the free-flight error by ~16."""
+    r0 = np.array([[1.5, 0.3, 1.2]]); v0 = np.array([[-8.0, 1.0, 2.0]]); w0 = np.array([[100.0, -250.0, 60.0]])
+
+    def run(sub):
+        r, v, w = r0.copy(), v0.copy(), w0.copy()
+        for _ in range(60):
+            r, v, w = T.step_ms(r, v, w, 1, substeps=sub)
+        return np.concatenate([r, v], axis=1)
+    ref = run(16)
+    e1, e2 = np.abs(run(1) - ref).max(), np.abs(run(2) - ref).max()
+    assert e1 < 1e-6 and 10.0 < e1 / e2 < 20.0, (e1, e2)
+
+
+def test_bounce_is_dissipative_and_spin_couples_through_friction():
+    r = np.array([[0.5, 0.0, T.TABLE_HEIGHT + T.R_BALL + 0.3]]); v = np.zeros((1, 3)); w = np.array([[0.0, 200.0, 0.0]])
+    vz_in, vz_out, vx_out = 0.0, 0.0, 0.0
+    for _ in range(400):
+        r, v, w = T.step_ms(r, v, w, 1)
+        vz_in = min(vz_in, v[0, 2]); vz_out = max(vz_out, v[0, 2])
+    vx_out = v[0, 0]
+    assert 0.5 < vz_out / -vz_in < 1.0          # restitution below one
+    assert abs(vx_out) > 0.05 and w[0, 1] < 200.0       # topspin about +y kicks the ball along x and loses spin
+    assert r[0, 2] > T.TABLE_HEIGHT              # never tunnels through the table
+
+
+def test_seed_order_is_the_pool_round_robin():
+    assert T.seed_order(0, 8, 3) == [0, 3, 6, 1, 4, 7, 2, 5]
+    assert T.seed_order(1024, 4, 128)[:4] == [1024, 1025, 1026, 1027]

@@ -321,10 +321,138 @@ def gen_fullsize():
           % (dt, b, torch.get_num_threads(), [(int(i % w), int(i // w)) for i in idx], track[1:1 + b].tolist(), flat[:, -2:].tolist()))
 
 
+def install_mujoco_standin(history):
+    """`mujoco` is not importable here.  The reference's generator only needs containers (MjModel/MjData), the
+    fixed camera pose and `mj_step`.  This stand-in provides the containers and REPLAYS states that oracle/trajgen_ref.py
+    integrated beforehand (keyed by the initial state the reference itself drew), so that the reference's own sampling
+    loop, bounds checks, hit counting and selection run unchanged on top of the oracle's physics.  It pins the
+    reference's control flow, NOT MuJoCo's arithmetic (parity of the physics stays unpinned)."""
+    from oracle import trajgen_ref as T
+    mj = types.ModuleType('mujoco')
+    x = T.CAMERA_RIGHT / np.linalg.norm(T.CAMERA_RIGHT)
+    y = T.CAMERA_UP - x * np.dot(x, T.CAMERA_UP)
+    y = y / np.linalg.norm(y)
+    z = np.cross(x, y)
+
+    class Model(object):
+        cam_intrinsic = np.array([[T.FX / T.WIDTH, T.FY / T.HEIGHT, 0.0, 0.0]])
+        cam_sensorsize = np.array([[1.0, 1.0]])
+        cam_resolution = np.array([[T.WIDTH, T.HEIGHT]])
+
+    class MjModel(object):
+        @staticmethod
+        def from_xml_string(xml):
+            return Model()
+
+    class MjData(object):
+        def __init__(self, model):
+            self.model = model
+            self.qpos = np.zeros(7); self.qpos[3] = 1.0
+            self.qvel = np.zeros(6)
+            self.time = 0.0
+            self.cam_xmat = np.stack([x, y, z], axis=1).reshape(1, 9)
+            self.cam_xpos = T.CAMERA_POS[None].copy()
+            self._row, self._step = None, 0
+
+    def mj_step(model, data, nstep=1):
+        if data._row is None:
+            data._row = history[(data.qpos[:3].tobytes(), data.qvel.tobytes())]
+        for _ in range(nstep):
+            data._step += 1
+            data.time += T.TIMESTEP
+        st = data._row[data._step]
+        data.qpos[:3] = st[0:3]; data.qvel[:3] = st[3:6]; data.qvel[3:6] = st[6:9]
+
+    class mjtObj(object):
+        mjOBJ_CAMERA = 7
+    mj.MjModel, mj.MjData, mj.mj_step, mj.mjtObj = MjModel, MjData, mj_step, mjtObj
+    mj.mj_name2id = lambda model, objtype, name: 0
+    sys.modules['mujoco'] = mj
+    sys.modules['mujoco_viewer'] = types.ModuleType('mujoco_viewer')
+    if 'tqdm' not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except Exception:
+            sys.modules['tqdm'] = types.ModuleType('tqdm')
+
+
+def gen_trajgen():
+    """f2: the reference's `_init_simulation`, `_count_hits` and `find_valid_trajectories_worker`, the latter two driven by the
+    oracle integrator through the stand-in above."""
+    from oracle import trajgen_ref as T
+    history = {}
+    install_mujoco_standin(history)
+    import syntheticdataset.mujocosimulation as ms
+    import syntheticdataset.helper as mh
+    out = {}
+    n_init, n_sel = 48, 160
+    # ---- initial states: straight from the reference's sampler (the stand-in only holds the arrays)
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS:
+            st = []
+            for seed in list(range(n_init)) + [12345, 2 ** 31 + 7, 2 ** 40 + 3]:
+                _, data = ms._init_simulation(seed, mode, direction)
+                st.append(np.concatenate([data.qpos[:3], data.qvel[:6]]))
+            out['init/%s/%s' % (mode, direction)] = np.stack(st)
+    out['init_seeds'] = np.array(list(range(n_init)) + [12345, 2 ** 31 + 7, 2 ** 40 + 3], dtype=np.int64)
+    # ---- camera matrices as `_calc_cammatrices` builds them from the (stand-in) camera pose
+    _, data = ms._init_simulation(0, 'intermediate', 'left_to_right')
+    ex, inm = mh._calc_cammatrices(data, camera_name=mh.CAMERA_NAME)
+    out['Mext'], out['Mint'] = ex, inm[:3, :3]
+    # ---- worker: integrate every seed for the full second with the oracle, then let the reference select
+    t0 = time.time()
+    hit_cases = []
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS:
+            seeds = list(range(n_sel))
+            st = [T.init_state(s, mode, direction) for s in seeds]
+            r = np.stack([a[0] for a in st]); v = np.stack([a[1] for a in st]); w = np.stack([a[2] for a in st])
+            hist = np.zeros((len(seeds), 1001, 9))
+            hist[:, 0] = np.concatenate([r, v, w], axis=1)
+            for k in range(1, 1001):
+                r, v, w = T.step_ms(r, v, w, 1)
+                hist[:, k] = np.concatenate([r, v, w], axis=1)
+            for i in range(len(seeds)):
+                history[(hist[i, 0, :3].tobytes(), hist[i, 0, 3:9].tobytes())] = hist[i]
+            res = ms.find_valid_trajectories_worker((seeds, mode, direction))
+            key = 'worker/%s/%s' % (mode, direction)
+            out[key + '/seeds'] = np.array([t['seed'] for t in res], dtype=np.int64)
+            out[key + '/n'] = np.array([len(t['positions']) for t in res], dtype=np.int64)
+            out[key + '/bounces'] = np.concatenate([t['bounces'] for t in res]) if res else np.zeros(0)
+            out[key + '/n_bounces'] = np.array([len(t['bounces']) for t in res], dtype=np.int64)
+            if res:
+                out[key + '/first_positions'] = res[0]['positions']
+                out[key + '/first_velocities'] = res[0]['velocities']
+                out[key + '/first_rotations'] = res[0]['rotations']
+                out[key + '/first_times'] = res[0]['times']
+                assert np.array_equal(res[0]['Mext'][0], ex) and np.array_equal(res[0]['Mint'][0], inm[:3, :3])
+            # hit counting on raw (unselected) tracks: the sampled states at 1, 2, 4, ... ms
+            picked = 0
+            for i in range(len(seeds)):
+                track = np.concatenate([hist[i, 1:2, :3], hist[i, 2:1000:2, :3]])
+                ho, hw, hg = mh._count_hits(list(track), direction)
+                if (len(ho) + len(hw) + len(hg) > 0 and picked < 3) or i == 0:
+                    keep = track[:360].astype(np.float32).astype(np.float64)       # float32-representable: half the file size
+                    ho, hw, hg = mh._count_hits(list(keep), direction)
+                    hit_cases.append((direction, keep, ho, hw, hg))
+                    picked += i != 0
+            print('trajgen %s/%s: %d of %d seeds accepted (%.0f s)' % (mode, direction, len(res), len(seeds), time.time() - t0))
+    out['hits/n'] = np.array([len(hit_cases)])
+    for j, (direction, track, ho, hw, hg) in enumerate(hit_cases):
+        out['hits/%d/direction' % j] = np.array([T.DIRECTIONS.index(direction)])
+        out['hits/%d/track' % j] = track.astype(np.float64)
+        out['hits/%d/opponent' % j] = np.array(ho, dtype=np.float64)
+        out['hits/%d/own' % j] = np.array(hw, dtype=np.float64)
+        out['hits/%d/ground' % j] = np.array(hg, dtype=np.float64)
+    out['n_sel'] = np.array([n_sel])
+    np.savez_compressed(os.path.join(OUT, 'trajgen.npz'), **out)
+    print('trajgen.npz: %d arrays, %.0f KB' % (len(out), os.path.getsize(os.path.join(OUT, 'trajgen.npz')) / 1024))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table']
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen}[w_]()

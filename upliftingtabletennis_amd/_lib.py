@@ -35,6 +35,10 @@ SIGNATURES = {
     'ttup_uplift_destroy': (None, [_vp]),
     'ttup_uplift_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'ttup_transform_rotationaxes': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'ttup_trajgen_max_samples': (_i, []),
+    'ttup_trajgen_workspace_bytes': (_sz, [_i]),
+    'ttup_trajgen_simulate': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ttup_trajgen_select': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None
