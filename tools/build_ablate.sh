@@ -1,11 +1,11 @@
 #!/bin/bash
-# Build variants of libttup.so with one -DTTUP_ABLATE_* flag each (conv.hip only) for phase-by-phase timing.
-#   tools/build_ablate.sh S1 S2 S3 SG  ->  upliftingtabletennis_amd/_ablate/libttup_S1.so ...   (select with TTUP_LIB)
+# Build variants of libttup.so with one -DTTUP_<flag> each, e.g. ABLATE_S1 or BB_UNROLL (conv.hip only) for phase-by-phase timing.
+#   tools/build_ablate.sh ABLATE_S1 ABLATE_S2  ->  upliftingtabletennis_amd/_ablate/libttup_ABLATE_S1.so ...   (select with TTUP_LIB)
 set -e
 cd "$(dirname "$0")/../upliftingtabletennis_amd"
 mkdir -p _ablate
 for f in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -DTTUP_ABLATE_$f -c csrc/conv.hip -o _ablate/conv_$f.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -DTTUP_$f -c csrc/conv.hip -o _ablate/conv_$f.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _ablate/libttup_$f.so csrc/api.o _ablate/conv_$f.o csrc/refine.o csrc/wasb_net.o csrc/uplift.o csrc/trajgen.o
   rm _ablate/conv_$f.o
 done
