@@ -68,6 +68,12 @@ class Pipeline:
     def step(self):
         return self.worker.process_clip(self.frames, self.table_px, self.fps)
 
+    def submit(self):
+        return self.worker.submit(self.frames)
+
+    def collect(self, ticket):
+        return self.worker.collect(ticket, self.table_px, self.fps)
+
 
 TRAFFIC_FILE = 'r1d_traffic.json'
 
@@ -175,10 +181,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     from upliftingtabletennis_amd import pipeline
+    # K steps, software-pipelined one deep: the detector of step k+1 is enqueued before the host filters / pads the
+    # detections of step k and enqueues their uplift, so the GPU does not idle during the host glue.  Every step's
+    # detect + refine + uplift + gather completes inside the timed region (the last collect is before the barrier).
+    ticket = None
     for _ in range(a.steps):
-        rec = pipe.step()
-        # final gather of the small per-frame / per-trajectory records (the only collective on the path)
-        gathered = pipeline.gather_records(rec, dist)
+        nxt = pipe.submit()
+        if ticket is not None:
+            rec = pipe.collect(ticket)
+            # final gather of the small per-frame / per-trajectory records (the only collective on the path)
+            gathered = pipeline.gather_records(rec, dist)
+        ticket = nxt
+    rec = pipe.collect(ticket)
+    gathered = pipeline.gather_records(rec, dist)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -340,3 +340,31 @@ def test_table_detector_and_full_pipeline_surface():
     assert tuple(spin.shape) == (3,) and p3.shape == (6, 3) and np.isfinite(p3).all()
     spin2, p32 = pipe.predict(list(frames), 60.0, table_keypoints=filt)
     assert p32.shape == (6, 3)
+
+
+# ------------------------------------------------------------------------------------------ e: per-GPU worker
+def test_stream_worker_pipelined_steps_equal_the_blocking_step():
+    """bench.py's worker: `submit` + `collect` (detector of the next clip enqueued before the host glue of this one) returns
+    exactly what the blocking `process_clip` returns, and the detections equal a stand-alone heatmap -> extract_position run."""
+    from upliftingtabletennis_amd import pipeline
+    w, h = 160, 96
+    worker = pipeline.StreamWorker('cuda:0', weights.random_wasb_state_dict(5, planted=True), weights.random_uplift_state_dict(5, 'large'),
+                                   net_wh=(w, h), max_triples=20, traj_len=8, seq_len=12)
+    clips = [torch.from_numpy(synth.synth_frames(18, 108, 176, seed=s)[0]).cuda() for s in (1, 2, 3)]
+    _, table, _, _ = synth.synth_trajectories(1, 4, seed=0)
+    table_px = np.array(table[0], dtype=np.float64) * np.array([1920, 1080, 1.0])
+    blocking = [worker.process_clip(c, table_px, 60.0) for c in clips]
+    tickets, piped = None, []
+    for c in clips:
+        nxt = worker.submit(c)
+        if tickets is not None:
+            piped.append(worker.collect(tickets, table_px, 60.0))
+        tickets = nxt
+    piped.append(worker.collect(tickets, table_px, 60.0))
+    for a, b in zip(blocking, piped):
+        for k in ('xyv', 'spin', 'pos3d', 'n_valid'):
+            assert torch.equal(a[k], b[k]), k
+    heat, _, _ = worker.net.forward_frames(clips[0], want_heatmap=True)
+    ref = refine.extract_position_table(heat, 1920, 1080)[:, 0]
+    assert np.allclose(blocking[0]['xyv'].cpu().numpy(), ref, rtol=0, atol=1e-9)
+    assert blocking[0]['xyv'].shape == (16, 3) and blocking[0]['pos3d'].shape == (2, 12, 3)

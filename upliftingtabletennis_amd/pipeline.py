@@ -95,3 +95,25 @@ class StreamWorker:
         xyv = self.detect(frames_u8)
         spin, p3, nvalid = self.uplift_segments(xyv.cpu().numpy(), table_px, fps)
         return {'xyv': xyv, 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
+
+    # Two-phase form of process_clip for back-to-back clips: `submit` only enqueues the detector (and an asynchronous copy
+    # of its (N,3) result into pinned host memory) and returns at once; `collect` waits for that copy, runs the host glue
+    # and enqueues the uplift.  Submitting clip k+1 before collecting clip k keeps the GPU busy while the host filters
+    # and pads the detections of clip k.
+    def submit(self, frames_u8):
+        xyv = self.detect(frames_u8)
+        ring = self.__dict__.setdefault('_pinned', {})          # two pinned buffers per shape, used alternately
+        slot = ring.setdefault(tuple(xyv.shape), {'bufs': [None, None], 'next': 0})
+        i = slot['next']; slot['next'] = 1 - i
+        if slot['bufs'][i] is None:
+            slot['bufs'][i] = torch.empty(xyv.shape, dtype=xyv.dtype, pin_memory=True)
+        host = slot['bufs'][i]
+        host.copy_(xyv, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return {'xyv': xyv, 'host': host, 'done': done}
+
+    def collect(self, ticket, table_px, fps):
+        ticket['done'].synchronize()
+        spin, p3, nvalid = self.uplift_segments(ticket['host'].numpy(), table_px, fps)
+        return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
