@@ -449,10 +449,47 @@ def gen_trajgen():
     print('trajgen.npz: %d arrays, %.0f KB' % (len(out), os.path.getsize(os.path.join(OUT, 'trajgen.npz')) / 1024))
 
 
+
+def gen_calib():
+    """f4: the reference's `calibrate_camera` (inference/utils.py:312) and `TableTennisPipeline.reproject` arithmetic on
+    synthetic keypoints: the 13 table points projected through known cameras, with pixel noise, an outlier and an
+    invisible keypoint."""
+    if 'mujoco' not in sys.modules:
+        install_mujoco_standin({})
+    for name in ('matplotlib', 'matplotlib.pyplot', 'sklearn', 'sklearn.cluster'):
+        pass
+    import inference.utils as iu
+    from uplifting.helper import table_points, world2cam, cam2img
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(7)
+    out, t0 = {}, time.time()
+    cams = [(2100.0, 2050.0, [0.1, -0.3, 6.5], [2.05, 0.02, 0.03]), (1500.0, 1540.0, [-0.4, 0.2, 5.0], [1.9, -0.1, 0.4]), (2600.0, 2600.0, [0.0, 0.0, 8.0], [2.2, 0.05, -0.2])]
+    for ci, (fx, fy, t, eul) in enumerate(cams):
+        Mint = np.array([[fx, 0, 960, 0], [0, fy, 540, 0], [0, 0, 1, 0.0]])
+        Mext = np.eye(4)
+        Mext[:3, :3] = Rotation.from_euler('xyz', eul).as_matrix()
+        Mext[:3, 3] = t
+        uv = cam2img(world2cam(table_points.astype(np.float64), Mext), Mint)
+        kp = np.concatenate([uv + rng.normal(0, 0.6, uv.shape), np.ones((13, 1))], axis=1)
+        if ci == 1:
+            kp[4, :2] += [40.0, -25.0]           # outlier
+            kp[7, 2] = 0                          # invisible
+        M_int, M_ext = iu.calibrate_camera(kp)
+        out['calib/%d/keypoints' % ci] = kp
+        out['calib/%d/Mint' % ci] = np.asarray(M_int)
+        out['calib/%d/Mext' % ci] = np.asarray(M_ext)
+        pts = rng.uniform(-1.5, 1.5, (5, 3)) + [0, 0, 1.0]
+        out['calib/%d/points' % ci] = pts
+        out['calib/%d/reproj' % ci] = cam2img(world2cam(pts, np.asarray(M_ext)), np.asarray(M_int))
+        print('calib case %d: %.0f s, fx %.1f fy %.1f' % (ci, time.time() - t0, M_int[0][0], M_int[1][1]))
+    out['n'] = np.array([len(cams)])
+    np.savez_compressed(os.path.join(OUT, 'calib.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen']
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib}[w_]()

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, glue, refine, uplift, wasb, weights
+from . import _lib, calib, glue, refine, uplift, wasb, weights
 
 HEIGHT, WIDTH = 1080, 1920
 KEYPOINT_VISIBLE = 1
@@ -127,6 +127,10 @@ class TableDetector:
             return np.zeros((0, 13, 3)), np.zeros((0, 13, h, w), np.float32)
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
+    def calibrate_camera(self, keypoints):
+        """interface.py:174-175: (13,3) keypoints -> (Mint, Mext); host numpy/SciPy like the reference (calib.py)."""
+        return calib.calibrate_camera(keypoints)
+
     def filter_trajectory(self, table_keypoints, table_keypoints_aux):
         return glue.filter_trajectory_table(table_keypoints, table_keypoints_aux)
 
@@ -195,3 +199,11 @@ class TableTennisPipeline:
         filtered, _, times_ball = self.ball_detector.filter_trajectory(ball_positions, ball_positions_aux, fps)
         ball_coords, table_coords, times, mask = glue._uplifting_transform(filtered, np.asarray(table_keypoints, dtype=np.float64), times_ball)
         return self.uplifting_model.predict_without_normalization(ball_coords, table_coords, mask, times)
+
+    def calibrate_camera(self, keypoints):
+        """interface.py:291-299: (13,3) table keypoints [x, y, visibility] in pixels -> Mint (3,4), Mext (4,4)."""
+        return calib.calibrate_camera(keypoints)
+
+    def reproject(self, positions_3d, Mint, Mext):
+        """interface.py:301-312: (N,3) world positions -> (N,2) pixel positions."""
+        return calib.reproject(positions_3d, Mint, Mext)
