@@ -810,7 +810,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 }
 
 // Persistent: a workgroup walks tiles; the next tile's input region is prefetched into registers while the current one is
-// computed (C=32).  C=32 rotates one conv's weights (18 KB) at a time through a register-prefetched LDS slot; C=16 runs one tile
+// computed (C=32).  C=32 keeps the weights of both convs (2 x 18 KB) resident in LDS; C=16 runs one tile
 // per workgroup with its 5 weight fragments per conv straight from L2 (persistent variants measured slower there).
 template <int C, int NB, int TH, int TW>
 __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     constexpr int SZ_A = R0H * R0W * C, SZ_B = (R0H - 2) * (R0W - 2) * C;
     constexpr int KSTEPS = (C == 16) ? 5 : 9, MT = C / 16;
     constexpr int W_UNITS = KSTEPS * MT * 64;                    // 16-byte units per conv
-    constexpr bool RESIDENT = false;                             // (all convs' weights resident in LDS: measured slower for C=16)
+    constexpr bool RESIDENT = (C == 32);                         // both convs' weights (2 x 18 KB) stay in LDS: no rotation, two barriers fewer per tile
     constexpr bool WGLOBAL = (C == 16);                          // C=16: one tile per workgroup, weight fragments straight from global/L2
     constexpr int W_PT = (W_UNITS + 511) / 512;
     constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 511) / 512;
@@ -852,7 +852,9 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
 #pragma unroll
         for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) ((u32x4*)(s_wt + slot * W_UNITS * 8))[u] = pwt[k]; }
     };
-    if (!WGLOBAL && my_tiles > 0) load_wt(0);
+    if (RESIDENT) {
+        for (int cv = 0; cv < 2 * NB; ++cv) { load_wt(cv); store_wt(cv); }
+    } else if (!WGLOBAL && my_tiles > 0) load_wt(0);
     if (my_tiles > 0) issue_in(0);
 
     for (int it = 0; it < my_tiles; ++it) {
@@ -865,16 +867,16 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
             const int u = tid + k * 512;
             if (u < IN_UNITS) { const int c8 = u % (C / 8), pix = u / (C / 8); *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = pin[k]; }
         }
-        if (!WGLOBAL) store_wt(0);
+        if (!WGLOBAL && !RESIDENT) store_wt(0);
         __syncthreads();
         if (it + 1 < my_tiles) issue_in(it + 1);
-        if (!WGLOBAL) load_wt(1);
+        if (!WGLOBAL && !RESIDENT) load_wt(1);
         const bf16_t* w0 = WGLOBAL ? a.w[0] : s_wt;
-        const bf16_t* w1 = WGLOBAL ? a.w[1] : s_wt;
+        const bf16_t* w1 = WGLOBAL ? a.w[1] : (RESIDENT ? s_wt + W_UNITS * 8 : s_wt);
         if (NB == 1) {
             bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
             __syncthreads();
-            if (!WGLOBAL) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
+            if (!WGLOBAL && !RESIDENT) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
             bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
         } else {
             static_assert(NB == 1 || WGLOBAL, "two-block chains read their weights from global memory");
@@ -937,12 +939,13 @@ static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
     return TTUP_OK;
 }
 
+constexpr int BB_WT_SLOTS = 2;          // C=32: the weights of both convs of the block are LDS-resident
 template <int C, int NB, int TH, int TW>
 static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr int L = 2 * NB;
     constexpr int KSTEPS = (C == 16) ? 5 : 9, MT = C / 16;
     constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2 +
-                            (size_t)(C == 16 ? 0 : 1) * KSTEPS * MT * 1024;
+                            (size_t)(C == 16 ? 0 : BB_WT_SLOTS) * KSTEPS * MT * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done && SMEM > 64 * 1024) {
@@ -970,29 +973,10 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         TTUP_REQUIRE(p.cout == c && p.cin_total == c && p.k == 3 && p.stride == 1 && p.ck == (c == 16 ? 16 : 32), TTUP_EINVAL, "bb_chain: unexpected conv shape");
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
-    if (c == 16 && n_convs == 4) {
-        static const int tile = getenv("TTUP_BB16_TILE") ? atoi(getenv("TTUP_BB16_TILE")) : 3;
-        if (tile == 1) return launch_bb2_t<16, 24, 26>(a, batch, h, w, st);
-        if (tile == 2) return launch_bb2_t<16, 16, 26>(a, batch, h, w, st);
-        if (tile == 3) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
-        if (tile == 4) return launch_bb2_t<16, 26, 26>(a, batch, h, w, st);
-        if (tile == 5) return launch_bb2_t<16, 32, 32>(a, batch, h, w, st);
-        if (tile == 6) return launch_bb2_t<16, 24, 48>(a, batch, h, w, st);
-        if (tile == 7) return launch_bb2_t<16, 24, 42>(a, batch, h, w, st);
-        return launch_bb2_t<16, 16, 32>(a, batch, h, w, st);
-    }
+    // tile shapes tuned on MI355X: larger tiles amortise the per-tile overhead and waste fewer ragged 16-pixel MFMA groups
+    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
-    if (c == 32 && n_convs == 2) {
-        static const int tile = getenv("TTUP_BB32_TILE") ? atoi(getenv("TTUP_BB32_TILE")) : 4;
-        if (tile == 1) return launch_bb_t<32, 1, 14, 30>(a, batch, h, w, st);
-        if (tile == 2) return launch_bb_t<32, 1, 16, 32>(a, batch, h, w, st);
-        if (tile == 3) return launch_bb_t<32, 1, 14, 32>(a, batch, h, w, st);
-        if (tile == 4) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);
-        if (tile == 5) return launch_bb_t<32, 1, 30, 30>(a, batch, h, w, st);
-        if (tile == 6) return launch_bb_t<32, 1, 30, 14>(a, batch, h, w, st);
-        if (tile == 7) return launch_bb_t<32, 1, 22, 38>(a, batch, h, w, st);
-        return launch_bb_t<32, 1, 8, 32>(a, batch, h, w, st);
-    }
+    if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
     return TTUP_EINVAL;
 }
