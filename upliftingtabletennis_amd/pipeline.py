@@ -115,5 +115,12 @@ class StreamWorker:
 
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
-        spin, p3, nvalid = self.uplift_segments(ticket['host'].numpy(), table_px, fps)
+        # the uplift (about a hundred small launches for a handful of trajectories) runs on a side stream, so it shares
+        # the GPU with the detector of the clip submitted in the meantime instead of queueing behind it
+        side = self.__dict__.get('_side')
+        if side is None:
+            side = self._side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
+            spin, p3, nvalid = self.uplift_segments(ticket['host'].numpy(), table_px, fps)
+        side.synchronize()
         return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
