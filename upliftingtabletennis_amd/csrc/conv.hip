@@ -479,7 +479,7 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
 // One workgroup (8 waves) produces an 8x32 tile of transition1[0] (3x3 s1 128->16) and the matching 4x16 tile of
 // transition1[1] (3x3 s2 128->32) without the 128-channel layer1 tensor ever leaving the CU:
 //   phase 1  layer1 = relu(conv3(A2) + downsample(T2) + b) on the 10x34 halo tile (1x1, K = 32+64, 128 couts),
-//            rounded to bf16 into LDS exactly as the unfused path rounds it into HBM (results are bit-identical);
+//            rounded to bf16 into LDS exactly as the unfused path rounds it into HBM;
 //   phase 2a 3x3 s1 over the LDS tile -> B0;   phase 2b 3x3 s2 over the same tile -> B1.
 // Reference: wasb.py:96-105 (conv3/bn3 + downsample + add + relu), :454-459 (transition1).
 struct FusedArgs {
@@ -494,26 +494,37 @@ struct FusedArgs {
 __device__ __forceinline__ int l1_off(int pix, int c8) { return pix * 128 + ((c8 ^ (pix & 15)) << 3); }
 __device__ __forceinline__ int st_off(int pix, int c8) { return pix * 32 + ((c8 ^ ((4 - ((pix >> 2) & 3)) & 3)) << 3); }
 
+// No weight traffic inside the tile loop: W1 and W5 stay in LDS for the life of the workgroup; the 3x3/s2 conv (phase 2b)
+// is split over K instead of over output rows -- wave (cc, m) keeps the nine W6 fragments of its 32-channel chunk cc and
+// m-tile m in REGISTERS for all tiles and accumulates partial sums for all four output rows (four independent MFMA
+// chains); the partials meet in LDS (in the L1 tile's storage once every wave is done reading it) and wave (m, r)
+// reduces row r.  Four barriers per tile.  The fp32 summation order of phase 2b (four partial sums) differs from the
+// layer-wise kernel's, everything else is the same arithmetic.
 __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     constexpr int IH = 10, IW = 34, NPIX = IH * IW;            // 340 halo pixels
-    constexpr int NT1 = 22;                                     // 16-pixel groups covering the halo tile
-    constexpr int W1_U = 3 * 8 * 64, W5_U = 4 * 9 * 64, W6H_U = 2 * 9 * 2 * 64;      // 16-byte units
+    constexpr int NT1 = 22;
+    constexpr int W1_U = 3 * 8 * 64, W5_U = 4 * 9 * 64;         // 16-byte units
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]              87,040 B
-    bf16_t* s_w1 = s_l1 + NPIX * 128;                           // phase-1 weights         24,576 B (resident)
-    bf16_t* s_w = s_w1 + W1_U * 8;                              // phase-2 weights         36,864 B (W5 -> W6a -> W6b per tile)
+    bf16_t* s_l1 = (bf16_t*)smem;                               // [340][128]  87,040 B  (phase-2b partial sums alias its first 32 KB)
+    bf16_t* s_w1 = s_l1 + NPIX * 128;                           // 24,576 B resident
+    bf16_t* s_w5 = s_w1 + W1_U * 8;                             // 36,864 B resident
+    float* s_b1 = (float*)(s_w5 + W5_U * 8);                    // 512 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    // Persistent workgroup: W1 stays in LDS; every other global load of a tile (pixel fragments of the 1x1 conv, W5, both
-    // halves of W6) is issued one phase ahead into registers so that its latency hides behind the matrix work.
     for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
-    float* s_b1 = (float*)(s_w + W5_U * 8);                    // phase-1 bias, 512 B (kept out of the register file)
+    for (int u = tid; u < W5_U; u += 512) ((u32x4*)s_w5)[u] = ((const u32x4*)a.w5)[u];
     if (tid < 128) s_b1[tid] = a.b1[tid];
+    const int cc = wave & 3, m6 = wave >> 2;
+    bf16x8 af6[9];
+#pragma unroll
+    for (int s9 = 0; s9 < 9; ++s9) af6[s9] = *(const bf16x8*)(a.w6 + (((cc * 9 + s9) * 2 + m6) * 64 + lane) * 8);
+    const f32x4 bias6 = *(const f32x4*)(a.b6 + g * 8 + m6 * 4);
+    const f32x4 b5 = *(const f32x4*)(a.b5 + g * 4);
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
-    u32x4 pb[3][3], pw[5];          // pw: one weight block in flight at a time (W5 during phase 1, W6a during 2a, W6b during 2b/0)
+    u32x4 pb[3][3];
     bool p_in[3];
-    auto issue_pix = [&](int it) {      // phase-1 pixel fragments straight from global: 16 px x 64 B are contiguous in NHWC
+    auto issue_pix = [&](int it) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int gy0 = (tt / a.tiles_x) * 8 - 1, gx0 = (tt % a.tiles_x) * 32 - 1;
@@ -532,31 +543,21 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             }
         }
     };
-    auto load_w = [&](u32x4* dst, const bf16_t* src, int units) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < units) dst[k] = ((const u32x4*)src)[u]; }
-    };
-    auto store_w = [&](const u32x4* src, int units) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { const int u = tid + k * 512; if (u < units) ((u32x4*)s_w)[u] = src[k]; }
-    };
     if (my_tiles > 0) issue_pix(0);
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        __syncthreads();            // previous tile done with s_l1 / s_w (W1 visible on the first pass)
-        load_w(pw, a.w5, W5_U);     // in flight during phase 1
-        // ---------------- phase 1: layer1 halo tile (one 16-pixel group at a time keeps the accumulator footprint at 32 VGPRs)
+        __syncthreads();            // previous tile's reduction has read its partial sums (weights visible on the first pass)
+        // ---------------- phase 1: layer1 halo tile
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t, pix = j * 16 + n;
             if (j >= NT1) continue;
-            f32x4 acc[8];          // seeded with the bias of the lane's channels g*32 + 4m ..
+            f32x4 acc[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc[m] = *(const f32x4*)(s_b1 + g * 32 + m * 4);
-#ifndef TTUP_ABLATE_P1
 #pragma unroll
             for (int chunk = 0; chunk < 3; ++chunk) {
                 const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
@@ -566,7 +567,6 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
                 }
             }
-#endif
             if (pix < NPIX) {
                 const bool inside = p_in[t];
 #pragma unroll
@@ -581,22 +581,16 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                 }
             }
         }
-        store_w(pw, W5_U);
         __syncthreads();
-        load_w(pw, a.w6, W6H_U);                                // first half of W6: in flight during phase 2a
-        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phases 2a/2b
+        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phase 2
         // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
-#ifdef TTUP_ABLATE_P2A
-        if (a.H < 0)
-#endif
         {
-            const f32x4 b5 = *(const f32x4*)(a.b5 + g * 4);
             f32x4 acc[2] = {b5, b5};
 #pragma unroll 2
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int s9 = 0; s9 < 9; ++s9) {
-                    const bf16x8 af = *(const bf16x8*)(s_w + ((c * 9 + s9) * 64 + lane) * 8);
+                    const bf16x8 af = *(const bf16x8*)(s_w5 + ((c * 9 + s9) * 64 + lane) * 8);
                     const int dy = s9 / 3, dx = s9 % 3;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -609,41 +603,46 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
-                if (oy < a.H && ox < a.W) {
+                if (oy < a.H && ox < a.W)
                     *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) =
                         u32x2{relu_pk(pack2(acc[t][0], acc[t][1])), relu_pk(pack2(acc[t][2], acc[t][3]))};
+            }
+        }
+        // ---------------- phase 2b: 3x3 s2 128 -> 32, K-chunk cc / m-tile m6 of all four output rows
+        f32x4 part[4];
+        {
+            const f32x4 seed = cc == 0 ? bias6 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[r] = seed;
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {
+                const int dy = s9 / 3, dx = s9 % 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pix = (2 * r + dy) * IW + 2 * n + dx;
+                    const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, cc * 4 + g));
+                    part[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af6[s9], bfr, part[r], 0, 0, 0);
                 }
             }
         }
-        // ---------------- phase 2b: 3x3 s2 128 -> 32; wave = (output row r, m-tile m); weights two chunks at a time
-#ifndef TTUP_ABLATE_P2B
+        __syncthreads();            // every wave is done reading the L1 tile: its storage now carries the partial sums
         {
-            const int r = wave >> 1, m = wave & 1;
-            f32x4 acc = *(const f32x4*)(a.b6 + g * 8 + m * 4);
+            float* s_part = (float*)s_l1;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                __syncthreads();
-                store_w(pw, W6H_U);
-                __syncthreads();
-                if (half == 0) load_w(pw, a.w6 + (size_t)W6H_U * 8, W6H_U);      // second half: in flight during the first
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                    for (int s9 = 0; s9 < 9; ++s9) {
-                        const bf16x8 af = *(const bf16x8*)(s_w + (((cc * 9 + s9) * 2 + m) * 64 + lane) * 8);
-                        const int dy = s9 / 3, dx = s9 % 3;
-                        const int pix = (2 * r + dy) * IW + 2 * n + dx;
-                        const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, (half * 2 + cc) * 4 + g));
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc, 0, 0, 0);
-                    }
-            }
-            const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
-            const int oy = (oy0 >> 1) + r, ox = (ox0 >> 1) + n;
-            if (oy < OH && ox < OW) {
-                *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + m * 4) = u32x2{relu_pk(pack2(acc[0], acc[1])), relu_pk(pack2(acc[2], acc[3]))};
-            }
+            for (int r = 0; r < 4; ++r) *(f32x4*)(s_part + (((m6 * 4 + cc) * 4 + r) * 64 + lane) * 4) = part[r];
         }
-#endif
+        __syncthreads();
+        {
+            const float* s_part = (const float*)s_l1;
+            const int mr = wave >> 2, rr = wave & 3;            // this wave reduces m-tile mr, output row rr
+            f32x4 v = *(const f32x4*)(s_part + (((mr * 4 + 0) * 4 + rr) * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) v += *(const f32x4*)(s_part + (((mr * 4 + c) * 4 + rr) * 64 + lane) * 4);
+            const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
+            const int oy = (oy0 >> 1) + rr, ox = (ox0 >> 1) + n;
+            if (oy < OH && ox < OW)
+                *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + mr * 4) = u32x2{relu_pk(pack2(v[0], v[1])), relu_pk(pack2(v[2], v[3]))};
+        }
     }
 }
 
