@@ -284,6 +284,124 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ 3x3 64 -> 64 with resident weights
+// The 64-channel BasicBlock convs of stages 3/4 (wasb.py:48-64) at 1/4 resolution: both 32-channel chunks of the weights
+// (73.7 KB) stay in LDS for the life of the persistent workgroup, the whole 64-channel halo tile (10x34 px, 43.5 KB) is
+// staged at once (register-prefetched one tile ahead), so a tile is 18 k-steps between two barriers and no weight byte
+// moves inside the loop -- the generic kernel re-stages 36.8 KB of weights per (tile, chunk) item.
+__global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
+    constexpr int IH = 10, IW = 34, NPIX = IH * IW;
+    constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units
+    constexpr int IN_UNITS = NPIX * 8, IN_PT = (IN_UNITS + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_w = (bf16_t*)smem;                                // 73,728 B
+    bf16_t* s_in = s_w + W_U * 8;                               // [2 chunks][340 px][32 ch]  43,520 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    for (int u = tid; u < W_U; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.wpack)[u];
+    f32x4 bias[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bias[m] = *(const f32x4*)(a.bias + g * 16 + m * 4);
+    const bf16_t* bB[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bB[dx] = s_in + lds_off<32, IW>(0, n + dx, g);
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    u32x4 pin[IN_PT];
+    auto issue = [&](int it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * 8 - 1, gx0 = (t % a.tiles_x) * 32 - 1;
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u & 7, pix = u >> 3;
+            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            pin[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                pin[k] = *(const u32x4*)(a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * 64 + c8 * 8);
+        }
+    };
+    if (my_tiles > 0) issue(0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            if (u < IN_UNITS) { const int c8 = u & 7, pix = u >> 3; *(u32x4*)(s_in + (c8 >> 2) * (NPIX * 32) + lds_off<32, IW>(pix / IW, pix % IW, c8 & 3)) = pin[k]; }
+        }
+        __syncthreads();
+        if (it + 1 < my_tiles) issue(it + 1);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w + (((c * 9 + s9) * 4 + m) * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+                    const bf16x8 bfr = *(const bf16x8*)(bB[s9 % 3] + c * (NPIX * 32) + ((r + s9 / 3) * IW + cg * 16) * 32);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nt = wave * 2 + t;
+            const int oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
+            if (oy >= a.H || ox >= a.W) continue;
+            const size_t o = ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16;
+            float v[16];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r];
+            if (a.residual) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x4 rv = *(const u32x4*)(a.residual + o + q * 8);
+                    const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[q * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 pk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[i] = a.relu ? relu_pk(w) : w; }
+                *(u32x4*)(a.dst + o + q * 8) = pk;
+            }
+        }
+    }
+}
+
+static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
+    ConvKArgs a;
+    memset(&a, 0, sizeof a);
+    a.src0 = (const bf16_t*)l.src0; a.wpack = (const bf16_t*)p.w_dev; a.bias = p.bias_dev; a.residual = (const bf16_t*)l.residual; a.dst = (bf16_t*)l.dst;
+    a.H = l.h; a.W = l.w; a.OH = l.h; a.OW = l.w; a.relu = l.relu;
+    a.tiles_x = cdiv(l.w, 32); a.tiles_per_img = a.tiles_x * cdiv(l.h, 8); a.total_tiles = a.tiles_per_img * l.batch;
+    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_done = true;
+    }
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL(conv64_kernel, dim3(grid), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 // ------------------------------------------------------------------ fused stem: conv1 + conv2 (+ Bottleneck conv1)
 // Persistent workgroups (8 waves) keep ALL weights of the stem in LDS (conv1 20 KB + conv2 73.7 KB) and walk 8x32 tiles:
 //   X0 halo tile (12x36 px, 16 ch, register-prefetched one tile ahead) -> conv1 3x3 9(16)->64 +ReLU on the 10x34 halo
@@ -1157,6 +1275,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         TTUP_REQUIRE(p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64, TTUP_EINVAL, "conv: fused follower needs a 3x3 s1 conv with 64 outputs");
         return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);
     }
+    if (p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64 && p.cin_total == 64 && p.c0 == 64 && !l.src1 && !getenv("TTUP_NO_CONV64")) return launch_conv64(p, l, st);
     if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
     if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);
     if (p.k == 1 && p.stride == 1 && p.ck == 32) return dispatch_cout<32, 1, 1, 8, 32>(p, l, st);
