@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Phase timing of the 16-channel chain kernel from a TTUP_TIMING build (tools/build_ablate.sh TIMING; TTUP_LIB=...):
+per-workgroup s_memtime stamps -> mean cycles per phase."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from upliftingtabletennis_amd import synth, wasb, weights, _lib
+n = 8
+frames, _ = synth.synth_frames(n + 2, 720, 1280, seed=0)
+net = wasb.WASBNet(weights.random_wasb_state_dict(0, planted=True), resolution=(1280, 704), max_batch=n, dtype='bf16')
+net.forward_frames(torch.from_numpy(frames).cuda())
+torch.cuda.synchronize()
+lib = ctypes.CDLL(_lib.LIB_PATH)
+buf = np.zeros(8192 * 8, dtype=np.uint64)
+rc = lib.ttup_debug_read_timing(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+t = buf.reshape(8192, 8).astype(np.int64)
+ok = t[:, 0] > 0
+d = np.diff(t[ok][:, :7], axis=1)
+names = ['stage+barrier', 'conv1', 'barrier1', 'conv2+barrier', 'conv3+barrier', 'conv4']
+print('rc', rc, 'workgroups', int(ok.sum()))
+for i, nm in enumerate(names):
+    print('%-16s mean %8.0f  median %8.0f  p90 %8.0f cycles (100 MHz s_memtime ticks x?)' % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+print('total mean', (t[ok][:, 6] - t[ok][:, 0]).mean())

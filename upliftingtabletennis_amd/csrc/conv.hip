@@ -1008,6 +1008,13 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     }
 }
 
+#ifdef TTUP_TIMING
+// debug build only (tools/build_ablate.sh TIMING): per-workgroup phase timestamps of bb_chain2_kernel
+__device__ unsigned long long ttup_tbuf[8192 * 8];
+#define TTUP_STAMP(k) do { if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TTUP_STAMP(k) do { } while (0)
+#endif
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
 // Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
 template <int C, int TH, int TW>
@@ -1022,6 +1029,7 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
     const int tl = blockIdx.x;
     const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
     const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+    TTUP_STAMP(0);
     for (int u = tid; u < R0H * R0W * (C / 8); u += 512) {
         const int c8 = u % (C / 8), pix = u / (C / 8);
         const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
@@ -1030,13 +1038,19 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
         *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v;
     }
     __syncthreads();
+    TTUP_STAMP(1);
     bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
+    TTUP_STAMP(2);
     __syncthreads();
+    TTUP_STAMP(3);
     bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
     __syncthreads();
+    TTUP_STAMP(4);
     bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
     __syncthreads();
+    TTUP_STAMP(5);
     bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+    TTUP_STAMP(6);
 }
 
 template <int C, int TH, int TW>
@@ -1529,3 +1543,10 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
 }
 
 }  // namespace ttup
+
+#ifdef TTUP_TIMING
+extern "C" int ttup_debug_read_timing(unsigned long long* out_host, int n_words) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ttup::ttup_tbuf), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif
