@@ -21,3 +21,23 @@ print('rc', rc, 'workgroups', int(ok.sum()))
 for i, nm in enumerate(names):
     print('%-16s mean %8.0f  median %8.0f  p90 %8.0f cycles (100 MHz s_memtime ticks x?)' % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
 print('total mean', (t[ok][:, 6] - t[ok][:, 0]).mean())
+
+buf2 = np.zeros(2 * 32 * 64 * 8, dtype=np.uint64)
+lib.ttup_debug_read_timing_it(buf2.ctypes.data_as(ctypes.c_void_p), buf2.size)
+t2 = buf2.reshape(2, 32, 64, 8).astype(np.int64)
+for kid, name, labels in ((0, 'stem', ['wait top barrier', 'X0 commit+barrier+issue', 'conv1', 'barrier', 'conv2', 'epilogue+follower+stores (to next top)']),
+                          (1, 'bneck', ['wait top barrier', 'phase 1', 'barrier', 'phase 2a', 'phase 2b', 'barrier', 'partials+barrier+reduce (to next top)'])):
+    x = t2[kid][:, 2:60]                    # skip warm-up iterations
+    ok2 = (x[..., 0] > 0) & (x[..., 1] > 0)
+    n_slots = len(labels)
+    print(name, 'tiles sampled', int(ok2.sum()))
+    tot = 0.0
+    for i in range(n_slots):
+        if i + 1 < n_slots:
+            d2 = (x[..., i + 1] - x[..., i])[ok2]
+        else:                                # last slot: until the next iteration's slot 0
+            nxt = t2[kid][:, 3:61, 0]
+            d2 = (nxt - x[..., i])[ok2 & (nxt > 0)]
+        tot += d2.mean()
+        print('  %-42s mean %7.0f  p90 %7.0f' % (labels[i], d2.mean(), np.percentile(d2, 90)))
+    print('  total per tile %.0f cycles' % tot)

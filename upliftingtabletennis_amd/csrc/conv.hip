@@ -19,6 +19,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+#ifdef TTUP_TIMING
+// debug build only (tools/build_ablate.sh TIMING): phase timestamps (s_memtime) of wave 0.
+//   TTUP_STAMP(k)        one-tile-per-workgroup kernels: slot k of workgroup blockIdx.x          (bb_chain2_kernel)
+//   TTUP_STAMP_IT(id,it,k) persistent kernels: kernel id (0 stem, 1 bneck), tile iteration it < 64 of workgroups < 32
+__device__ unsigned long long ttup_tbuf[8192 * 8];
+__device__ unsigned long long ttup_tbuf_it[2 * 32 * 64 * 8];
+#define TTUP_STAMP(k) do { if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TTUP_STAMP_IT(id, it, k) do { if (tid == 0 && blockIdx.x < 32 && (it) < 64) ttup_tbuf_it[(((id) * 32 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TTUP_STAMP(k) do { } while (0)
+#define TTUP_STAMP_IT(id, it, k) do { } while (0)
+#endif
+
 struct ConvKArgs {
     const bf16_t* src0;
     const bf16_t* src1;
@@ -475,11 +488,14 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        TTUP_STAMP_IT(0, it, 0);
         __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
+        TTUP_STAMP_IT(0, it, 1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k]; }
         __syncthreads();
         if (it + 1 < my_tiles) issue(it + 1);
+        TTUP_STAMP_IT(0, it, 2);
         // ---------------- conv1 on the 10x34 region (22 groups of 16 pixels, linear pixel index)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -516,7 +532,9 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                 }
             }
         }
+        TTUP_STAMP_IT(0, it, 3);
         __syncthreads();
+        TTUP_STAMP_IT(0, it, 4);
         // ---------------- conv2 on the 8x32 tile, both 32-channel planes straight from LDS
         f32x4 acc[4][2];
 #pragma unroll
@@ -538,6 +556,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                 }
             }
 #endif
+        TTUP_STAMP_IT(0, it, 5);
         // ---------------- T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -667,7 +686,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        TTUP_STAMP_IT(1, it, 0);
         __syncthreads();            // previous tile's reduction has read its partial sums (weights visible on the first pass)
+        TTUP_STAMP_IT(1, it, 1);
         // ---------------- phase 1: layer1 halo tile
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -699,33 +720,39 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                 }
             }
         }
+        TTUP_STAMP_IT(1, it, 2);
         __syncthreads();
+        TTUP_STAMP_IT(1, it, 3);
         if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phase 2
-        // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile
+        // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile.  A wave owns two VERTICALLY adjacent 16-pixel groups
+        // (rows 2q, 2q+1 of column half ch): the four input rows they touch are read once per (chunk, tap column) and
+        // shared by both outputs -- 4 fragment reads instead of 6.
         {
+            const int q2 = wave >> 1, ch = wave & 1;
             f32x4 acc[2] = {b5, b5};
 #pragma unroll 2
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int s9 = 0; s9 < 9; ++s9) {
-                    const bf16x8 af = *(const bf16x8*)(s_w5 + ((c * 9 + s9) * 64 + lane) * 8);
-                    const int dy = s9 / 3, dx = s9 % 3;
+                for (int dx = 0; dx < 3; ++dx) {
+                    bf16x8 brow[4];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
-                        const int pix = (r + dy) * IW + cg * 16 + n + dx;
-                        const bf16x8 bfr = *(const bf16x8*)(s_l1 + l1_off(pix, c * 4 + g));
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                    for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n + dx, c * 4 + g));
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const bf16x8 af = *(const bf16x8*)(s_w5 + ((c * 9 + dy * 3 + dx) * 64 + lane) * 8);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, brow[dy], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, brow[dy + 1], acc[1], 0, 0, 0);
                     }
                 }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int nt = wave * 2 + t, oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
+                const int oy = oy0 + 2 * q2 + t, ox = ox0 + ch * 16 + n;
                 if (oy < a.H && ox < a.W)
                     *(u32x2*)(a.b0 + ((size_t)(b * a.H + oy) * a.W + ox) * 16 + g * 4) =
                         u32x2{relu_pk(pack2(acc[t][0], acc[t][1])), relu_pk(pack2(acc[t][2], acc[t][3]))};
             }
         }
+        TTUP_STAMP_IT(1, it, 4);
         // ---------------- phase 2b: 3x3 s2 128 -> 32, K-chunk cc / m-tile m6 of all four output rows
         f32x4 part[4];
         {
@@ -743,7 +770,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                 }
             }
         }
+        TTUP_STAMP_IT(1, it, 5);
         __syncthreads();            // every wave is done reading the L1 tile: its storage now carries the partial sums
+        TTUP_STAMP_IT(1, it, 6);
         {
             float* s_part = (float*)s_l1;
 #pragma unroll
@@ -1008,13 +1037,6 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     }
 }
 
-#ifdef TTUP_TIMING
-// debug build only (tools/build_ablate.sh TIMING): per-workgroup phase timestamps of bb_chain2_kernel
-__device__ unsigned long long ttup_tbuf[8192 * 8];
-#define TTUP_STAMP(k) do { if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TTUP_STAMP(k) do { } while (0)
-#endif
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
 // Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
 template <int C, int TH, int TW>
@@ -1548,5 +1570,9 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
 extern "C" int ttup_debug_read_timing(unsigned long long* out_host, int n_words) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ttup::ttup_tbuf), (size_t)n_words * sizeof(unsigned long long));
+}
+extern "C" int ttup_debug_read_timing_it(unsigned long long* out_host, int n_words) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ttup::ttup_tbuf_it), (size_t)n_words * sizeof(unsigned long long));
 }
 #endif
