@@ -350,25 +350,28 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
+        // two vertically adjacent 16-pixel groups per wave: their four input rows are read once per (chunk, tap column)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s9 = 0; s9 < 9; ++s9) {
-                bf16x8 af[4];
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 brow[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w + (((c * 9 + s9) * 4 + m) * 64 + lane) * 8);
+                for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(bB[dx] + c * (NPIX * 32) + ((2 * (wave >> 1) + rr) * IW + (wave & 1) * 16) * 32);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
-                    const bf16x8 bfr = *(const bf16x8*)(bB[s9 % 3] + c * (NPIX * 32) + ((r + s9 / 3) * IW + cg * 16) * 32);
+                for (int dy = 0; dy < 3; ++dy) {
+                    bf16x8 af[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+                    for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w + (((c * 9 + dy * 3 + dx) * 4 + m) * 64 + lane) * 8);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[dy + t], acc[m][t], 0, 0, 0);
                 }
             }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int nt = wave * 2 + t;
-            const int oy = oy0 + (nt >> 1), ox = ox0 + (nt & 1) * 16 + n;
+            const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
             if (oy >= a.H || ox >= a.W) continue;
             const size_t o = ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16;
             float v[16];
@@ -540,19 +543,24 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
 #ifndef TTUP_ABLATE_S2
+        // a wave owns two vertically adjacent 16-pixel groups (rows 2q, 2q+1 of column half ch): the four input rows they
+        // touch are read once per (chunk, tap column) and shared by both outputs
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s9 = 0; s9 < 9; ++s9) {
-                bf16x8 af[4];
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 brow[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w2 + (((c * 9 + s9) * 4 + m) * 64 + lane) * 8);
+                for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(bB[dx] + c * (NP1 * 32) + ((2 * (wave >> 1) + rr) * TW1 + (wave & 1) * 16) * 32);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
-                    const bf16x8 bfr = *(const bf16x8*)(bB[s9 % 3] + c * (NP1 * 32) + ((r + s9 / 3) * TW1 + cg * 16) * 32);
+                for (int dy = 0; dy < 3; ++dy) {
+                    bf16x8 af[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][t], 0, 0, 0);
+                    for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w2 + (((c * 9 + dy * 3 + dx) * 4 + m) * 64 + lane) * 8);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[dy + t], acc[m][t], 0, 0, 0);
                 }
             }
 #endif
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         // ---------------- T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int nt = wave * 2 + t, r = nt >> 1, cg = nt & 1;
+            const int r = 2 * (wave >> 1) + t, cg = wave & 1;
             const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
             const bool ok = oy < a.H && ox < a.W;
             u32x4 pk[2];
