@@ -492,10 +492,12 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
         TTUP_STAMP_IT(0, it, 0);
-        __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
-        TTUP_STAMP_IT(0, it, 1);
+        // The X0 tile was last read in conv1 of the previous tile, which every wave left before the barrier in the middle
+        // of that iteration: it can be overwritten without waiting.  ONE barrier then covers "X0 tile complete" and
+        // "previous conv2 done reading the T1 tile" (and the weights on the first pass).
 #pragma unroll
         for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k]; }
+        TTUP_STAMP_IT(0, it, 1);
         __syncthreads();
         if (it + 1 < my_tiles) issue(it + 1);
         TTUP_STAMP_IT(0, it, 2);
