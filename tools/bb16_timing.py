@@ -21,6 +21,8 @@ print('rc', rc, 'workgroups', int(ok.sum()))
 for i, nm in enumerate(names):
     print('%-16s mean %8.0f  median %8.0f  p90 %8.0f cycles (100 MHz s_memtime ticks x?)' % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
 print('total mean', (t[ok][:, 6] - t[ok][:, 0]).mean())
+rt = t[ok][:, 7]
+print('in-kernel shader clock: %.0f MHz (s_memtime span / s_memrealtime span x 100 MHz, median over workgroups)' % np.median((t[ok][:, 6] - t[ok][:, 0]) / np.maximum(rt, 1) * 100.0))
 
 buf2 = np.zeros(2 * 32 * 64 * 8, dtype=np.uint64)
 lib.ttup_debug_read_timing_it(buf2.ctypes.data_as(ctypes.c_void_p), buf2.size)

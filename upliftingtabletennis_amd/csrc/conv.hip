@@ -1061,6 +1061,9 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
     const int tl = blockIdx.x;
     const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
     const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+#ifdef TTUP_TIMING
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     TTUP_STAMP(0);
     for (int u = tid; u < R0H * R0W * (C / 8); u += 512) {
         const int c8 = u % (C / 8), pix = u / (C / 8);
@@ -1083,6 +1086,9 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
     TTUP_STAMP(5);
     bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
     TTUP_STAMP(6);
+#ifdef TTUP_TIMING
+    if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz ticks for the same span
+#endif
 }
 
 template <int C, int TH, int TW>
