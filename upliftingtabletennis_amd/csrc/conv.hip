@@ -1226,7 +1226,6 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, 
     }
     TTUP_REQUIRE(c0 % 16 == 0 && c1 % 32 == 0, TTUP_EINVAL, "channel counts %d+%d unsupported", c0, c1);
     int ck = (c0 % 32 == 0) ? 32 : 16;
-    if (getenv("TTUP_FORCE_CK16") && k == 3 && c1 == 0 && a.stride == 1 && c0 == 64 && cout == 64) ck = 16;      // experiment: smaller LDS footprint, more workgroups per CU
     TTUP_REQUIRE(ck == 32 || (c1 == 0 && k == 3), TTUP_EINVAL, "16-channel chunks only for single-source 3x3");
     const int mt = cout / 16, ksteps = ck == 32 ? taps : (taps + 1) / 2, nchunk = cin_total / ck;
     std::vector<bf16_t> w((size_t)nchunk * ksteps * mt * 64 * 8);
@@ -1327,7 +1326,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         TTUP_REQUIRE(p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64, TTUP_EINVAL, "conv: fused follower needs a 3x3 s1 conv with 64 outputs");
         return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);
     }
-    if (p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64 && p.cin_total == 64 && p.c0 == 64 && !l.src1 && !getenv("TTUP_NO_CONV64")) return launch_conv64(p, l, st);
+    if (p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64 && p.cin_total == 64 && p.c0 == 64 && !l.src1) return launch_conv64(p, l, st);
     if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
     if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);
     if (p.k == 1 && p.stride == 1 && p.ck == 32) return dispatch_cout<32, 1, 1, 8, 32>(p, l, st);
