@@ -49,7 +49,8 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
                        void* b0, void* b1, int batch, int h, int w, hipStream_t st);
 
 // fused chain of 1 or 2 BasicBlocks (2 or 4 3x3 convs, C = 16 or 32) of one branch, bf16 only (csrc/conv.hip)
-int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w, hipStream_t st);
+int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
+                    const PackedConv* follow, void* y_follow, hipStream_t st);
 
 // y = relu(base + sum_k nearest_upsample(t_k, 2^shift_k)); all NHWC with c channels; base at (h,w).
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,

@@ -838,6 +838,9 @@ struct BBArgs {
     const bf16_t* x; bf16_t* y;
     const bf16_t* w[4]; const float* bias[4];
     int H, W, tiles_x, tiles_per_img, total_tiles;
+    // optional 1x1 follower on the chain output (C=32 -> 16, BN folded, no ReLU: the fuse-layer conv of wasb.py:189-205 that
+    // feeds the higher-resolution branch): one extra MFMA per 16-pixel group on the bf16 pairs just packed
+    const bf16_t* wf; const float* bf; bf16_t* yf;
 };
 
 // element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
@@ -854,7 +857,8 @@ template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
 // unrolled so every LDS address is a per-lane base plus an immediate.
 template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
-                                        bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane) {
+                                        bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
+                                        const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
@@ -893,6 +897,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     const int out_ch = (C == 32) ? ((g ^ (((n + OOFF) >> 1) & 3)) << 3) : ch_off;
     // zero padding of the next conv: outputs outside the image must be 0; only border tiles have any (wave-uniform test)
     const bool interior = gy0 >= 0 && gy0 + RHO <= H && gx0 >= 0 && gx0 + RWO <= W;
+    constexpr bool CAN_FOLLOW = GLOBAL_OUT && C == 32;
+    bf16x8 af_f = {};
+    f32x4 bias_f = {0.f, 0.f, 0.f, 0.f};
+    if (CAN_FOLLOW && yf) { af_f = *(const bf16x8*)(wf + lane * 8); bias_f = *(const f32x4*)(bfp + g * 4); }
     for (int y = wave; y < RHO; y += 8) {
         const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
         const bf16_t* rp0 = row + n * C;
@@ -927,7 +935,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt) {
             const int x = xt * 16 + n;
-            if (xt == XT - 1 && x >= RWO) continue;
+            const bool valid = !(xt == XT - 1 && x >= RWO);       // ragged last group: computed (the follower MFMA needs the whole wave), not stored
             float v[4 * MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -951,12 +959,19 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
             }
             if (GLOBAL_OUT) {
-                if (inside) {
+                if (inside && valid) {
                     bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
                     if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                     else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
-            } else {
+                if constexpr (CAN_FOLLOW) {
+                    if (yf) {          // lane (n, g) holds channels 8g..8g+7 of its pixel = k-group g of the follower's only k-step
+                        const u32x4 bq = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                        const f32x4 cf = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_f, __builtin_bit_cast(bf16x8, bq), bias_f, 0, 0, 0);
+                        if (inside && valid) *(u32x2*)(yf + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{pack2(cf[0], cf[1]), pack2(cf[2], cf[3])};
+                    }
+                }
+            } else if (valid) {
                 bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + out_ch;
                 if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                 else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -1033,7 +1048,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
             bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
             __syncthreads();
             if (!WGLOBAL && !RESIDENT) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
-            bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+            bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane, a.wf, a.bf, a.yf);
         } else {
             static_assert(NB == 1 || WGLOBAL, "two-block chains read their weights from global memory");
             bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
@@ -1131,11 +1146,18 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     return TTUP_OK;
 }
 
-int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w, hipStream_t st) {
+int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
+                    const PackedConv* follow, void* y_follow, hipStream_t st) {
     TTUP_REQUIRE(n_convs == 2 || n_convs == 4, TTUP_EINVAL, "bb_chain: 2 or 4 convs expected");
     const int c = convs[0]->cout;
     BBArgs a;
     a.x = (const bf16_t*)x; a.y = (bf16_t*)y;
+    a.wf = nullptr; a.bf = nullptr; a.yf = nullptr;
+    if (follow) {
+        TTUP_REQUIRE(c == 32 && n_convs == 2 && follow->cout == 16 && follow->cin_total == 32 && follow->k == 1 && follow->ck == 32 && y_follow, TTUP_EINVAL,
+                     "bb_chain: the fused follower is a 1x1 32->16 conv on a 32-channel block");
+        a.wf = (const bf16_t*)follow->w_dev; a.bf = follow->bias_dev; a.yf = (bf16_t*)y_follow;
+    }
     for (int i = 0; i < 4; ++i) { a.w[i] = nullptr; a.bias[i] = nullptr; }
     for (int i = 0; i < n_convs; ++i) {
         const PackedConv& p = *convs[i];

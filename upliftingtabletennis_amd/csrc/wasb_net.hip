@@ -237,8 +237,18 @@ struct Builder {
                     const int pc = pack(*tm->chain[0], nullptr, 0);
                     const Tensor sj = net->tensors[xs[j]];
                     const int dst = new_tensor(STAGE_CH[i], sj.h, sj.w);
+                    // 32 -> 16 on the output of a fused 32-channel block: rides in that kernel's epilogue (one MFMA per pixel group)
+                    bool attached = false;
+                    if (fuse && sj.c == 32 && STAGE_CH[i] == 16) {
+                        for (int k = (int)net->ops.size() - 1; k >= 0 && !attached; --k) {
+                            Op& po = net->ops[k];
+                            if (po.dst != xs[j]) continue;
+                            if (po.kind == Op::BB_CHAIN && po.n_chain == 2 && po.conv2 < 0) { po.conv2 = pc; po.dst2 = dst; attached = true; }
+                            break;
+                        }
+                    }
                     Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = xs[j]; op.dst = dst; op.relu = 0;
-                    net->ops.push_back(op);
+                    if (!attached) net->ops.push_back(op);
                     up_t.push_back(dst); up_s.push_back(j - i);
                 } else {            // chain of stride-2 3x3 convs; the last one adds the running sum
                     int cur = xs[j];
@@ -372,7 +382,8 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
             const Tensor& s = net->tensors[op.src0];
             const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int k = 0; k < op.n_chain; ++k) cv[k] = &net->convs[op.chain[k]];
-            const int rc = launch_bb_chain(cv, op.n_chain, s.ptr, net->tensors[op.dst].ptr, mb, s.h, s.w, st);
+            const int rc = launch_bb_chain(cv, op.n_chain, s.ptr, net->tensors[op.dst].ptr, mb, s.h, s.w,
+                                           op.conv2 >= 0 ? &net->convs[op.conv2] : nullptr, op.dst2 >= 0 ? net->tensors[op.dst2].ptr : nullptr, st);
             if (rc) return rc;
         } else if (op.kind == Op::BNECK_TRANS) {
             const Tensor& s = net->tensors[op.src0];
