@@ -371,3 +371,24 @@ def test_stream_worker_pipelined_steps_equal_the_blocking_step():
     ref = refine.extract_position_table(heat, 1920, 1080)[:, 0]
     assert np.allclose(blocking[0]['xyv'].cpu().numpy(), ref, rtol=0, atol=1e-9)
     assert blocking[0]['xyv'].shape == (16, 3) and blocking[0]['pos3d'].shape == (2, 12, 3)
+
+
+# ------------------------------------------------------------------------------------------ edge cases: empty inputs
+def test_empty_batches_behave_like_the_reference():
+    """Empty batches: the detector and the refine return empty results (the reference's loops simply do not run); the
+    uplift model raises (the reference fails on `mask.min()` of an empty tensor); too few frames for one triple raise."""
+    from upliftingtabletennis_amd import trajgen
+    net = wasb.WASBNet(weights.random_wasb_state_dict(1), resolution=(96, 64), max_batch=4, dtype='bf16')
+    heat, none = net(torch.zeros(0, 9, 64, 96))
+    assert heat.shape == (0, 1, 64, 96) and none is None
+    heat, idx, win = net.forward(torch.zeros(0, 9, 64, 96), want_peaks=True)
+    assert idx.shape == (0,) and win.shape == (0, 9)
+    with pytest.raises(ValueError):
+        net.forward_frames(torch.zeros(2, 70, 100, 3, dtype=torch.uint8).cuda())
+    assert refine.extract_position_ball(torch.zeros(0, 64, 96), 1920, 1080).shape == (0, 3)
+    assert refine.extract_position_table(torch.zeros(0, 13, 64, 96), 1920, 1080).shape == (0, 13, 3)
+    up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=weights.random_uplift_state_dict(0, 'large'), max_batch=4, max_len=16)
+    with pytest.raises(ValueError):
+        up(torch.zeros(0, 8, 2), torch.zeros(0, 13, 3), torch.zeros(0, 8), torch.zeros(0, 8))
+    res = trajgen.simulate_seeds([], 'intermediate', 'left_to_right')
+    assert res['n_keep'].shape == (0,) and res['samples'].shape[2] == 0

@@ -21,6 +21,8 @@ def refine_device(heatmaps, image_width, image_height, variant):
     out = torch.empty((n, 3), dtype=torch.float64, device=dev)
     idx = torch.empty((n,), dtype=torch.int64, device=dev)
     win = torch.empty((n, 9), dtype=torch.float32, device=dev)
+    if n == 0:              # nothing to refine (the reference's per-heatmap loop simply does not run)
+        return out, idx, win
     ws_bytes = lib.ttup_refine_workspace_bytes(n, h, w)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -33,6 +35,8 @@ def refine_windows_device(idx, win, h, w, image_width, image_height, variant):
     """Second half only (peaks already found by the CNN's fused epilogue)."""
     lib = _lib.load()
     out = torch.empty((idx.shape[0], 3), dtype=torch.float64, device=idx.device)
+    if idx.shape[0] == 0:
+        return out
     with torch.cuda.device(idx.device):
         _lib.check(lib.ttup_refine_windows(_lib.ptr(idx), _lib.ptr(win), idx.shape[0], h, w, int(image_width), int(image_height),
                                            variant, _lib.ptr(out), _lib.stream_ptr()))

@@ -73,6 +73,8 @@ def simulate_seeds(seeds, mode, direction, substeps=SUBSTEPS, device=None, want_
     device = torch.device(device if device is not None else 'cuda')
     sd = torch.as_tensor(np.asarray(seeds, dtype=np.int64), device=device)
     n = int(sd.numel())
+    if substeps < 1 or substeps > 64:
+        raise ValueError('substeps must be in [1, 64]')
     S = lib.ttup_trajgen_max_samples()
     samples = torch.zeros((S, 9, n), dtype=torch.float64, device=device)
     n_saved = torch.zeros((n,), dtype=torch.int32, device=device)
@@ -85,6 +87,8 @@ def simulate_seeds(seeds, mode, direction, substeps=SUBSTEPS, device=None, want_
     ex, mint = camera_matrices()
     cam = np.ascontiguousarray(np.concatenate([ex.reshape(-1), mint.reshape(-1)]), dtype=np.float64)
     m, d = MODES.index(mode), DIRECTIONS.index(direction)
+    if n == 0:              # no seeds: empty results
+        return {'samples': samples, 'n_saved': n_saved, 'n_keep': n_keep, 'bounces': bounces, 'n_bounces': n_bounces, 'init': init, 'seeds': sd}
     with torch.cuda.device(device):
         _lib.check(lib.ttup_trajgen_simulate(_lib.ptr(sd), n, m, d, int(substeps), cam.ctypes.data_as(ctypes.c_void_p), _lib.ptr(samples), _lib.ptr(n_saved),
                                              _lib.ptr(init), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))

@@ -41,6 +41,8 @@ class MultiStageModel:
         b, t, _ = ball.shape
         if table.shape != (b, 13, 3) or mask.shape != (b, t) or times.shape != (b, t):
             raise ValueError('inconsistent input shapes')
+        if b == 0 or t == 0:      # the reference fails on mask.min() of an empty tensor (model.py:541)
+            raise ValueError('empty batch: the uplift model needs at least one trajectory with one time step')
         rot = torch.empty((b, 3), dtype=torch.float32, device=self.device)
         pos = torch.empty((b, t, 3), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -52,6 +52,11 @@ class WASBNet:
             raise ValueError('expected input (B,%d,%d,%d), got %s' % (self.IN_CH, self.H, self.W, tuple(x.shape)))
         x = x.to(self.device, torch.float32).contiguous()
         b = x.shape[0]
+        if b == 0:          # empty batch: empty results, like the reference nn.Module
+            heat = torch.empty((0, self.OUT_CH, self.H, self.W), dtype=torch.float32, device=self.device) if want_heatmap else None
+            if want_peaks:
+                return heat, torch.empty((0,), dtype=torch.int64, device=self.device), torch.empty((0, 9), dtype=torch.float32, device=self.device)
+            return heat, None
         outs = []
         for b0 in range(0, b, self.max_batch):
             xb = x[b0:b0 + self.max_batch]
