@@ -75,7 +75,7 @@ class Pipeline:
         return self.worker.collect(ticket, self.table_px, self.fps)
 
 
-TRAFFIC_FILE = 'r1f_traffic.json'
+TRAFFIC_FILE = 'r1g_traffic.json'
 
 
 def roofline(pipe):
