@@ -1542,18 +1542,35 @@ __global__ void preprocess_kernel(PreArgs a) {
     float vals[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) vals[k] = 0.f;
+    // the three channel bytes of a source pixel come in one unaligned 4-byte load (the fourth byte is the next pixel's
+    // first channel); only the very last pixel of the clip falls back to byte loads so that nothing is read past the end
+    typedef unsigned int __attribute__((aligned(1))) u32_unaligned;
+    const size_t frame_bytes = (size_t)a.src_h * a.src_w * 3;
+    const uint8_t* clip_last = a.frames + (size_t)(a.first_triple + a.n_triples + a.nf - 1) * frame_bytes - 4;
+    auto load3 = [&](const uint8_t* q) -> unsigned {
+        if (q <= clip_last) return *(const u32_unaligned*)q;
+        return (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
+    };
     for (int f = 0; f < a.nf; ++f) {
-        const uint8_t* img = a.frames + (size_t)(a.first_triple + t + f) * a.src_h * a.src_w * 3;
+        const uint8_t* img = a.frames + (size_t)(a.first_triple + t + f) * frame_bytes;
+        if (same) {
+            const unsigned w = load3(img + ((size_t)y * a.src_w + x) * 3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vals[f * 3 + c] = a.lut[c * 256 + ((w >> (8 * c)) & 255)];
+            continue;
+        }
+        // a tap with weight 0 (equal widths: every second x tap; integer row positions) is not loaded: 0 * v adds nothing
+        const unsigned p00 = load3(img + ((size_t)y0 * a.src_w + x0) * 3);
+        const unsigned p01 = a1 ? load3(img + ((size_t)y0 * a.src_w + x1) * 3) : 0u;
+        const unsigned p10 = b1 ? load3(img + ((size_t)y1 * a.src_w + x0) * 3) : 0u;
+        const unsigned p11 = (a1 && b1) ? load3(img + ((size_t)y1 * a.src_w + x1) * 3) : 0u;
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            int v;
-            if (same) {
-                v = img[((size_t)y * a.src_w + x) * 3 + c];
-            } else {
-                const int top = img[((size_t)y0 * a.src_w + x0) * 3 + c] * a0 + img[((size_t)y0 * a.src_w + x1) * 3 + c] * a1;
-                const int bot = img[((size_t)y1 * a.src_w + x0) * 3 + c] * a0 + img[((size_t)y1 * a.src_w + x1) * 3 + c] * a1;
-                v = (((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2) >> 2;
-                v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            }
+            const int sh = 8 * c;
+            const int top = (int)((p00 >> sh) & 255) * a0 + (int)((p01 >> sh) & 255) * a1;
+            const int bot = (int)((p10 >> sh) & 255) * a0 + (int)((p11 >> sh) & 255) * a1;
+            int v = (((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
             vals[f * 3 + c] = a.lut[c * 256 + v];
         }
     }
