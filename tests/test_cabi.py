@@ -147,3 +147,35 @@ def test_calibrate_camera_and_reproject_match_reference(golden):
         assert np.median(err[vis]) < 2.0
     with pytest.raises(AssertionError):
         calib.calibrate_camera(np.concatenate([kp[:, :2], np.zeros((13, 1))], axis=1))       # fewer than 6 visible points
+
+
+# ------------------------------------------------------------------------------------------ a8: checkpoint ingestion
+def test_reference_format_checkpoints_are_ingested(tmp_path, monkeypatch):
+    """The reference saves {'model_state_dict', 'identifier', 'additional_info'} with torch.save (helper_balldetection.py
+    :510-529, uplifting/helper.py:371-391) and lays them out as inference_<task>/<model>/model.pt; the loaders read the
+    same layout from TTUP_WEIGHTS, pick resolution / size from additional_info, and the packed blobs are identical to the
+    ones packed from the in-memory state_dict.  A missing file under TTUP_WEIGHTS is an error, not a silent fallback."""
+    import torch
+    from upliftingtabletennis_amd import interface
+    ball = weights.random_wasb_state_dict(3)
+    table = weights.random_wasb_state_dict(4, in_ch=3, head_out=13)
+    up = weights.random_uplift_state_dict(5, 'large')
+    layout = {('inference_balldetection', 'wasb'): (ball, {'model_name': 'wasb', 'image_resolution': (1280, 704), 'in_frames': 3, 'lr': 1e-3}),
+              ('inference_tabledetection', 'hrnet'): (table, {'model_name': 'hrnet', 'image_resolution': (1280, 704)}),
+              ('inference_uplifting', 'ours'): (up, {'name': 'connectstage', 'size': 'large', 'tabletoken_mode': 'dynamic', 'time_rotation': 'new',
+                                                      'transform_mode': 'global', 'randdet_prob': 0.0, 'randmiss_prob': 0.0, 'tablemiss_prob': 0.0})}
+    for (task, name), (sd, info) in layout.items():
+        d = tmp_path / task / name
+        d.mkdir(parents=True)
+        torch.save({'model_state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, 'identifier': 'unit-test', 'additional_info': info}, str(d / 'model.pt'))
+    monkeypatch.setenv('TTUP_WEIGHTS', str(tmp_path))
+    sd, res, frames = interface._load_ball_checkpoint('wasb')
+    assert res == (1280, 704) and frames == 3
+    assert weights.pack_wasb_blob(sd) == weights.pack_wasb_blob(ball)
+    sd, res = interface._load_table_checkpoint('hrnet')
+    assert res == (1280, 704) and weights.pack_wasb_blob(sd, in_ch=3, head_out=13) == weights.pack_wasb_blob(table, in_ch=3, head_out=13)
+    sd, size, mode = interface._load_uplift_checkpoint()
+    assert (size, mode) == ('large', 'global') and weights.pack_uplift_blob(sd, 'large') == weights.pack_uplift_blob(up, 'large')
+    (tmp_path / 'inference_balldetection' / 'wasb' / 'model.pt').unlink()
+    with pytest.raises(RuntimeError):
+        interface._load_ball_checkpoint('wasb')
