@@ -24,12 +24,13 @@ print('total mean', (t[ok][:, 6] - t[ok][:, 0]).mean())
 rt = t[ok][:, 7]
 print('in-kernel shader clock: %.0f MHz (s_memtime span / s_memrealtime span x 100 MHz, median over workgroups)' % np.median((t[ok][:, 6] - t[ok][:, 0]) / np.maximum(rt, 1) * 100.0))
 
-buf2 = np.zeros(2 * 32 * 64 * 8, dtype=np.uint64)
+buf2 = np.zeros(3 * 32 * 64 * 8, dtype=np.uint64)
 lib.ttup_debug_read_timing_it(buf2.ctypes.data_as(ctypes.c_void_p), buf2.size)
-t2 = buf2.reshape(2, 32, 64, 8).astype(np.int64)
+t2 = buf2.reshape(3, 32, 64, 8).astype(np.int64)
 for kid, name, labels in ((0, 'stem', ['wait top barrier', 'X0 commit+barrier+issue', 'conv1', 'barrier', 'conv2', 'epilogue+follower+stores (to next top)']),
+                          (2, 'bb32 (last launch)', ['wait top barrier', 'commit+barrier+issue', 'conv1', 'barrier', 'conv2+epilogue (to next top)']),
                           (1, 'bneck', ['wait top barrier', 'phase 1', 'barrier', 'phase 2a', 'phase 2b', 'barrier', 'partials+barrier+reduce (to next top)'])):
-    x = t2[kid][:, 2:60]                    # skip warm-up iterations
+    x = t2[kid][:, 2:(60 if kid < 2 else 9)]                    # skip warm-up iterations (the 32-channel block has ~11 tiles per workgroup)
     ok2 = (x[..., 0] > 0) & (x[..., 1] > 0)
     n_slots = len(labels)
     print(name, 'tiles sampled', int(ok2.sum()))
@@ -38,7 +39,7 @@ for kid, name, labels in ((0, 'stem', ['wait top barrier', 'X0 commit+barrier+is
         if i + 1 < n_slots:
             d2 = (x[..., i + 1] - x[..., i])[ok2]
         else:                                # last slot: until the next iteration's slot 0
-            nxt = t2[kid][:, 3:61, 0]
+            nxt = t2[kid][:, 3:(61 if kid < 2 else 10), 0]
             d2 = (nxt - x[..., i])[ok2 & (nxt > 0)]
         tot += d2.mean()
         print('  %-42s mean %7.0f  p90 %7.0f' % (labels[i], d2.mean(), np.percentile(d2, 90)))

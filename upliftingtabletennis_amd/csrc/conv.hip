@@ -22,9 +22,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #ifdef TTUP_TIMING
 // debug build only (tools/build_ablate.sh TIMING): phase timestamps (s_memtime) of wave 0.
 //   TTUP_STAMP(k)        one-tile-per-workgroup kernels: slot k of workgroup blockIdx.x          (bb_chain2_kernel)
-//   TTUP_STAMP_IT(id,it,k) persistent kernels: kernel id (0 stem, 1 bneck), tile iteration it < 64 of workgroups < 32
+//   TTUP_STAMP_IT(id,it,k) persistent kernels: kernel id (0 stem, 1 bneck, 2 32-channel block), tile iteration it < 64 of workgroups < 32
 __device__ unsigned long long ttup_tbuf[8192 * 8];
-__device__ unsigned long long ttup_tbuf_it[2 * 32 * 64 * 8];
+__device__ unsigned long long ttup_tbuf_it[3 * 32 * 64 * 8];
 #define TTUP_STAMP(k) do { if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TTUP_STAMP_IT(id, it, k) do { if (tid == 0 && blockIdx.x < 32 && (it) < 64) ttup_tbuf_it[(((id) * 32 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1035,7 +1035,9 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+        if (C == 32) TTUP_STAMP_IT(2, it, 0);
         __syncthreads();                       // previous tile fully consumed (resident weights visible on the first pass)
+        if (C == 32) TTUP_STAMP_IT(2, it, 1);
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
             const int u = tid + k * 512;
@@ -1044,12 +1046,15 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         if (!WGLOBAL && !RESIDENT) store_wt(0);
         __syncthreads();
         if (it + 1 < my_tiles) issue_in(it + 1);
+        if (C == 32) TTUP_STAMP_IT(2, it, 2);
         if (!WGLOBAL && !RESIDENT) load_wt(1);
         const bf16_t* w0 = WGLOBAL ? a.w[0] : s_wt;
         const bf16_t* w1 = WGLOBAL ? a.w[1] : (RESIDENT ? s_wt + W_UNITS * 8 : s_wt);
         if (NB == 1) {
             bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+            if (C == 32) TTUP_STAMP_IT(2, it, 3);
             __syncthreads();
+            if (C == 32) TTUP_STAMP_IT(2, it, 4);
             if (!WGLOBAL && !RESIDENT) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
             bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane, a.wf, a.bf, a.yf);
         } else {
