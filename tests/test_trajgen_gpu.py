@@ -94,6 +94,26 @@ def test_device_pipeline_reproduces_reference_worker_decisions(golden):
     assert accepted >= 50
 
 
+def test_device_decisions_for_every_mode(golden):
+    """Seeds accepted in each of the six modes (found by a device search) and their neighbours: the device's accept / reject
+    decisions, kept lengths and bounce times equal the reference worker's (run on the oracle integrator)."""
+    g = golden('trajgen.npz')
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS:
+            key = 'rare/%s/%s' % (mode, direction)
+            seeds = g[key + '/all_seeds']
+            res = trajgen.simulate_seeds(seeds, mode, direction)
+            nk = res['n_keep'].cpu().numpy()
+            sel = np.nonzero(nk)[0]
+            assert np.array_equal(seeds[sel], g[key + '/seeds']), (mode, direction)
+            assert np.array_equal(nk[sel], g[key + '/n'])
+            nb = res['n_bounces'].cpu().numpy()[sel]
+            assert np.array_equal(nb, g[key + '/n_bounces'])
+            bo = res['bounces'].cpu().numpy()[sel]
+            assert np.array_equal(np.concatenate([bo[i, :nb[i]] for i in range(len(sel))]), g[key + '/bounces'])
+            assert len(sel) >= 4
+
+
 def test_get_valid_trajectories_mirrors_reference_api(tmp_path):
     """Pool ordering, truncation, dictionary keys, save_dataset layout; contents against the oracle's `generate`."""
     got = trajgen.get_valid_trajectories(6, 4, 'final_lose', 'left_to_right', batches_per_launch=3)

@@ -113,3 +113,24 @@ def test_bounce_is_dissipative_and_spin_couples_through_friction():
 def test_seed_order_is_the_pool_round_robin():
     assert T.seed_order(0, 8, 3) == [0, 3, 6, 1, 4, 7, 2, 5]
     assert T.seed_order(1024, 4, 128)[:4] == [1024, 1025, 1026, 1027]
+
+
+def test_every_mode_is_accepted_and_rejected_like_the_reference_worker(golden):
+    """Seeds that pass each of the six modes (and their mostly rejected neighbours): oracle sampling loop + selection against
+    the reference worker's decisions, kept lengths and bounce times (every mode's cut / count branch is taken)."""
+    g = golden('trajgen.npz')
+    times = T.save_times()
+    for mode in T.MODES:
+        for direction in T.DIRECTIONS[:1]:            # one direction per mode keeps the CPU suite short; the GPU test does both
+            key = 'rare/%s/%s' % (mode, direction)
+            seeds = [int(s) for s in g[key + '/all_seeds']]
+            pos, vel, rot, ns = T.simulate(seeds, mode, direction)
+            got_s, got_n, got_b = [], [], []
+            for i, s in enumerate(seeds):
+                res = T.select(pos[i, :ns[i]], times, mode, direction)
+                if res is not None:
+                    got_s.append(s); got_n.append(res[0]); got_b.append(res[1])
+            assert got_s == [int(s) for s in g[key + '/seeds']], (mode, got_s)
+            assert got_n == [int(n) for n in g[key + '/n']]
+            assert np.array_equal(np.concatenate(got_b), g[key + '/bounces'])
+            assert [len(b) for b in got_b] == [int(n) for n in g[key + '/n_bounces']] and len(got_s) >= 4

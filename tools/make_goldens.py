@@ -437,6 +437,34 @@ def gen_trajgen():
                     hit_cases.append((direction, keep, ho, hw, hg))
                     picked += i != 0
             print('trajgen %s/%s: %d of %d seeds accepted (%.0f s)' % (mode, direction, len(res), len(seeds), time.time() - t0))
+    # ---- seeds that the device generator accepts for every mode (found with a device search over the first ~20 000 seeds):
+    # the reference worker, again on the oracle integrator, exercises every mode's acceptance and cut branch
+    RARE = {"final_lose/left_to_right": [162, 166, 167, 170], "final_lose/right_to_left": [162, 167, 169, 170],
+            "final_win/left_to_right": [9366, 9807, 10696, 11390], "final_win/right_to_left": [1417, 3309, 6651, 6948],
+            "intermediate/left_to_right": [190, 203, 242, 296], "intermediate/right_to_left": [190, 193, 242, 251],
+            "first_good/left_to_right": [290, 341, 484, 625], "first_good/right_to_left": [417, 823, 955, 1121],
+            "first_short/left_to_right": [1218, 2194, 3239, 5097], "first_short/right_to_left": [592, 760, 1012, 2008],
+            "first_long/left_to_right": [268, 318, 479, 686], "first_long/right_to_left": [246, 490, 494, 540]}
+    for cfg, seeds in RARE.items():
+        mode, direction = cfg.split('/')
+        seeds = seeds + [s + 1 for s in seeds]            # the neighbours are (mostly) rejected: both outcomes per mode
+        st = [T.init_state(sd, mode, direction) for sd in seeds]
+        r = np.stack([a[0] for a in st]); v = np.stack([a[1] for a in st]); w = np.stack([a[2] for a in st])
+        hist = np.zeros((len(seeds), 1001, 9))
+        hist[:, 0] = np.concatenate([r, v, w], axis=1)
+        for k in range(1, 1001):
+            r, v, w = T.step_ms(r, v, w, 1)
+            hist[:, k] = np.concatenate([r, v, w], axis=1)
+        for i in range(len(seeds)):
+            history[(hist[i, 0, :3].tobytes(), hist[i, 0, 3:9].tobytes())] = hist[i]
+        res = ms.find_valid_trajectories_worker((seeds, mode, direction))
+        key = 'rare/%s/%s' % (mode, direction)
+        out[key + '/all_seeds'] = np.array(seeds, dtype=np.int64)
+        out[key + '/seeds'] = np.array([t['seed'] for t in res], dtype=np.int64)
+        out[key + '/n'] = np.array([len(t['positions']) for t in res], dtype=np.int64)
+        out[key + '/bounces'] = np.concatenate([t['bounces'] for t in res]) if res else np.zeros(0)
+        out[key + '/n_bounces'] = np.array([len(t['bounces']) for t in res], dtype=np.int64)
+        print('trajgen rare %s: %d of %d accepted (%.0f s)' % (cfg, len(res), len(seeds), time.time() - t0))
     out['hits/n'] = np.array([len(hit_cases)])
     for j, (direction, track, ho, hw, hg) in enumerate(hit_cases):
         out['hits/%d/direction' % j] = np.array([T.DIRECTIONS.index(direction)])
