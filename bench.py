@@ -163,13 +163,22 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (there is no CPU fallback); the CPU oracle is only the baseline leg')
+    # TTUP_BENCH_SHARE_GPU=1 + TTUP_DIST_BACKEND=gloo: dry run of the multi-rank flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather goes through the host); the measured configuration is one rank per GPU over RCCL
+    share = os.environ.get('TTUP_BENCH_SHARE_GPU') == '1'
+    backend = os.environ.get('TTUP_DIST_BACKEND', 'nccl')
+    if share:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     pipe = Pipeline(device, seed=rank)
     for _ in range(a.warmup):
         pipe.step()
@@ -197,7 +206,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     frames = TRIPLES * a.steps * world

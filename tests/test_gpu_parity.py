@@ -392,3 +392,21 @@ def test_empty_batches_behave_like_the_reference():
         up(torch.zeros(0, 8, 2), torch.zeros(0, 13, 3), torch.zeros(0, 8), torch.zeros(0, 8))
     res = trajgen.simulate_seeds([], 'intermediate', 'left_to_right')
     assert res['n_keep'].shape == (0,) and res['samples'].shape[2] == 0
+
+
+def test_bench_two_rank_flow_on_one_gpu():
+    """bench.py's multi-rank path (init, per-rank pipelines, per-step gather, barrier + max-over-ranks timing, rank-0 line)
+    as a dry run: two ranks share this box's GPU and gather through gloo (the measured configuration is one rank per GPU
+    over RCCL; only the collective backend differs)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TTUP_BENCH_SHARE_GPU='1', TTUP_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29533',
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-roofline', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert abs(rec['value'] - 2 * 256 * 2 / (rec['ms_per_step'] * 2 / 1e3)) / rec['value'] < 1e-3

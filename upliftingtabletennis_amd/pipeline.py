@@ -38,8 +38,11 @@ def gather_records(records, dist=None, dst=0):
         return {k: [v] for k, v in records.items()}
     world, rank = dist.get_world_size(), dist.get_rank()
     out = {} if rank == dst else None
+    on_host = dist.get_backend() == 'gloo'        # gloo (CPU tests, single-GPU dry runs) gathers on the host; nccl = RCCL on device
     for k in sorted(records):
         v = records[k].contiguous()
+        if on_host:
+            v = v.cpu()
         n = torch.tensor([v.shape[0]], dtype=torch.int64, device=v.device)
         sizes = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(sizes, n)
