@@ -27,3 +27,12 @@ for it in range(3):
     rot, p3 = w.up(torch.cat(balls), torch.cat(tables), mask, torch.cat(times)); sync(); t5 = time.perf_counter()
     spin = w._uplift.transform_rotationaxes(rot, p3); sync(); t6 = time.perf_counter()
     print('cnn %.2f ms  fit %.2f  d2h %.2f  glue %.2f  uplift %.2f  axes %.2f  total %.2f' % tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t6 - t0)))
+# PCIe-inclusive note for DESIGN.md: host -> device copy of the 258-frame uint8 clip (pinned and pageable)
+host = frames.cpu()
+pinned = host.pin_memory()
+for name, src in (('pinned', pinned), ('pageable', host)):
+    sync(); t0 = time.perf_counter()
+    for _ in range(3):
+        d = src.to(dev, non_blocking=True); sync()
+    dt = (time.perf_counter() - t0) / 3
+    print('H2D %s: %.1f MB in %.2f ms -> %.1f GB/s' % (name, src.numel() / 1e6, dt * 1e3, src.numel() / dt / 1e9))
