@@ -327,6 +327,20 @@ def test_table_hrnet_matches_reference(golden, name):
     assert np.median(hm) < 1e-5 and hm.max() < 0.6
 
 
+def test_ball_detector_clip_path_equals_triple_path():
+    """`predict_clip` (frames uploaded once, fused pre-processing / CNN / argmax / windows) returns the positions `predict`
+    returns for the (prev, curr, next) triples the reference builds; the planted weights give an unambiguous peak."""
+    from upliftingtabletennis_amd import interface
+    det = interface.BallDetector('wasb', max_batch=4)          # 7 triples over max_batch 4: exercises the 2-frame overlap
+    frames, _ = synth.synth_frames(9, 720, 1280, seed=5)
+    images = [f for f in frames]
+    pos_t, preds = det.predict([(images[i - 1], images[i], images[i + 1]) for i in range(1, len(images) - 1)])
+    pos_c = det.predict_clip(images)
+    assert pos_c.shape == pos_t.shape == (7, 3) and preds.shape[0] == 7
+    assert np.abs(pos_c - pos_t).max() < 0.05, np.abs(pos_c - pos_t).max()
+    assert det.predict_clip(images[:2]).shape == (0, 3)
+
+
 def test_table_detector_and_full_pipeline_surface():
     from upliftingtabletennis_amd.interface import TableDetector, TableTennisPipeline
     frames, track = synth.synth_frames(8, 720, 1280, seed=4)

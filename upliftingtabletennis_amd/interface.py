@@ -85,6 +85,23 @@ class BallDetector:
             return np.zeros((0, 3)), np.zeros((0, 1, h, w), np.float32)
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
+    def predict_clip(self, images):
+        """Fast path for consecutive frames (what TableTennisPipeline.predict feeds the detector, interface.py:276-279):
+        images = list of N BGR uint8 HWC frames -> pred_pos (N-2, 3), the same values `predict` returns for the triples
+        (images[i-1], images[i], images[i+1]).  Every frame is uploaded once and pre-processing, CNN, argmax and window
+        extraction run fused on the device; no heatmap is written."""
+        n = len(images)
+        if n < 3:
+            return np.zeros((0, 3))
+        w, h = self.model_resolution
+        out = []
+        step = self.max_batch                      # triples per call; consecutive calls overlap by two frames
+        for t0 in range(0, n - 2, step):
+            fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[t0:t0 + step + 2]])).to(self.device)
+            _, idx, win = self.model.forward_frames(fr, want_heatmap=False)
+            out.append(refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE).cpu().numpy())
+        return np.concatenate(out, axis=0)
+
     def filter_trajectory(self, ball_positions, ball_positions_aux, fps):
         return glue.filter_trajectory_ball(ball_positions, ball_positions_aux, fps)
 
@@ -193,9 +210,10 @@ class TableTennisPipeline:
             kp, _ = self.table_detector.predict(images)
             kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict(images)[0]
             table_keypoints = self.table_detector_aux.filter_trajectory(kp, kp_aux)
-        image_triples = [(images[i - 1], images[i], images[i + 1]) for i in range(1, len(images) - 1)]
-        ball_positions, _ = self.ball_detector.predict(image_triples)
-        ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict(image_triples)[0]
+        # the reference builds (prev, curr, next) triples and pushes each through the detector (interface.py:276-279);
+        # the triples are consecutive frames, so the clip path computes the same positions with every frame uploaded once
+        ball_positions = self.ball_detector.predict_clip(images)
+        ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict_clip(images)
         filtered, _, times_ball = self.ball_detector.filter_trajectory(ball_positions, ball_positions_aux, fps)
         ball_coords, table_coords, times, mask = glue._uplifting_transform(filtered, np.asarray(table_keypoints, dtype=np.float64), times_ball)
         return self.uplifting_model.predict_without_normalization(ball_coords, table_coords, mask, times)
