@@ -350,6 +350,11 @@ def test_table_detector_and_full_pipeline_surface():
     assert (pos[..., 2] == 1).all()
     filt = det.filter_trajectory(pos, pos)
     assert filt.shape == (13, 3)
+    # keypoints-only path (no heatmaps to the host): same peaks through the fused argmax; random weights give noise-like maps
+    # whose near-ties may resolve differently between the fused bf16 epilogue and the stored fp32 heatmap, so compare loosely
+    kp = det.predict_keypoints(list(frames[:5]))
+    assert kp.shape == (5, 13, 3) and (kp[..., 2] == 1).all()
+    assert (np.abs(kp[..., :2] - pos[..., :2]).max(axis=-1) < 0.05).mean() >= 0.8
     with pytest.raises(NotImplementedError):
         TableDetector('segformerpp_b2')
     pipe = TableTennisPipeline(max_batch=8)

@@ -144,6 +144,18 @@ class TableDetector:
             return np.zeros((0, 13, 3)), np.zeros((0, 13, h, w), np.float32)
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
+    def predict_keypoints(self, images):
+        """`predict` without the heatmaps: (B,13,3) keypoints only.  Pre-processing, CNN, per-channel argmax and windows run
+        fused on the device; nothing but the 39 numbers per frame comes back to the host."""
+        w, h = self.model_resolution
+        out = []
+        for b0 in range(0, len(images), self.max_batch):
+            fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[b0:b0 + self.max_batch]])).to(self.device)
+            _, idx, win = self.model.forward_frames(fr, want_heatmap=False)
+            pos = refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
+            out.append(pos.cpu().numpy().reshape(-1, 13, 3))
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 13, 3))
+
     def calibrate_camera(self, keypoints):
         """interface.py:174-175: (13,3) keypoints -> (Mint, Mext); host numpy/SciPy like the reference (calib.py)."""
         return calib.calibrate_camera(keypoints)
@@ -207,8 +219,8 @@ class TableTennisPipeline:
         (optional override; by default they are detected with the in-tree HRNet like interface.py:281-283).
         Returns (pred_spin torch (3,), pred_pos_3d numpy (T',3))."""
         if table_keypoints is None:        # 2. table detection (interface.py:281-283)
-            kp, _ = self.table_detector.predict(images)
-            kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict(images)[0]
+            kp = self.table_detector.predict_keypoints(images)
+            kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict_keypoints(images)
             table_keypoints = self.table_detector_aux.filter_trajectory(kp, kp_aux)
         # the reference builds (prev, curr, next) triples and pushes each through the detector (interface.py:276-279);
         # the triples are consecutive frames, so the clip path computes the same positions with every frame uploaded once
