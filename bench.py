@@ -8,16 +8,23 @@ A step = one pass of the hot path over one stream batch that is already resident
   258 uint8 frames (1280x720x3)  -> 256 triples -> fused pre-processing (cv2-style resize to 1280x704 +
   normalise) -> WASB/HRNet CNN (bf16 MFMA) -> heatmap argmax + 3x3 window -> L-BFGS-B Gaussian refine
   (table variant, as on the hub surface) -> two-detector filter + uplift transform on the host (as in the
-  reference) -> uplift transformer on 8 trajectories of 32 detections (padded to 50) -> spin frame change.
+  reference) -> uplift transformer on the clip cut into 120-step trajectories (120 + 120 + 16 detections, padded to
+  121 tokens: north_star's "120-step trajectories") -> spin frame change.
+`--gpus N` without a torch.distributed environment starts the N ranks itself (a `torch.distributed.run` child process,
+before this process touches the GPU) and relays rank 0's line; under `torch.distributed.run` it is one of the ranks.
 Every rank processes its own stream (independent units); the only collective is the final gather of
 the per-frame (x,y,v) records and the per-trajectory (spin, positions) records.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant CNN kernel,
-HIP-event timed inside this process) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the CNN kernel with the largest total
+time per micro-batch, HIP-event timed inside this process in graph order), `cpu_baseline` (the CPU oracle timed on a
+bounded sample) and, at N=1, the driver-timed extras for BASELINE configs 2, 3 and 5 (`cnn_only_fps`,
+`uplift_only_traj_s`, `trajgen_traj_s`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,8 +37,10 @@ sys.path.insert(0, ROOT)
 H_SRC, W_SRC = 720, 1280
 W_NET, H_NET = 1280, 704
 TRIPLES = int(os.environ.get('TTUP_BENCH_TRIPLES', '256'))
-TRAJ_LEN = 32
+TRAJ_LEN = 120                 # detections per trajectory (north_star: 120-step trajectories)
+SEQ_LEN = TRAJ_LEN + 1          # tokens: the uplift net needs at least one padded slot (uplifting/model.py:541-546)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+SUSTAINED_BF16_TFLOPS = 1650.0 # the same pipes at the 1.57 GHz this workload sustains (tools/phase_timing.py)
 PEAK_HBM_GBS = 8000.0
 GFLOP_PER_FRAME_EXECUTED = 331.3   # 344.07 minus the elided stage-4 fuse outputs 1..3
 
@@ -43,6 +52,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the config 2/3/5 legs (cnn-only, uplift-only, generator)')
     return ap.parse_args()
 
 
@@ -52,10 +62,10 @@ class Pipeline:
     def __init__(self, device, seed):
         from upliftingtabletennis_amd import pipeline, synth, weights
         self.worker = pipeline.StreamWorker(device, weights.random_wasb_state_dict(0, planted=True), weights.random_uplift_state_dict(0, 'large'),
-                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=50)
+                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=SEQ_LEN)
         self.net = self.worker.net
         # synthetic clip: 34 distinct frames tiled to TRIPLES+2 (keeps generation time low; content still varies per frame)
-        base, track = synth.synth_frames(TRAJ_LEN + 2, H_SRC, W_SRC, seed=seed)
+        base, track = synth.synth_frames(34, H_SRC, W_SRC, seed=seed)
         reps = (TRIPLES + 2 + len(base) - 1) // len(base)
         clip = np.concatenate([base] * reps)[:TRIPLES + 2]
         self.frames = torch.from_numpy(clip).to(device)
@@ -75,38 +85,51 @@ class Pipeline:
         return self.worker.collect(ticket, self.table_px, self.fps)
 
 
-TRAFFIC_FILE = 'r1g_traffic.json'
+TRAFFIC_FILE = 'r2_traffic.json'      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round (tools/pmc_traffic.py)
+
+
+def _traffic(kernel_base):
+    """HBM bytes per launch of a kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    runs; MI355X_MICROARCH.md, HBM).  None when the profile does not hold the kernel."""
+    try:
+        for e in json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE))):
+            if kernel_base in e['kernel']:
+                return e['hbm_bytes']
+    except Exception:
+        pass
+    return None
 
 
 def roofline(pipe):
-    """Per-op HIP-event timing of the CNN inside the library; dominant op -> roofline object."""
+    """HIP-event timing of the CNN graph inside the library, in launch order (one micro-batch, the stream the kernels
+    run on).  Ops are grouped by the kernel they launch; the kernel with the largest TOTAL time is the dominant one:
+    achieved = its algorithmic FLOP per launch / its average launch duration."""
     from upliftingtabletennis_amd import wasb
-    ops = wasb.time_ops(pipe.net, reps=5)
-    conv = [o for o in ops if o['kind'] != 'upsum']
-    dom = max(conv, key=lambda o: o['ms'])
+    ops = wasb.time_ops(pipe.net, reps=5, in_graph=True)
+    groups = {}
+    for o in ops:
+        g = groups.setdefault(o['kernel'], {'kernel': o['kernel'], 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'shape': (o['h'], o['w'])})
+        g['launches'] += 1; g['ms'] += o['ms']; g['flops'] += o['flops']
+    table = sorted(groups.values(), key=lambda g: -g['ms'])
     tot_ms = sum(o['ms'] for o in ops)
-    tot_fl = sum(o['flops'] for o in conv)
+    tot_fl = sum(o['flops'] for o in ops)
+    dom = next(g for g in table if g['flops'] > 0)          # the element-wise sums are HBM-bound and never the largest
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+    base = dom['kernel'].split('<')[0]
     r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-         'kernel': ('stem_kernel (3x3 9->64 + 3x3 64->64 + 1x1 64->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'stem' else ('bneck_trans_kernel (1x1 96->128 + 3x3 128->16 + 3x3/s2 128->32) @%dx%d (op %d)' % (dom['h'], dom['w'], dom['index'])) if dom['kind'] == 'bneck_trans' else
-                   'conv_mfma_kernel %dx%d k%d s%d @%dx%d (op %d)' % (dom['cin'], dom['cout'], dom['k'], dom['stride'], dom['h'], dom['w'], dom['index']),
-         'launch_ms': round(dom['ms'], 4), 'micro_batch': dom['batch'],
+         'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': _traffic(base),
+         'peak_sustained': SUSTAINED_BF16_TFLOPS, 'frac_sustained': round(achieved / SUSTAINED_BF16_TFLOPS, 4),
+         'kernel': '%s @%dx%d: %d launches per micro-batch of %d frames, dominant by total time (%.3f of %.3f ms)'
+                   % (dom['kernel'], dom['shape'][0], dom['shape'][1], dom['launches'], ops[0]['batch'], dom['ms'], tot_ms),
+         'launch_ms': round(dom['ms'] / dom['launches'], 4), 'launches': dom['launches'], 'micro_batch': ops[0]['batch'],
+         'algorithmic_gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 2),
+         'timing': 'hipEvent between consecutive ops of the graph in launch order (ttup_wasb_time_graph), 5 passes',
+         'per_kernel': [{'kernel': g['kernel'], 'launches': g['launches'], 'ms': round(g['ms'], 4),
+                         'tflops': round(g['flops'] / (g['ms'] * 1e-3) / 1e12, 1) if g['flops'] else None} for g in table],
          'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                          'frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
-    # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-    # runs, gfx950 correction; tools/pmc_traffic.py).  Only attached when kernel and launch geometry match.
-    try:
-        key = 'stem_kernel' if dom['kind'] == 'stem' else 'bneck_trans_kernel' if dom['kind'] == 'bneck_trans' else None
-        # the persistent fused kernels launch one grid per micro-batch; the PMC passes (tools/prof_cnn.py) ran the same
-        # micro-batch of 8 triples at 1280x704, so the entry is matched by kernel name and micro-batch
-        for e in json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE))):
-            if key and key in e['kernel'] and dom['batch'] == 8 and (dom['h'], dom['w']) == (H_NET, W_NET):
-                r['traffic'] = e['hbm_bytes']
-                r['traffic_note'] = 'bytes per launch from profiles/%s (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)' % TRAFFIC_FILE
-                break
-    except Exception:
-        pass
+    if r['traffic'] is not None:
+        r['traffic_note'] = 'bytes per launch from profiles/%s (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)' % TRAFFIC_FILE
     return r, ops
 
 
@@ -132,46 +155,144 @@ def heatmap_roofline(device):
     ms = e0.elapsed_time(e1) / reps
     gbs = n * H_NET * W_NET * 4 / (ms * 1e-3) / 1e9
     return {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-            'traffic': None, 'kernel': 'argmax_partial_kernel + argmax_finish_kernel', 'launch_ms': round(ms, 4), 'heatmaps': n}
+            'traffic': _traffic('argmax_partial_kernel'), 'kernel': 'argmax_partial_kernel + argmax_finish_kernel', 'launch_ms': round(ms, 4), 'heatmaps': n,
+            'algorithmic_bytes_per_launch': n * H_NET * W_NET * 4}
 
 
 def cpu_baseline():
-    """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload: 2 triples through
-    the CNN + refine, one 32-point trajectory through the uplift net."""
+    """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload: 4 triples through
+    resize + normalise + CNN + refine, one 120-point trajectory through the uplift net (about 15-30 s of CPU work)."""
     from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
     from upliftingtabletennis_amd import synth, weights
-    n = 2
+    n = 4
     frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
     sd = weights.random_wasb_state_dict(0, planted=True)
     usd = weights.random_uplift_state_dict(0, 'large')
     t0 = time.time()
-    x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
-    heat = wasb_ref.wasb_forward(x, sd).numpy()
-    pos = refine_ref.extract_position_table(heat, 1920, 1080)[:, 0]
-    ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=50 - TRAJ_LEN)
+    for i in range(n):          # batch 1 per triple, like interface.py:102-119
+        x = glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET))[None]
+        heat = wasb_ref.wasb_forward(x, sd).numpy()
+        refine_ref.extract_position_table(heat, 1920, 1080)
+    ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=1)
     rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
     uplift_ref.transform_rotationaxes(rot, p3)
     dt = time.time() - t0
     return {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d triples 1280x720 (resize+normalise, CNN fp32, refine) + 1 trajectory of %d points; %.1f s' % (n, TRAJ_LEN, dt)}
+            'sample': '%d triples 1280x720, batch 1 (resize+normalise, CNN fp32, refine) + 1 trajectory of %d points; %.1f s' % (n, TRAJ_LEN, dt)}
+
+
+def extras(device):
+    """Driver-timed legs for the other BASELINE configs (N=1 only): CNN only (config 2), uplift only (config 3),
+    trajectory generator (config 5), and the RK4 + Gauss-Newton fit named by north_star (extension)."""
+    from upliftingtabletennis_amd import synth, uplift, wasb, weights
+    out = {}
+    # config 2: ball-detection CNN only, bf16, batch 256 (pre-processing, CNN, fused argmax + window; no refine / uplift)
+    base, _ = synth.synth_frames(34, H_SRC, W_SRC, seed=1)
+    clip = torch.from_numpy(np.concatenate([base] * 8)[:258]).to(device)
+    net = wasb.WASBNet(weights.random_wasb_state_dict(0, planted=True), resolution=(W_NET, H_NET), max_batch=256, dtype='bf16', device=device)
+    net.forward_frames(clip)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        net.forward_frames(clip)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    out['cnn_only_fps'] = {'value': round(256 / dt, 1), 'unit': 'frames/s', 'config': 'BASELINE config 2: CNN only, bf16, batch 256 x 1280x720',
+                           'ms_per_batch': round(dt * 1e3, 3), 'tflops': round(256 / dt * GFLOP_PER_FRAME_EXECUTED / 1e3, 1)}
+    del net, clip
+    # config 3: uplift only, 10 000 trajectories x 120 steps (+1 padded token)
+    B, T = 10000, 120
+    arrs = [torch.from_numpy(a).to(device) for a in synth.synth_trajectories(2000, T, seed=0, pad=1)]
+    ball, table, mask, times = [a.repeat((5,) + (1,) * (a.dim() - 1)).contiguous() for a in arrs]
+    up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=weights.random_uplift_state_dict(0, 'large'), max_batch=B, max_len=T + 1, device=device)
+    up(ball[:64], table[:64], mask[:64], times[:64])
+    up(ball, table, mask, times)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    up(ball, table, mask, times)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['uplift_only_traj_s'] = {'value': round(B / dt, 1), 'unit': 'trajectories/s', 'config': 'BASELINE config 3: uplift transformer (the reference\'s uplift), B=10000, T=120',
+                                 'seconds': round(dt, 4), 'tflops_fp32': round(B * 2.0 / dt / 1e3, 1)}
+    del up
+    try:
+        from upliftingtabletennis_amd import odefit
+        out['odefit_traj_s'] = odefit.bench(device, B, T)
+    except ImportError:
+        pass
+    # config 5: 125 000 accepted drag+Magnus trajectories in the reference's output format
+    from upliftingtabletennis_amd import trajgen
+    trajgen.simulate_seeds(list(range(1024)), 'final_lose', 'left_to_right')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = trajgen.simulate_seeds(np.arange(262144), 'final_lose', 'left_to_right')
+    torch.cuda.synchronize()
+    dt_dev = time.perf_counter() - t0
+    acc = int((res['n_keep'] > 0).sum().item())
+    del res
+    t0 = time.perf_counter()
+    tr = trajgen.get_valid_trajectories(125000, 128, 'final_lose', 'left_to_right', batches_per_launch=128)
+    dt = time.perf_counter() - t0
+    out['trajgen_traj_s'] = {'value': round(len(tr) / dt, 1), 'unit': 'trajectories/s', 'seconds': round(dt, 3),
+                             'config': 'BASELINE config 5: 125000 accepted final_lose trajectories, device RK4 + selection, reference-format dicts on the host',
+                             'device_seeds_s': round(262144 / dt_dev, 1), 'device_accepted_traj_s': round(acc / dt_dev, 1)}
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torch.distributed: start the N ranks as a child `torch.distributed.run`
+    (this process has not touched the GPU: no torch.cuda.is_available(), no HIP call) and relay rank 0's JSON line."""
+    n_dev = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if n_dev < a.gpus and os.environ.get('TTUP_BENCH_SHARE_GPU') != '1':
+        print('bench.py: --gpus %d but only %d device(s) visible (TTUP_BENCH_SHARE_GPU=1 TTUP_DIST_BACKEND=gloo runs a dry run '
+              'of the multi-rank flow on fewer devices)' % (a.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), '--gpus', str(a.gpus), '--steps', str(a.steps), '--warmup', str(a.warmup)]
+    cmd += ['--no-cpu-baseline'] * a.no_cpu_baseline + ['--no-roofline'] * a.no_roofline + ['--no-extras'] * a.no_extras
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        print('bench.py: the %d-rank run failed (exit code %d)' % (a.gpus, r.returncode), file=sys.stderr)
+        return r.returncode or 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
     a = parse()
+    share = os.environ.get('TTUP_BENCH_SHARE_GPU') == '1'
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (there is no CPU fallback); the CPU oracle is only the baseline leg')
     # TTUP_BENCH_SHARE_GPU=1 + TTUP_DIST_BACKEND=gloo: dry run of the multi-rank flow on a box with fewer GPUs than ranks
     # (ranks share devices, the gather goes through the host); the measured configuration is one rank per GPU over RCCL
-    share = os.environ.get('TTUP_BENCH_SHARE_GPU') == '1'
     backend = os.environ.get('TTUP_DIST_BACKEND', 'nccl')
     if share:
         local = local % torch.cuda.device_count()
+    elif local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
+    collective = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -179,6 +300,12 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # prove the collective backend sees every rank: a sum of ones over device tensors (RCCL) must equal the world size
+        ones = torch.ones(1, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones)
+        collective = {'backend': dist.get_backend(), 'ranks': int(ones.item()), 'world_size': dist.get_world_size()}
+        if collective['ranks'] != world:
+            raise SystemExit('bench.py: all_reduce saw %d of %d ranks' % (collective['ranks'], world))
     pipe = Pipeline(device, seed=rank)
     for _ in range(a.warmup):
         pipe.step()
@@ -214,9 +341,12 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'full detect->uplift pipeline: %d triples of 1280x720 uint8 frames per step per GPU (WASB/HRNet @1280x704, '
-                                   'table-variant refine), %d trajectories x %d detections through the uplift transformer; random-init weights'
-                                   % (TRIPLES, TRIPLES // TRAJ_LEN, TRAJ_LEN),
+                                   'table-variant refine), cut into %d trajectories of up to %d detections (%d tokens) through the uplift transformer; '
+                                   'random-init weights' % (TRIPLES, (TRIPLES + TRAJ_LEN - 1) // TRAJ_LEN, TRAJ_LEN, SEQ_LEN),
                        'frames_per_step_per_gpu': TRIPLES, 'parallelism': 'stream-per-gpu x%d, final gather' % world}}
+    if collective is not None:
+        line['rccl_ranks'] = collective['ranks'] if collective['backend'] == 'nccl' else 0
+        line['collective'] = collective
     if rank == 0:
         if not a.no_roofline:
             r, ops = roofline(pipe)
@@ -227,6 +357,10 @@ def main():
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', 'bench_ops.json'), 'w') as f:
                 json.dump(ops, f, indent=1)
+        if not a.no_extras and world == 1:
+            del pipe
+            torch.cuda.empty_cache()
+            line.update(extras(device))
         if not a.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -102,8 +102,12 @@ int ttup_wasb_forward_frames(ttup_wasb* net, const uint8_t* frames_dev, int n_fr
  * "stage4_0") of the last forward as float32 NCHW into out_dev; *c,*h,*w receive its shape. */
 int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_dev, int* c, int* h, int* w, void* stream);
 
-/* measurement aid (bench.py): per-op timing of the CNN graph with HIP events on `stream`; see csrc/wasb_net.hip */
+/* measurement aids (bench.py), HIP events on `stream`; see csrc/wasb_net.hip.  time_ops: every op on its own (warm inputs);
+ * time_graph: the whole graph in launch order with an event between consecutive ops (the cache state the forward pass sees),
+ * names_out = max_ops x 64 chars receiving the HIP kernel name of each op (nullable). */
 int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
+int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, char* names_out,
+                         int* n_ops_out, void* stream);
 /* micro-batch the handle was created with (TTUP_MICRO_BATCH) */
 int ttup_wasb_micro_batch(ttup_wasb* net);
 /* heatmap channels per sample returned by forward: 1 (ball) or 13 (table) */

@@ -54,6 +54,52 @@ def test_no_cpu_fallback():
         BallDetector('wasb')
 
 
+def test_hub_surface_keeps_the_reference_signatures(monkeypatch, tmp_path):
+    """hubconf.py:11-31, :34-88: entry-point names, defaults, and the RuntimeError of a failed download; the un-vendored
+    default detector raises NotImplementedError; a missing checkpoint is an error unless TTUP_SYNTHETIC_WEIGHTS=1."""
+    import inspect
+    import hubconf
+    from upliftingtabletennis_amd import interface
+    assert inspect.signature(hubconf.ball_detection).parameters['model_name'].default == 'segformerpp_b2'
+    assert inspect.signature(hubconf.table_detection).parameters['model_name'].default == 'segformerpp_b2'
+    assert inspect.signature(hubconf.download_example_images).parameters['local_folder'].default == 'example_images'
+    assert list(inspect.signature(hubconf.full_pipeline).parameters) == []
+    assert list(inspect.signature(interface.TableTennisPipeline.predict).parameters) == ['self', 'images', 'fps']
+    with pytest.raises(NotImplementedError):
+        hubconf.ball_detection()
+    with pytest.raises(NotImplementedError):
+        hubconf.table_detection()
+    have = tmp_path / 'have'
+    have.mkdir()
+    (have / 'frame0.png').write_bytes(b'x')
+    assert hubconf.download_example_images(str(have)) == str(have)       # already present: returned as is
+    monkeypatch.setenv('http_proxy', 'http://127.0.0.1:9'); monkeypatch.setenv('https_proxy', 'http://127.0.0.1:9')
+    with pytest.raises(RuntimeError, match='Failed to download images'):
+        hubconf.download_example_images(str(tmp_path / 'missing'))
+    monkeypatch.delenv('TTUP_WEIGHTS', raising=False)
+    monkeypatch.delenv('TTUP_SYNTHETIC_WEIGHTS', raising=False)
+    monkeypatch.setattr(interface.torch.hub, 'get_dir', lambda: str(tmp_path))
+    for fn, args in ((interface._load_ball_checkpoint, ('wasb',)), (interface._load_table_checkpoint, ('hrnet',)), (interface._load_uplift_checkpoint, ())):
+        with pytest.raises(RuntimeError, match='Failed to download weights'):
+            fn(*args)
+    monkeypatch.setenv('TTUP_SYNTHETIC_WEIGHTS', '1')
+    with pytest.warns(RuntimeWarning):
+        sd, res, frames = interface._load_ball_checkpoint('wasb')
+    assert res == (1280, 704) and frames == 3
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` starts its ranks itself; with fewer visible devices it says so and exits 2 without touching a GPU."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs present')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TTUP_BENCH_SHARE_GPU')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'only' in r.stderr and not r.stdout.strip()
+
+
 def test_blob_layout_roundtrip():
     sd = weights.random_wasb_state_dict(3)
     blob = weights.pack_wasb_blob(sd)
@@ -99,6 +145,22 @@ def host_fit(tmp_path_factory):
     return ctypes.CDLL(so)
 
 
+def _check_fit_bars(err, variant):
+    """Bars on |offset - SciPy offset| in heatmap pixels over the 51 golden windows (tests/golden/refine.npz).
+    Table variant (sigma in [0.5, 3], the hub surface): every window to 1e-5 px (measured 4e-7).
+    Ball variant (sigma free up to 50): flat valleys amplify last-bit exp() differences through the 1e-8 finite-difference
+    step -- 44 of 51 windows agree to 1e-6, all but window 36 (the sigma=30 blob, measured 0.030 px) to 1e-3."""
+    n = err.shape[0]
+    if variant == 1:
+        assert err.max() < 1e-5, (err.max(), int(err.argmax()))
+        return
+    assert (err < 1e-6).sum() >= n - 8, np.sort(err)[-10:]
+    assert (err < 1e-4).sum() >= n - 6, np.sort(err)[-10:]
+    rest = np.delete(err, 36)
+    assert rest.max() < 1.5e-3, (rest.max(), int(err.argmax()))
+    assert err[36] < 0.05, err[36]
+
+
 def test_fit_solver_host_build_tracks_scipy(host_fit, golden):
     """csrc/lbfgsb.h compiled for the host against the scipy-based oracle on the golden windows
     (the same code runs per lane in the HIP fit kernel)."""
@@ -112,11 +174,7 @@ def test_fit_solver_host_build_tracks_scipy(host_fit, golden):
         host_fit.ttup_host_fit(w.ctypes.data_as(ctypes.c_void_p), n, variant, out.ctypes.data_as(ctypes.c_void_p))
         ref = np.array([refine_ref.fit_window(win[i], variant)[:2] for i in range(n)])
         err = np.abs(out[:, :2] - ref).max(1)
-        # well-posed windows agree to ~1e-6; ill-posed ones (flat valleys, sigma free up to 50) amplify the
-        # last-bit differences between libm exp and numpy's SIMD exp through the finite-difference gradient
-        assert np.median(err) < 1e-6, np.median(err)
-        assert (err < 1e-3).mean() > 0.8, err
-        assert err.max() < 0.6, err.max()
+        _check_fit_bars(err, variant)
 
 
 def test_filter_trajectory_table_matches_reference(golden):
@@ -179,3 +237,9 @@ def test_reference_format_checkpoints_are_ingested(tmp_path, monkeypatch):
     (tmp_path / 'inference_balldetection' / 'wasb' / 'model.pt').unlink()
     with pytest.raises(RuntimeError):
         interface._load_ball_checkpoint('wasb')
+    # a checkpoint trained with the other RoPE time convention must not run silently on the 'new' path
+    d = tmp_path / 'inference_uplifting' / 'ours' / 'model.pt'
+    info = dict(layout[('inference_uplifting', 'ours')][1], time_rotation='old')
+    torch.save({'model_state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in up.items()}, 'identifier': 'unit-test', 'additional_info': info}, str(d))
+    with pytest.raises(ValueError, match='time_rotation'):
+        interface._load_uplift_checkpoint()

@@ -15,6 +15,15 @@ if has_gpu():
     from upliftingtabletennis_amd import refine, uplift, wasb, _lib
 
 
+@pytest.fixture(autouse=True)
+def _synthetic_weights(monkeypatch):
+    """No trained checkpoints exist offline: the hub-surface classes run on the seeded generators, asked for explicitly
+    (without this variable their constructors raise the reference's RuntimeError, tests/test_cabi.py)."""
+    monkeypatch.setenv('TTUP_SYNTHETIC_WEIGHTS', '1')
+    monkeypatch.delenv('TTUP_WEIGHTS', raising=False)
+
+
+
 def _wasb_case(g, name):
     seed, planted, b, h, w = [int(v) for v in g[name + '/meta']]
     sd = weights.random_wasb_state_dict(seed, planted=bool(planted))
@@ -131,8 +140,10 @@ def test_refine_matches_reference_goldens(golden):
         # error in heatmap pixels (the goldens were scaled to 1920x1080 from a 12x14 map: 137x / 90x)
         hm = np.abs(got - ref).reshape(n, -1)[:, :2] / np.array([1920 / heat.shape[3], 1080 / heat.shape[2]])
         err = hm.max(1)
-        # same L-BFGS-B iteration in fp64; flat-valley cases amplify last-bit exp() differences
-        assert np.median(err) < 1e-6 and (err < 1e-3).mean() > 0.8 and err.max() < 0.6, err
+        # same L-BFGS-B iteration in fp64: the bars of tests/test_cabi.py::_check_fit_bars (table variant every window to
+        # 1e-5 px; ball variant all but the named sigma=30 window 36 to 1.5e-3 px, that one below 0.05 px)
+        from test_cabi import _check_fit_bars
+        _check_fit_bars(err, 0 if key == 'ball' else 1)
         assert np.array_equal(got[..., 2], ref[..., 2])
     got = refine.extract_position_table(torch.from_numpy(g['mc']), 1920, 1080)
     assert got.shape == g['table_mc'].shape
@@ -246,7 +257,7 @@ def test_interface_surface():
     filt, idx, times = det.filter_trajectory(pos, pos, 60.0)
     assert filt.shape == (3, 2) and np.allclose(times, np.arange(3) / 60.0)
     with pytest.raises(NotImplementedError):
-        BallDetector('segformerpp_b2')
+        BallDetector()                                      # the reference default 'segformerpp_b2' is not vendored
     up = UpliftingModel()
     ball, table, mask, times = synth.synth_trajectories(1, 20, seed=1, pad=1)
     spin, p3 = up.predict_without_normalization(torch.from_numpy(ball), torch.from_numpy(table), torch.from_numpy(mask), torch.from_numpy(times))
@@ -346,7 +357,7 @@ def test_table_detector_and_full_pipeline_surface():
     frames, track = synth.synth_frames(8, 720, 1280, seed=4)
     det = TableDetector('hrnet', max_batch=4)
     pos, heat = det.predict(list(frames[:5]))
-    assert pos.shape == (5, 13, 3) and pos.dtype == np.float64 and heat.shape == (5, 13, 704, 1280)
+    assert pos.shape == (5, 13, 3) and pos.dtype == np.float64 and heat.shape == (5, 1, 13, 704, 1280)      # interface.py:165-167
     assert (pos[..., 2] == 1).all()
     filt = det.filter_trajectory(pos, pos)
     assert filt.shape == (13, 3)
@@ -360,7 +371,7 @@ def test_table_detector_and_full_pipeline_surface():
     pipe = TableTennisPipeline(max_batch=8)
     spin, p3 = pipe.predict(list(frames), 60.0)                  # table keypoints detected by the HRNet
     assert tuple(spin.shape) == (3,) and p3.shape == (6, 3) and np.isfinite(p3).all()
-    spin2, p32 = pipe.predict(list(frames), 60.0, table_keypoints=filt)
+    spin2, p32 = pipe.predict_with_table(list(frames), 60.0, filt)
     assert p32.shape == (6, 3)
 
 
@@ -429,3 +440,46 @@ def test_bench_two_rank_flow_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
     assert abs(rec['value'] - 2 * 256 * 2 / (rec['ms_per_step'] * 2 / 1e3)) / rec['value'] < 1e-3
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed environment: the parent starts the two ranks itself (before it
+    touches the GPU) and relays rank 0's line.  Same dry-run transport as above (two ranks share this box's GPU, gloo)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(TTUP_BENCH_SHARE_GPU='1', TTUP_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-roofline', '--no-cpu-baseline'],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['collective']['ranks'] == 2 and rec['collective']['backend'] == 'gloo' and rec['rccl_ranks'] == 0
+    # a mismatch between --gpus and the launcher's world size is diagnosed, not ignored
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
+
+
+def test_rccl_gather_on_device_tensors():
+    """The path's only collective over RCCL itself (backend 'nccl' on ROCm) with device tensors: a world of one rank on this
+    box's single GPU -- init, all_reduce, all_gather of the record sizes and the gather of `gather_records`."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from upliftingtabletennis_amd import pipeline
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+t = torch.ones(4, device='cuda'); dist.all_reduce(t); assert t.tolist() == [1.0] * 4
+rec = {'xyv': torch.arange(12, dtype=torch.float64, device='cuda').reshape(4, 3), 'spin': torch.ones(2, 3, device='cuda')}
+out = pipeline.gather_records(rec, dist)
+assert torch.equal(out['xyv'][0], rec['xyv']) and out['spin'][0].is_cuda
+two = [torch.empty(1, dtype=torch.int64, device='cuda')]; dist.all_gather(two, torch.tensor([7], device='cuda')); assert int(two[0]) == 7
+dist.barrier(); dist.destroy_process_group(); print('rccl ok', dist.is_nccl_available())
+''' % root
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'rccl ok True' in out.stdout, out.stderr[-2000:]

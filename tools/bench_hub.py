@@ -4,6 +4,7 @@ spin + 3D positions out), wall clock including the host->device upload of the fr
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('TTUP_SYNTHETIC_WEIGHTS', '1')      # no trained checkpoints offline
 import hubconf
 from upliftingtabletennis_amd import synth
 frames, _ = synth.synth_frames(48, 720, 1280, seed=0)      # 46 detections: the reference caps a rally at 50 tokens and needs one padded slot

@@ -25,6 +25,7 @@ SIGNATURES = {
     'ttup_wasb_forward_frames': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'ttup_wasb_read_tap': (_i, [_vp, _c.c_char_p, _i, _vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _vp]),
     'ttup_wasb_time_ops': (_i, [_vp, _i, _i, _i, _vp, _vp, _c.POINTER(_i), _vp]),
+    'ttup_wasb_time_graph': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _c.POINTER(_i), _vp]),
     'ttup_wasb_micro_batch': (_i, [_vp]),
     'ttup_wasb_out_channels': (_i, [_vp]),
     'ttup_preprocess_frames': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -1,5 +1,8 @@
 // Library-level entry points: version, error string, device probe.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace ttup {
 static thread_local char g_err[1024] = "";
@@ -10,6 +13,41 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+int ensure_max_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return TTUP_OK;
+    int dev = 0;
+    TTUP_HIP_CHECK(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find({kernel, dev});
+    if (it != done.end() && it->second >= bytes) return TTUP_OK;
+    TTUP_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[{kernel, dev}] = bytes;
+    return TTUP_OK;
+}
+
+int device_normalise_lut(const float** lut_dev) {
+    int dev = 0;
+    TTUP_HIP_CHECK(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::map<int, float*> luts;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = luts.find(dev);
+    if (it == luts.end()) {
+        // ImageNet mean / std of balldetection/transforms.py:388-401, evaluated in fp64 like the reference, rounded to fp32
+        const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
+        float h[3 * 256];
+        for (int c = 0; c < 3; ++c) for (int v = 0; v < 256; ++v) h[c * 256 + v] = (float)(((double)v / 255.0 - mean[c]) / sd[c]);
+        float* d = nullptr;
+        TTUP_HIP_CHECK(hipMalloc((void**)&d, sizeof h));
+        TTUP_HIP_CHECK(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+        it = luts.emplace(dev, d).first;
+    }
+    *lut_dev = it->second;
+    return TTUP_OK;
+}
 }  // namespace ttup
 
 extern "C" int ttup_version(void) { return 100; }

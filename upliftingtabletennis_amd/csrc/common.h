@@ -48,4 +48,10 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Per-device one-time setup (api.hip).  Kernels that need more than 64 KB of dynamic LDS must have
+// hipFuncAttributeMaxDynamicSharedMemorySize raised on EVERY device they are launched on, and handles may live on any
+// device of the process: both helpers key their state by hipGetDevice() under a mutex (no process-global flags).
+int ensure_max_lds(const void* kernel, size_t bytes);          // TTUP_OK or TTUP_EHIP
+int device_normalise_lut(const float** lut_dev);               // [3][256] (v/255 - mean[c]) / std[c] on the current device
+
 }  // namespace ttup

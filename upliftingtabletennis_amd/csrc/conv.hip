@@ -406,11 +406,7 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     a.H = l.h; a.W = l.w; a.OH = l.h; a.OW = l.w; a.relu = l.relu;
     a.tiles_x = cdiv(l.w, 32); a.tiles_per_img = a.tiles_x * cdiv(l.h, 8); a.total_tiles = a.tiles_per_img * l.batch;
     constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)conv64_kernel, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
     hipLaunchKernelGGL(conv64_kernel, dim3(grid), dim3(512), SMEM, st, a);
@@ -610,11 +606,7 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
     a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
     constexpr size_t SMEM = (size_t)(5 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * 340 * 32 + 432 * 16) * 2;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)stem_kernel, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(512), SMEM, st, a);
@@ -815,11 +807,7 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
     a.w6 = (const bf16_t*)p6.w_dev; a.b6 = p6.bias_dev; a.b0 = (bf16_t*)b0; a.b1o = (bf16_t*)b1;
     a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
     constexpr size_t SMEM = (size_t)(340 * 128 + 3 * 8 * 64 * 8 + 4 * 9 * 64 * 8) * 2 + 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bneck_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)bneck_trans_kernel, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
     hipLaunchKernelGGL(bneck_trans_kernel, dim3(grid), dim3(512), SMEM, st, a);
@@ -1118,11 +1106,7 @@ template <int C, int TH, int TW>
 static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done && SMEM > 64 * 1024) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bb_chain2_kernel<C, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW>, SMEM)) return rc;
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
@@ -1139,11 +1123,7 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2 +
                             (size_t)(C == 16 ? 0 : BB_WT_SLOTS) * KSTEPS * MT * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done && SMEM > 64 * 1024) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)bb_chain_kernel<C, NB, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)bb_chain_kernel<C, NB, TH, TW>, SMEM)) return rc;
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     const int per_cu = (int)((160 * 1024) / SMEM) > 2 ? 2 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
@@ -1305,12 +1285,7 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     // persistent grid: as many workgroups as can be resident (LDS-limited), each walks its share of the tiles
     const int per_cu = (int)((160 * 1024) / SMEM) > 4 ? 4 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
     const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;
-    static bool attr_done = false;
-    if (!attr_done && SMEM > 64 * 1024) {
-        TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
-        attr_done = true;
-    }
+    if (int rc = ensure_max_lds((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>, SMEM)) return rc;
     if (grid == 0) return TTUP_OK;
     hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>), dim3(grid), dim3(NW * 64), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
@@ -1608,15 +1583,7 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     a.total = (long long)n_triples * dst_h * dst_w;
     a.scale_x = (double)src_w / dst_w; a.scale_y = (double)src_h / dst_h;
     if (a.total == 0) return TTUP_OK;
-    static float* lut_dev = nullptr;           // built once per process (per device 0 context; inputs are device-independent)
-    if (!lut_dev) {
-        const double mean[3] = {0.485, 0.456, 0.406}, sd[3] = {0.229, 0.224, 0.225};
-        float h[3 * 256];
-        for (int c = 0; c < 3; ++c) for (int v = 0; v < 256; ++v) h[c * 256 + v] = (float)(((double)v / 255.0 - mean[c]) / sd[c]);
-        TTUP_HIP_CHECK(hipMalloc((void**)&lut_dev, sizeof h));
-        TTUP_HIP_CHECK(hipMemcpy(lut_dev, h, sizeof h, hipMemcpyHostToDevice));
-    }
-    a.lut = lut_dev;
+    if (int rc = device_normalise_lut(&a.lut)) return rc;       // one table per device
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
     if (dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32)
         hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);

@@ -15,11 +15,12 @@
 // Gradients are scipy's '2-point' scheme: h = 1e-8 absolute, flipped when x+h leaves the box
 // (scipy/optimize/_numdiff.py:_adjust_scheme_to_bounds), df/dx with dx recomputed as (x+h)-x.
 //
-// The same source compiles for the host (tests/test_refine_solver_cpu.py builds it with g++) and for gfx950.
+// The same source compiles for gfx950 (hipcc, the product) and for the host (g++, test infrastructure only:
+// tests/test_cabi.py builds tests/helpers/host_fit.cpp into a temporary directory and compares it with SciPy).
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TTUP_HD __host__ __device__
 #else
 #define TTUP_HD

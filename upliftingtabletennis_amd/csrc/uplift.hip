@@ -485,11 +485,7 @@ int run_linear(const Linear& L, const float* x, int ldx, long long M, const floa
     const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((L.n + 64 * ntw - 1) / (64 * ntw)));
 #define TTUP_LIN(LN_, NTW_, MH_)                                                                                              \
     do {                                                                                                                      \
-        static bool attr_done = false;                                                                                        \
-        if (!attr_done) {                                                                                                     \
-            TTUP_HIP_CHECK(hipFuncSetAttribute((const void*)linear_kernel<LN_, NTW_, MH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_done = true;                                                                                                 \
-        }                                                                                                                     \
+        if (int rc_ = ensure_max_lds((const void*)linear_kernel<LN_, NTW_, MH_>, 160 * 1024)) return rc_;                     \
         hipLaunchKernelGGL((linear_kernel<LN_, NTW_, MH_>), grid, dim3(256 * MH_), smem, st, a);                              \
     } while (0)
 #define TTUP_LIN_N(LN_, MH_)                                          \

@@ -360,8 +360,8 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     return TTUP_OK;
 }
 
-int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
-    for (const Op& op : net->ops) {
+int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
+    {
         if (op.kind == Op::CONV) {
             const Tensor& s = net->tensors[op.src0];
             ConvLaunch l;
@@ -377,7 +377,7 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
                                        net->tensors[op.dst2].ptr, mb, s.h, s.w, st);
             if (rc) return rc;
         } else if (op.kind == Op::UPSUM_HEAD) {
-            continue;       // launched by forward_impl, which knows the output buffers
+            return TTUP_OK;       // launched by forward_micro (run_head_op), which knows the output buffers
         } else if (op.kind == Op::BB_CHAIN) {
             const Tensor& s = net->tensors[op.src0];
             const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -401,6 +401,20 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
     return TTUP_OK;
 }
 
+int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
+    for (const Op& op : net->ops) { const int rc = run_op(net, op, mb, st); if (rc) return rc; }
+    return TTUP_OK;
+}
+
+// the fused last op of the bf16 ball path: stage-4 fuse sum + head + argmax partials (+ window gather)
+int run_head_op(ttup_wasb* net, int mb, float* heat, long long* am, float* wn, hipStream_t st) {
+    const Op& op = net->ops.back();
+    const void* terms[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
+    return launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, net->H, net->W,
+                             am, wn, net->refine_ws, net->refine_ws_bytes, st);
+}
+
 int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int batch, int b0,
                   float* heat_dev, int64_t* argmax_dev, float* win_dev, int lane, hipStream_t st) {
     const int H = net->H, W = net->W;
@@ -416,16 +430,10 @@ int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev,
     if (rc) return rc;
     float* heat = heat_dev ? heat_dev + (size_t)b0 * K * hw : net->heat_scratch;
     if (net->fused_head) {
-        const Op& op = net->ops.back();
-        const void* terms[3] = {nullptr, nullptr, nullptr};
-        for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
         const bool peaks = argmax_dev || win_dev;
         long long* am = peaks ? (argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch) : nullptr;
         float* wn = peaks ? (win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch) : nullptr;
-        rc = launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, H, W,
-                               am, wn, net->refine_ws, net->refine_ws_bytes, st);
-        if (rc) return rc;
-        return TTUP_OK;
+        return run_head_op(net, mb, heat, am, wn, st);
     }
     rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st);
     if (rc) return rc;
@@ -572,9 +580,42 @@ extern "C" int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, f
     return launch_nhwc_to_nchw(t.ptr, out_dev, batch, t.c, t.h, t.w, net->dtype, (hipStream_t)stream);
 }
 
-// Profiling aid for bench.py: time every op of the graph separately with HIP events on `stream`
-// (micro-batch `batch`, `reps` back-to-back launches per op).  info_out: 8 ints per op
-// {kind(0 conv,1 upsum), cin_algorithmic, cout, k, stride, out_h, out_w, cin_padded}.
+// ---- measurement aids for bench.py
+// info: 8 ints per op {kind(0 conv,1 upsum,2 bneck_trans,3 bb_chain,4 stem,5 upsum_head), algorithmic MACs per output element
+// (or cin), cout, k, stride, out_h, out_w, cin_padded / chain length}; name: the HIP kernel the op launches.
+namespace {
+void op_info(const ttup_wasb* net, int i, int* o, char* name) {
+    const Op& op = net->ops[i];
+    const Tensor& d = net->tensors[op.dst];
+    const bool bf = net->dtype == TTUP_DTYPE_BF16;
+    char nm[64] = "";
+    if (op.kind == Op::STEM) {
+        o[0] = 4; o[1] = 9 * 9 * 64 + 9 * 64 * 64 + 64 * 32; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
+        snprintf(nm, sizeof nm, "stem_kernel");
+    } else if (op.kind == Op::BB_CHAIN) {
+        o[0] = 3; o[1] = op.n_chain * d.c * 9; o[2] = d.c; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = op.n_chain;
+        if (op.n_chain == 4) snprintf(nm, sizeof nm, "bb_chain2_kernel<16>");
+        else snprintf(nm, sizeof nm, "bb_chain_kernel<%d,1>%s", d.c, op.conv2 >= 0 ? "+1x1" : "");
+        if (op.conv2 >= 0) o[1] += 16;          // fused 1x1 32->16 follower: 32*16 MACs per pixel = 16 per output element of the block
+    } else if (op.kind == Op::BNECK_TRANS) {
+        // algorithmic MACs per output pixel of B0: 96*128 (1x1) + 1152*16 (3x3 s1) + 1152*32/4 (3x3 s2 at quarter density)
+        o[0] = 2; o[1] = 96 * 128 + 1152 * 16 + 1152 * 8; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
+        snprintf(nm, sizeof nm, "bneck_trans_kernel");
+    } else if (op.kind == Op::CONV) {
+        const PackedConv& pc = net->convs[op.conv];
+        o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
+        if (!bf) snprintf(nm, sizeof nm, "conv_direct_f32_kernel");
+        else if (pc.k == 3 && pc.stride == 1 && pc.cout == 64 && pc.cin_total == 64 && op.conv2 < 0) snprintf(nm, sizeof nm, "conv64_kernel");
+        else snprintf(nm, sizeof nm, "conv_mfma_kernel<%d,%d,%d,%d>", pc.ck, pc.cout, pc.k, pc.stride);
+    } else {
+        o[0] = op.kind == Op::UPSUM_HEAD ? 5 : 1; o[1] = op.n_terms; o[2] = d.c; o[3] = 0; o[4] = 0; o[5] = d.h; o[6] = d.w; o[7] = d.c;
+        snprintf(nm, sizeof nm, op.kind == Op::UPSUM_HEAD ? "upsum_head_kernel" : bf ? "upsum_bf16x8_kernel" : "upsum_kernel<float>");
+    }
+    if (name) { memset(name, 0, 64); memcpy(name, nm, strlen(nm)); }
+}
+}  // namespace
+
+// Every op on its own: `reps` back-to-back launches of one op between two HIP events on `stream` (inputs warm in the caches).
 extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream) {
     TTUP_REQUIRE(net && ms_out && info_out && n_ops_out, TTUP_EINVAL, "ttup_wasb_time_ops: null pointer");
     TTUP_REQUIRE(batch > 0 && batch <= net->micro && reps > 0, TTUP_EINVAL, "ttup_wasb_time_ops: batch must be in [1,%d]", net->micro);
@@ -585,39 +626,56 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
     TTUP_HIP_CHECK(hipEventCreate(&e0));
     TTUP_HIP_CHECK(hipEventCreate(&e1));
     int rc = TTUP_OK;
+    net->use_lane(0);
     for (int i = 0; i < n && rc == TTUP_OK; ++i) {
         const Op& op = net->ops[i];
-        std::vector<Op> one(1, op);
-        std::swap(net->ops, one);
-        rc = run_ops(net, batch, st);                       // warm-up launch of this op
+        auto once = [&]() { return op.kind == Op::UPSUM_HEAD ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st); };
+        rc = once();                       // warm-up launch of this op
         if (rc == TTUP_OK) {
             (void)hipEventRecord(e0, st);
-            for (int r = 0; r < reps && rc == TTUP_OK; ++r) rc = run_ops(net, batch, st);
+            for (int r = 0; r < reps && rc == TTUP_OK; ++r) rc = once();
             (void)hipEventRecord(e1, st);
             (void)hipEventSynchronize(e1);
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
             ms_out[i] = ms / reps;
         }
-        std::swap(net->ops, one);
-        int* o = info_out + 8 * i;
-        const Tensor& d = net->tensors[op.dst];
-        if (op.kind == Op::STEM) {
-            o[0] = 4; o[1] = 9 * 9 * 64 + 9 * 64 * 64 + 64 * 32; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
-        } else if (op.kind == Op::BB_CHAIN) {
-            o[0] = 3; o[1] = op.n_chain * d.c * 9; o[2] = d.c; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = op.n_chain;
-        } else if (op.kind == Op::BNECK_TRANS) {
-            // algorithmic MACs per output pixel of B0: 96*128 (1x1) + 1152*16 (3x3 s1) + 1152*32/4 (3x3 s2 at quarter density)
-            o[0] = 2; o[1] = 96 * 128 + 1152 * 16 + 1152 * 8; o[2] = 1; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = 0;
-        } else if (op.kind == Op::CONV) {
-            const PackedConv& pc = net->convs[op.conv];
-            o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
-        } else {
-            o[0] = 1; o[1] = op.n_terms; o[2] = d.c; o[3] = 0; o[4] = 0; o[5] = d.h; o[6] = d.w; o[7] = d.c;
-        }
+        op_info(net, i, info_out + 8 * i, nullptr);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    *n_ops_out = n;
+    return rc;
+}
+
+// The whole graph in order, as the forward pass launches it (one micro-batch on lane 0, `stream`), with a HIP event between
+// consecutive ops: ms_out[i] = average time from the end of op i-1 to the end of op i over `reps` passes, i.e. the launch
+// duration of op i with the cache state it really sees.  This is what bench.py's `roofline` is computed from and what the
+// rocprofv3 kernel trace of the same run (TTUP_LANES=1) reports per kernel.  names_out: max_ops x 64 chars.
+extern "C" int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, char* names_out,
+                                    int* n_ops_out, void* stream) {
+    TTUP_REQUIRE(net && ms_out && info_out && n_ops_out, TTUP_EINVAL, "ttup_wasb_time_graph: null pointer");
+    TTUP_REQUIRE(batch > 0 && batch <= net->micro && reps > 0, TTUP_EINVAL, "ttup_wasb_time_graph: batch must be in [1,%d]", net->micro);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)net->ops.size();
+    TTUP_REQUIRE(n <= max_ops, TTUP_EINVAL, "ttup_wasb_time_graph: %d ops exceed max_ops %d", n, max_ops);
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) TTUP_HIP_CHECK(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    int rc = TTUP_OK;
+    net->use_lane(0);
+    for (int r = -1; r < reps && rc == TTUP_OK; ++r) {          // pass -1 = warm-up
+        (void)hipEventRecord(ev[0], st);
+        for (int i = 0; i < n && rc == TTUP_OK; ++i) {
+            const Op& op = net->ops[i];
+            rc = op.kind == Op::UPSUM_HEAD ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st);
+            (void)hipEventRecord(ev[i + 1], st);
+        }
+        (void)hipEventSynchronize(ev[n]);
+        if (r >= 0) for (int i = 0; i < n; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); acc[i] += ms; }
+    }
+    for (int i = 0; i < n; ++i) { ms_out[i] = (float)(acc[i] / reps); op_info(net, i, info_out + 8 * i, names_out ? names_out + 64 * i : nullptr); }
+    for (auto& e : ev) (void)hipEventDestroy(e);
     *n_ops_out = n;
     return rc;
 }

@@ -3,8 +3,9 @@ refine -> uplift path, same constructor arguments, method names, argument meanin
 
 Differences forced by the environment (documented in DESIGN.md):
   * no network: weights come from ``TTUP_WEIGHTS`` (a directory laid out like the reference's weight zip:
-    inference_balldetection/<name>/model.pt, inference_uplifting/ours/model.pt) or, when absent, from the
-    seeded generators in ``weights.py`` (``TTUP_SYNTHETIC_WEIGHTS=1`` makes that explicit);
+    inference_balldetection/<name>/model.pt, inference_uplifting/ours/model.pt) or from the folder the reference
+    unpacks that zip into under the torch hub directory; when neither exists the constructors raise the reference's
+    RuntimeError unless ``TTUP_SYNTHETIC_WEIGHTS=1`` asks for the seeded generators in ``weights.py`` (with a warning);
   * only the in-tree WASB/HRNet detector is built; 'segformerpp_*' needs the un-vendored
     KieDani/SegformerPlusPlus hub repo and raises NotImplementedError;
   * table detection uses the in-tree HRNet ('hrnet'); when a detector's primary SegFormer++ model is unavailable the
@@ -24,7 +25,26 @@ KEYPOINT_VISIBLE = 1
 
 
 def _weights_dir():
-    return os.environ.get('TTUP_WEIGHTS', '')
+    """Where reference-format checkpoints are looked for: $TTUP_WEIGHTS, else the folder the reference itself unpacks its
+    weight archive into (interface.py:34-73: <torch hub dir>/checkpoints/tt_uplifting_extracted/weights)."""
+    d = os.environ.get('TTUP_WEIGHTS', '')
+    if d:
+        return d
+    hub = os.path.join(torch.hub.get_dir(), 'checkpoints', 'tt_uplifting_extracted', 'weights')
+    return hub if os.path.isdir(hub) else ''
+
+
+def _synthetic_or_raise(what, path):
+    """No checkpoint: the reference downloads one or raises RuntimeError (interface.py:61,71).  There is no network here,
+    so the same RuntimeError is raised unless TTUP_SYNTHETIC_WEIGHTS=1 explicitly asks for seeded random weights
+    (benchmarks / smoke tests: the outputs are then meaningless as detections)."""
+    if os.environ.get('TTUP_SYNTHETIC_WEIGHTS') == '1':
+        import warnings
+        warnings.warn('upliftingtabletennis_amd: %s runs on SEEDED RANDOM weights (TTUP_SYNTHETIC_WEIGHTS=1); its outputs '
+                      'are not detections' % what, RuntimeWarning, stacklevel=3)
+        return
+    raise RuntimeError('Failed to download weights: %s not found and there is no network; point TTUP_WEIGHTS at a folder laid '
+                       'out like the reference weight archive, or set TTUP_SYNTHETIC_WEIGHTS=1 for seeded random weights' % (path or what))
 
 
 def _load_ball_checkpoint(model_name):
@@ -33,8 +53,7 @@ def _load_ball_checkpoint(model_name):
     if _weights_dir() and os.path.exists(path):
         sd, info = weights.load_checkpoint_state_dict(path)
         return sd, tuple(info.get('image_resolution', wasb.RESOLUTIONS['wasb'])), int(info.get('in_frames', 3))
-    if _weights_dir():
-        raise RuntimeError('Failed to load weights: %s not found' % path)
+    _synthetic_or_raise("BallDetector('%s')" % model_name, path if _weights_dir() else '')
     return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')), planted=True), wasb.RESOLUTIONS['wasb'], 3
 
 
@@ -45,14 +64,15 @@ def _load_uplift_checkpoint():
         sd, info = weights.load_checkpoint_state_dict(path)
         if info.get('name', 'connectstage') != 'connectstage' or info.get('tabletoken_mode', 'dynamic') != 'dynamic':
             raise ValueError('only connectstage/dynamic uplift checkpoints are supported')
+        if info.get('time_rotation', 'new') != 'new':       # the reference hands this to get_model (inference_uplifting.py:49-52)
+            raise ValueError("only time_rotation='new' uplift checkpoints are supported (got %r)" % info.get('time_rotation'))
         return sd, info.get('size', 'large'), info.get('transform_mode', 'global')
-    if _weights_dir():
-        raise RuntimeError('Failed to load weights: %s not found' % path)
+    _synthetic_or_raise('UpliftingModel()', path if _weights_dir() else '')
     return weights.random_uplift_state_dict(int(os.environ.get('TTUP_SEED', '0')), 'large'), 'large', 'global'
 
 
 class BallDetector:
-    def __init__(self, model_name='wasb', max_batch=32, dtype='bf16'):
+    def __init__(self, model_name='segformerpp_b2', max_batch=32, dtype='bf16'):
         if 'segformerpp' in model_name or model_name == 'vitpose':
             raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference "
                                       "(KieDani/SegformerPlusPlus / mmcv); only 'wasb' is built" % model_name)
@@ -112,13 +132,12 @@ def _load_table_checkpoint(model_name):
     if _weights_dir() and os.path.exists(path):
         sd, info = weights.load_checkpoint_state_dict(path)
         return sd, tuple(info.get('image_resolution', (1280, 704)))
-    if _weights_dir():
-        raise RuntimeError('Failed to load weights: %s not found' % path)
+    _synthetic_or_raise("TableDetector('%s')" % model_name, path if _weights_dir() else '')
     return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')) + 1, planted=False, in_ch=3, head_out=13), (1280, 704)
 
 
 class TableDetector:
-    def __init__(self, model_name='hrnet', max_batch=8, dtype='bf16'):
+    def __init__(self, model_name='segformerpp_b2', max_batch=8, dtype='bf16'):
         if 'segformerpp' in model_name or model_name == 'vitpose':
             raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference; only 'hrnet' is built" % model_name)
         _lib.require_gpu()
@@ -132,16 +151,17 @@ class TableDetector:
 
     def predict(self, images):
         """images: list (length B) of BGR uint8 HWC frames.
-        Returns (pred_pos (B,13,3) float64 [x, y, visibility] in 1920x1080 px, preds (B,13,H,W) float32)."""
+        Returns (pred_pos (B,13,3) float64 [x, y, visibility] in 1920x1080 px, preds (B,1,13,H,W) float32 -- the reference
+        stacks one (1,13,H,W) tensor per frame with np.array, interface.py:165-167)."""
         pred_pos, preds = [], []
         w, h = self.model_resolution
         for b0 in range(0, len(images), self.max_batch):
             fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[b0:b0 + self.max_batch]])).to(self.device)
             heat = self.model(wasb.preprocess_frames(fr, (w, h)))
             pred_pos.append(refine.extract_position_table(heat, self.resolution[0], self.resolution[1]))
-            preds.append(heat.cpu().numpy())
+            preds.append(heat.cpu().numpy()[:, None])
         if not pred_pos:
-            return np.zeros((0, 13, 3)), np.zeros((0, 13, h, w), np.float32)
+            return np.zeros((0, 13, 3)), np.zeros((0, 1, 13, h, w), np.float32)
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
     def predict_keypoints(self, images):
@@ -214,10 +234,17 @@ class TableTennisPipeline:
         self.uplifting_model = UpliftingModel()
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
 
-    def predict(self, images, fps, table_keypoints=None):
-        """images: list of BGR frames of one rally; fps: frame rate.  table_keypoints: (13,3) [x,y,vis] in 1920x1080 px
-        (optional override; by default they are detected with the in-tree HRNet like interface.py:281-283).
+    def predict(self, images, fps):
+        """images: list of BGR frames of one rally; fps: frame rate (interface.py:265-289).
         Returns (pred_spin torch (3,), pred_pos_3d numpy (T',3))."""
+        return self._predict(images, fps, None)
+
+    def predict_with_table(self, images, fps, table_keypoints):
+        """`predict` with known table keypoints ((13,3) [x,y,vis] in 1920x1080 px), skipping table detection -- an addition
+        for fixed-camera streams; the reference surface is `predict`."""
+        return self._predict(images, fps, table_keypoints)
+
+    def _predict(self, images, fps, table_keypoints):
         if table_keypoints is None:        # 2. table detection (interface.py:281-283)
             kp = self.table_detector.predict_keypoints(images)
             kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict_keypoints(images)

@@ -126,4 +126,10 @@ class StreamWorker:
         with torch.cuda.stream(side):
             spin, p3, nvalid = self.uplift_segments(ticket['host'].numpy(), table_px, fps)
         side.synchronize()
+        # the results were allocated under the side stream and are consumed on the caller's stream (gather_records, RCCL,
+        # user code): tell the caching allocator, so their blocks are not handed to the next clip's side-stream uplift
+        # while reads queued on the caller's stream are still pending
+        cur = torch.cuda.current_stream(self.device)
+        for t in (spin, p3, nvalid):
+            t.record_stream(cur)
         return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}

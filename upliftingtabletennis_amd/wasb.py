@@ -163,23 +163,33 @@ def preprocess_triples(frames_u8, dst_wh):
     return out
 
 
-def time_ops(net, batch=None, reps=5):
+_OP_KINDS = {0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem', 5: 'upsum_head'}
+
+
+def time_ops(net, batch=None, reps=5, in_graph=True):
     """Per-op timing of the CNN graph (HIP events inside the library, on the current stream).
-    Returns a list of dicts {kind, cin, cout, k, stride, h, w, ms, flops} for one micro-batch."""
+    in_graph=True: the whole graph in launch order with an event between consecutive ops (what the forward pass sees);
+    False: every op on its own, back to back.  Returns a list of dicts {kernel, kind, cin, cout, k, stride, h, w, ms, flops}
+    for one micro-batch; flops = algorithmic 2*MACs of the op (0 for the element-wise sums)."""
     import numpy as _np
     lib = net._lib
     micro = lib.ttup_wasb_micro_batch(net._handle)
     batch = micro if batch is None else min(batch, micro)
     ms = _np.zeros(256, _np.float32)
     info = _np.zeros((256, 8), _np.int32)
+    names = _np.zeros((256, 64), _np.uint8)
     n = ctypes.c_int()
     with torch.cuda.device(net.device):
-        _lib.check(lib.ttup_wasb_time_ops(net._handle, batch, reps, 256, ms.ctypes.data_as(ctypes.c_void_p),
-                                          info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), _lib.stream_ptr()))
+        if in_graph:
+            _lib.check(lib.ttup_wasb_time_graph(net._handle, batch, reps, 256, ms.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p),
+                                                names.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), _lib.stream_ptr()))
+        else:
+            _lib.check(lib.ttup_wasb_time_ops(net._handle, batch, reps, 256, ms.ctypes.data_as(ctypes.c_void_p),
+                                              info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), _lib.stream_ptr()))
     ops = []
     for i in range(n.value):
         kind, cin, cout, k, stride, h, w, cpad = [int(v) for v in info[i]]
         flops = 2.0 * batch * h * w * cout * cin * k * k if kind in (0, 2, 3, 4) else 0.0
-        ops.append(dict(index=i, kind={0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem'}[kind], cin=cin, cout=cout, k=k, stride=stride, h=h, w=w,
-                        cin_padded=cpad, ms=float(ms[i]), flops=flops, batch=batch))
+        ops.append(dict(index=i, kernel=bytes(names[i]).split(b'\0')[0].decode() or _OP_KINDS[kind], kind=_OP_KINDS[kind], cin=cin, cout=cout, k=k,
+                        stride=stride, h=h, w=w, cin_padded=cpad, ms=float(ms[i]), flops=flops, batch=batch))
     return ops

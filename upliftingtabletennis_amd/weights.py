@@ -130,5 +130,6 @@ def load_checkpoint_state_dict(path):
     """Read a reference checkpoint file (torch.save of {'model_state_dict', 'identifier',
     'additional_info'}) -> (state_dict, additional_info)."""
     import torch
-    d = torch.load(path, map_location='cpu', weights_only=False)
+    # tensors + plain containers only (the default of the torch 2.6 the reference pins): a checkpoint folder is user input
+    d = torch.load(path, map_location='cpu', weights_only=True)
     return d['model_state_dict'], d.get('additional_info', {})
