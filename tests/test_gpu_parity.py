@@ -143,7 +143,7 @@ def test_refine_matches_reference_goldens(golden):
         # same L-BFGS-B iteration in fp64: the bars of tests/test_cabi.py::_check_fit_bars (table variant every window to
         # 1e-5 px; ball variant all but the named sigma=30 window 36 to 1.5e-3 px, that one below 0.05 px)
         from test_cabi import _check_fit_bars
-        _check_fit_bars(err, 0 if key == 'ball' else 1)
+        _check_fit_bars(err, 0 if key == 'ball' else 1, device=True)
         assert np.array_equal(got[..., 2], ref[..., 2])
     got = refine.extract_position_table(torch.from_numpy(g['mc']), 1920, 1080)
     assert got.shape == g['table_mc'].shape
