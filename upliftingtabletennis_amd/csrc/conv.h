@@ -32,6 +32,7 @@ struct ConvLaunch {
     int relu = 0;
     const PackedConv* follow = nullptr;   // bf16 only: fused 1x1 follower (64 -> 32, ReLU) applied to dst, written to dst2
     void* dst2 = nullptr;
+    const int* n_active = nullptr;        // f32 only: device-side batch (<= batch) decided by an earlier kernel (csrc/certify.hip)
 };
 
 // host-side packing (called from ttup_wasb_create)
@@ -39,6 +40,9 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b /*second source or null*/
 void free_conv(PackedConv* p);
 
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t stream);
+// fp32 matrix-pipe conv (csrc/conv_f32.hip)
+bool conv_f32_mfma_supported(const PackedConv& p);
+int launch_conv_f32_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t stream);
 
 // fused stem: conv1 + conv2 + Bottleneck conv1, bf16 only, persistent with all weights resident in LDS (csrc/conv.hip)
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
@@ -54,7 +58,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
 
 // y = relu(base + sum_k nearest_upsample(t_k, 2^shift_k)); all NHWC with c channels; base at (h,w).
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
-                 int batch, int h, int w, int c, int dtype, hipStream_t stream);
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active = nullptr);
 
 // float32 NCHW (B,cin,H,W) -> NHWC with cpad channels (zero filled)
 int launch_nchw_to_nhwc(const float* src, void* dst, int batch, int cin, int cpad, int h, int w, int dtype, hipStream_t stream);
@@ -63,7 +67,7 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, in
 
 // head: 1x1 conv cin -> n_out output channels (+bias), float32 (B,n_out,H,W) out; w_dev [n_out][cin], bias_dev [n_out]
 int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin,
-                int dtype, hipStream_t stream);
+                int dtype, hipStream_t stream, const int* n_active = nullptr);
 
 // uint8 frames -> normalised triples: see ttup_preprocess_triples.  out NCHW f32 or NHWC16 (dtype of the net)
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,

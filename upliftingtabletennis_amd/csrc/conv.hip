@@ -1315,6 +1315,9 @@ static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t s
 
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t st) {
     if (dtype == TTUP_DTYPE_F32) {
+        static const bool direct = getenv("TTUP_F32_DIRECT") != nullptr;         // cross-check of the matrix-pipe kernel
+        if (!direct && conv_f32_mfma_supported(p)) return launch_conv_f32_mfma(p, l, st);
+        TTUP_REQUIRE(!l.n_active, TTUP_EINVAL, "conv: a device-side batch needs the matrix-pipe fp32 kernel");
         ConvFArgs a;
         a.src0 = (const float*)l.src0; a.src1 = (const float*)l.src1; a.w = (const float*)p.w_dev; a.bias = p.bias_dev;
         a.residual = (const float*)l.residual; a.dst = (float*)l.dst;
@@ -1347,23 +1350,24 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-struct UpsumArgs { const void* base; const void* t[3]; int shift[3]; int n; void* dst; int H, W, C; long long total; };
+struct UpsumArgs { const void* base; const void* t[3]; int shift[3]; int n; void* dst; int H, W, C; long long total; const int* n_active; long long per_sample; };
 
 template <typename T>
 __global__ void upsum_kernel(UpsumArgs a) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.total) return;
-    const int c = (int)(i % a.C);
-    long long p = i / a.C;
-    const int x = (int)(p % a.W); p /= a.W;
-    const int y = (int)(p % a.H);
-    const int b = (int)(p / a.H);
-    float v = ld((const T*)a.base + i);
-    for (int k = 0; k < a.n; ++k) {
-        const int sh = a.shift[k], hh = a.H >> sh, ww = a.W >> sh;
-        v += ld((const T*)a.t[k] + ((size_t)(b * hh + (y >> sh)) * ww + (x >> sh)) * a.C + c);
+    const long long total = a.n_active ? (a.per_sample * *a.n_active < a.total ? a.per_sample * *a.n_active : a.total) : a.total;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % a.C);
+        long long p = i / a.C;
+        const int x = (int)(p % a.W); p /= a.W;
+        const int y = (int)(p % a.H);
+        const int b = (int)(p / a.H);
+        float v = ld((const T*)a.base + i);
+        for (int k = 0; k < a.n; ++k) {
+            const int sh = a.shift[k], hh = a.H >> sh, ww = a.W >> sh;
+            v += ld((const T*)a.t[k] + ((size_t)(b * hh + (y >> sh)) * ww + (x >> sh)) * a.C + c);
+        }
+        st((T*)a.dst + i, v > 0.f ? v : 0.f);
     }
-    st((T*)a.dst + i, v > 0.f ? v : 0.f);
 }
 
 // bf16 fast path: one lane = 8 channels (16 bytes) of one pixel; low-resolution terms are re-read by the 2^shift
@@ -1397,17 +1401,21 @@ __global__ __launch_bounds__(256) void upsum_bf16x8_kernel(UpsumArgs a) {
 }
 
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
-                 int batch, int h, int w, int c, int dtype, hipStream_t stream) {
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active) {
     UpsumArgs a;
     a.base = base; a.n = n_terms; a.dst = dst; a.H = h; a.W = w; a.C = c;
     for (int k = 0; k < 3; ++k) { a.t[k] = k < n_terms ? terms[k] : nullptr; a.shift[k] = k < n_terms ? shifts[k] : 0; }
     a.total = (long long)batch * h * w * c;
-    const unsigned blocks = (unsigned)((a.total + 255) / 256);
-    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(upsum_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+    a.n_active = n_active; a.per_sample = (long long)h * w * c;
+    if (a.total == 0) return TTUP_OK;
+    long long blocks = (a.total + 255) / 256;
+    if (n_active && blocks > 8192) blocks = 8192;             // grid-stride: the launch is sized for the largest batch
+    TTUP_REQUIRE(!n_active || dtype == TTUP_DTYPE_F32, TTUP_EINVAL, "upsum: a device-side batch is an fp32-path feature");
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(upsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (c % 8 == 0) {
         a.total /= 8;
         hipLaunchKernelGGL(upsum_bf16x8_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
-    } else hipLaunchKernelGGL(upsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+    } else hipLaunchKernelGGL(upsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -1452,27 +1460,31 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, in
 
 // head: 1x1 conv 16 -> n_out selected output channels (+bias), fp32 NCHW (B, n_out, H, W) out
 template <typename T, int CIN>
-__global__ void head_kernel(const T* src, const float* w, const float* bias, int n_out, float* heat, long long hw, long long npix) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
-    float x[CIN];
+__global__ void head_kernel(const T* src, const float* w, const float* bias, int n_out, float* heat, long long hw, long long npix_max, const int* n_active) {
+    const long long npix = n_active ? (hw * *n_active < npix_max ? hw * *n_active : npix_max) : npix_max;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        float x[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) x[c] = ld(src + i * CIN + c);
-    const long long b = i / hw, pix = i % hw;
-    for (int k = 0; k < n_out; ++k) {
-        float acc = 0.f;
+        for (int c = 0; c < CIN; ++c) x[c] = ld(src + i * CIN + c);
+        const long long b = i / hw, pix = i % hw;
+        for (int k = 0; k < n_out; ++k) {
+            float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) acc = fmaf(x[c], w[k * CIN + c], acc);
-        heat[(b * n_out + k) * hw + pix] = acc + bias[k];
+            for (int c = 0; c < CIN; ++c) acc = fmaf(x[c], w[k * CIN + c], acc);
+            heat[(b * n_out + k) * hw + pix] = acc + bias[k];
+        }
     }
 }
 
-int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin, int dtype, hipStream_t stream) {
+int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin, int dtype,
+                hipStream_t stream, const int* n_active) {
     TTUP_REQUIRE(cin == 16, TTUP_EINVAL, "head expects 16 input channels, got %d", cin);
     const long long hw = (long long)h * w, npix = (long long)batch * hw;
-    const unsigned blocks = (unsigned)((npix + 255) / 256);
-    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3(blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias_dev, n_out, heat, hw, npix);
-    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias_dev, n_out, heat, hw, npix);
+    if (npix == 0) return TTUP_OK;
+    long long blocks = (npix + 255) / 256;
+    if (n_active && blocks > 8192) blocks = 8192;
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active);
+    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
