@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-certify', action='store_true', help='plain bf16 argmax (no fp32 re-evaluation of near-ties)')
     ap.add_argument('--no-extras', action='store_true', help='skip the config 2/3/5 legs (cnn-only, uplift-only, generator)')
     return ap.parse_args()
 
@@ -59,10 +60,10 @@ def parse():
 class Pipeline:
     """Per-rank worker (upliftingtabletennis_amd.pipeline.StreamWorker) plus its resident synthetic clip."""
 
-    def __init__(self, device, seed):
+    def __init__(self, device, seed, certify=True):
         from upliftingtabletennis_amd import pipeline, synth, weights
         self.worker = pipeline.StreamWorker(device, weights.random_wasb_state_dict(0, planted=True), weights.random_uplift_state_dict(0, 'large'),
-                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=SEQ_LEN)
+                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=SEQ_LEN, certify=certify)
         self.net = self.worker.net
         # synthetic clip: 34 distinct frames tiled to TRIPLES+2 (keeps generation time low; content still varies per frame)
         base, track = synth.synth_frames(34, H_SRC, W_SRC, seed=seed)
@@ -252,7 +253,7 @@ def spawn_ranks(a):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__), '--gpus', str(a.gpus), '--steps', str(a.steps), '--warmup', str(a.warmup)]
-    cmd += ['--no-cpu-baseline'] * a.no_cpu_baseline + ['--no-roofline'] * a.no_roofline + ['--no-extras'] * a.no_extras
+    cmd += ['--no-cpu-baseline'] * a.no_cpu_baseline + ['--no-roofline'] * a.no_roofline + ['--no-extras'] * a.no_extras + ['--no-certify'] * a.no_certify
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '8')
@@ -306,7 +307,7 @@ def main():
         collective = {'backend': dist.get_backend(), 'ranks': int(ones.item()), 'world_size': dist.get_world_size()}
         if collective['ranks'] != world:
             raise SystemExit('bench.py: all_reduce saw %d of %d ranks' % (collective['ranks'], world))
-    pipe = Pipeline(device, seed=rank)
+    pipe = Pipeline(device, seed=rank, certify=not a.no_certify)
     for _ in range(a.warmup):
         pipe.step()
 
@@ -344,6 +345,12 @@ def main():
                                    'table-variant refine), cut into %d trajectories of up to %d detections (%d tokens) through the uplift transformer; '
                                    'random-init weights' % (TRIPLES, (TRIPLES + TRAJ_LEN - 1) // TRAJ_LEN, TRAJ_LEN, SEQ_LEN),
                        'frames_per_step_per_gpu': TRIPLES, 'parallelism': 'stream-per-gpu x%d, final gather' % world}}
+    if pipe.worker.certify:
+        cs = pipe.net.certify_stats()
+        line['certified_argmax'] = {'eps_abs': round(pipe.worker.certify_eps, 6), 'heatmaps': cs['heatmaps'], 'single_candidate': cs['single'],
+                                    'resolved_on_fp32_crops': cs['resolved'], 'not_certified': cs['not_certified'], 'crops': cs['crops'],
+                                    'fp32_full_frame_reruns': pipe.worker.fp32_reruns,
+                                    'note': 'every argmax index of the timed steps is the fp32 argmax (csrc/certify.hip); counts cover warm-up + timed steps'}
     if collective is not None:
         line['rccl_ranks'] = collective['ranks'] if collective['backend'] == 'nccl' else 0
         line['collective'] = collective

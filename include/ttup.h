@@ -108,6 +108,18 @@ int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_d
 int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
 int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, char* names_out,
                          int* n_ops_out, void* stream);
+/* Certified argmax for the bf16 ball detector (north_star: bit-exact heatmap argmax indices; reference
+ * balldetection/helper_balldetection.py:50 takes torch.argmax of the fp32 heatmap).  eps_abs bounds |bf16 heatmap - fp32 heatmap|
+ * (calibrated by the caller on its own frames; upliftingtabletennis_amd.wasb.WASBNet.calibrate).  Once set, every forward that
+ * returns peaks re-evaluates the pixels within 2*eps_abs of the bf16 maximum on fp32 receptive-field crops (crop x crop pixels,
+ * 0 = 168, the smallest that holds the 72-pixel receptive-field radius on both sides; at most max_crops_per_map per heatmap, 0 = 4) inside the same call, without host synchronisation, and returns the
+ * fp32 winner and its fp32 3x3 window.  eps_abs < 0 switches it off.  csrc/certify.hip.
+ * status (after a forward, per heatmap): 0 = one candidate (the bf16 index is certain), 1 = resolved on fp32 crops,
+ * 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned).
+ * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved, 0, 0}. */
+int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map);
+int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
+int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host8, int reset);
 /* micro-batch the handle was created with (TTUP_MICRO_BATCH) */
 int ttup_wasb_micro_batch(ttup_wasb* net);
 /* heatmap channels per sample returned by forward: 1 (ball) or 13 (table) */

@@ -156,3 +156,69 @@ def test_eval_path_callers(golden):
     assert np.abs(spin - ug[name + '/rot_local'][0]).max() <= 4e-4 * amp * np.abs(ug[name + '/rot_local'][0]).max()
     spin_g, _ = inference.process_trajectory_uplifting(up, ball, table, times, mask, 'local')
     assert np.abs(spin_g - ug[name + '/rot'][0]).max() <= 1e-4 * np.abs(ug[name + '/rot'][0]).max()
+
+
+@pytest.mark.parametrize('label,planted,eps', [('noise', False, 0.2), ('planted eps=1.0', True, 1.0), ('planted eps=0.2', True, 0.2)])
+def test_certified_argmax_agreement_64_frames(label, planted, eps):
+    """north_star: bit-exact heatmap argmax indices.  On 64 full-size triples per weight set (noise weights, and planted
+    weights whose noise part is NOT scaled down) the test reports the agreement rate of the raw bf16 argmax with the fp32
+    path's, and asserts that the certified argmax (candidates within 2*eps of the bf16 maximum re-evaluated on fp32
+    receptive-field crops inside the same call) agrees on EVERY frame -- index and 3x3 window bit for bit."""
+    n = 64
+    frames, _ = _clip(n + 2, seed=31)
+    fr = torch.from_numpy(frames).cuda()
+    sd = weights.random_wasb_state_dict(0, planted=planted, eps=eps)
+    net = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=n, dtype='bf16')
+    _, raw_idx, _ = net.forward_frames(fr)
+    raw_idx = raw_idx.clone()
+    eps_abs = net.calibrate(fr, n=4)
+    assert eps_abs > 0
+    _, idx, win = net.forward_frames(fr)
+    status = net.certify_status(n).cpu().numpy()
+    stats = net.certify_stats()
+    n_fixed = net.fix_uncertified(idx, win, frames_u8=fr)
+    twin = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=1, dtype='f32')
+    x = wasb.preprocess_triples(fr, (1280, 704))
+    ref_idx, ref_win = [], []
+    for k in range(n):
+        _, i1, w1 = twin.forward(x[k:k + 1], want_heatmap=False, want_peaks=True)
+        ref_idx.append(int(i1[0])); ref_win.append(w1[0].cpu().numpy())
+    ref_idx = np.array(ref_idx); ref_win = np.stack(ref_win)
+    raw_rate = float((raw_idx.cpu().numpy() == ref_idx).mean())
+    cert_rate = float((idx.cpu().numpy() == ref_idx).mean())
+    print('\n[%s] eps_abs %.4g; raw bf16 agreement %.3f, certified %.3f; status counts single/resolved/flagged = %d/%d/%d, crops %d, '
+          'candidates per resolved map %.1f, full-frame fp32 re-runs %d'
+          % (label, eps_abs, raw_rate, cert_rate, (status == 0).sum(), (status == 1).sum(), (status == 2).sum(), stats['crops'],
+             stats['candidates'] / max(1, stats['resolved']), n_fixed))
+    assert cert_rate == 1.0
+    # resolved (and re-run) maps carry the fp32 window bit for bit; single-candidate maps keep the bf16 window
+    exact = status != 0
+    assert np.array_equal(win.cpu().numpy()[exact], ref_win[exact])
+    assert stats['heatmaps'] == n and stats['single'] + stats['resolved'] + stats['not_certified'] == n
+
+
+def test_certified_argmax_small_and_switch_off(golden):
+    """Crop = whole image when the net is smaller than a crop; the float entry (`forward(x)`) certifies too; eps < 0 switches the
+    certification off and restores the plain bf16 outputs."""
+    g = golden('wasb_small.npz')
+    name = 'noise_96x160'
+    seed, planted, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, planted=bool(planted))
+    x = torch.from_numpy(np.random.default_rng(seed).standard_normal((b, 9, h, w)).astype(np.float32)).cuda()
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    _, i0, w0 = net.forward(x, want_heatmap=False, want_peaks=True)
+    net.set_certify(0.03 * float(g[name + '/heat'].max() - g[name + '/heat'].min()))
+    _, i1, w1 = net.forward(x, want_heatmap=False, want_peaks=True)
+    st = net.certify_status(b).cpu().numpy()
+    ok = st != 2                       # a noise heatmap can hold more than the 32 candidates kept per map: flagged, not resolved
+    assert (st == 1).any(), st
+    assert np.array_equal(i1.cpu().numpy()[ok], g[name + '/argmax'][ok])     # the reference's own argmax on noise weights
+    f32 = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='f32')
+    _, i2, w2 = f32.forward(x, want_heatmap=False, want_peaks=True)
+    res = torch.from_numpy(st == 1).cuda()
+    assert torch.equal(i1[res], i2[res]) and torch.equal(w1[res], w2[res])
+    net.set_certify(-1.0)
+    _, i3, w3 = net.forward(x, want_heatmap=False, want_peaks=True)
+    assert torch.equal(i3, i0) and torch.equal(w3, w0)
+    with pytest.raises(ValueError):
+        f32.set_certify(0.1)

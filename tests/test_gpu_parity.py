@@ -397,10 +397,24 @@ def test_stream_worker_pipelined_steps_equal_the_blocking_step():
     for a, b in zip(blocking, piped):
         for k in ('xyv', 'spin', 'pos3d', 'n_valid'):
             assert torch.equal(a[k], b[k]), k
-    heat, _, _ = worker.net.forward_frames(clips[0], want_heatmap=True)
-    ref = refine.extract_position_table(heat, 1920, 1080)[:, 0]
-    assert np.allclose(blocking[0]['xyv'].cpu().numpy(), ref, rtol=0, atol=1e-9)
     assert blocking[0]['xyv'].shape == (16, 3) and blocking[0]['pos3d'].shape == (2, 12, 3)
+    # the worker certifies its argmax on fp32 crops (csrc/certify.hip): heatmaps with a single candidate keep the bf16 window and
+    # equal a stand-alone heatmap -> extract_position run to the last bit
+    assert worker.certify and worker.certify_eps > 0
+    plain = pipeline.StreamWorker('cuda:0', weights.random_wasb_state_dict(5, planted=True), weights.random_uplift_state_dict(5, 'large'),
+                                  net_wh=(w, h), max_triples=20, traj_len=8, seq_len=12, certify=False)
+    heat, _, _ = plain.net.forward_frames(clips[0], want_heatmap=True)
+    ref = refine.extract_position_table(heat, 1920, 1080)[:, 0]
+    assert np.allclose(plain.process_clip(clips[0], table_px, 60.0)['xyv'].cpu().numpy(), ref, rtol=0, atol=1e-9)
+    worker.net.forward_frames(clips[0])
+    single = worker.net.certify_status(16).cpu().numpy() == 0
+    got = blocking[0]['xyv'].cpu().numpy()
+    assert np.allclose(got[single], ref[single], rtol=0, atol=1e-9)
+    # ... and the others equal the same run on the fp32 path (index and window are the fp32 ones)
+    f32 = wasb.WASBNet(weights.random_wasb_state_dict(5, planted=True), resolution=(w, h), max_batch=16, dtype='f32')
+    h32, _ = f32(wasb.preprocess_triples(clips[0], (w, h)))
+    ref32 = refine.extract_position_table(h32, 1920, 1080)[:, 0]
+    assert (~single).any() and np.allclose(got[~single], ref32[~single], rtol=0, atol=1e-9)
 
 
 # ------------------------------------------------------------------------------------------ edge cases: empty inputs

@@ -1,0 +1,316 @@
+// Certified argmax: the production CNN runs in bf16, the reference (balldetection/models/wasb.py, fp32) takes
+// `torch.argmax` of the fp32 heatmap (balldetection/helper_balldetection.py:50).  north_star asks for bit-exact argmax
+// indices, and bf16 rounding (|error| <= eps, a bound the caller calibrates against the fp32 path) can reorder pixels
+// whose fp32 values are closer than 2*eps.  So the index is made exact by construction instead of by luck:
+//
+//   1. scan      every pixel whose bf16 value is within 2*eps of the bf16 maximum is a candidate -- no other pixel can be
+//                the fp32 argmax.  One streaming pass over the fp32-stored heatmap (3.6 MB per frame, HBM-bound).
+//   2. plan      one candidate: certified as is.  Several: they are grouped into crops of `Hc x Wc` pixels whose origin is a
+//                multiple of 8 (the three stride-2 levels and the nearest-neighbour upsampling then sample exactly as in the
+//                full frame).  A heatmap pixel depends on the inputs within R = 72 pixels (measured receptive-field radius 71),
+//                so every candidate at least R inside its crop -- or next to a true image border, where the crop's zero padding
+//                IS the frame's -- gets bit for bit the value the fp32 path computes on the whole frame.
+//   3. crops     the selected windows are pre-processed again in fp32 from the uint8 frames and run through the SAME fp32
+//                graph (csrc/conv_f32.hip, the fp32 matrix pipe) as a small batch; everything is sized on the device
+//                (`n_active`), nothing synchronises with the host.
+//   4. resolve   the candidate with the largest fp32 value (ties -> smaller index, like torch.argmax) becomes the index,
+//                and its 3x3 window is taken from the fp32 crop, so the sub-pixel fit also sees fp32 values.
+// Heatmaps whose candidates overflow the budget (more than K candidates, more than `maxc` crops, crop list full) are
+// flagged 2 in `status`; the caller decides (the Python shim re-runs those frames on the full-frame fp32 handle).
+#include "wasb_net.h"
+
+namespace ttup {
+
+namespace {
+
+struct Best { float v; long long i; };
+__device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > bv || (v == bv && i < bi);
+}
+
+// ---- 1. candidates of each heatmap of a micro-batch: heat (n_maps, hw) fp32, argmax (n_maps)
+__global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict__ heat, const long long* __restrict__ argmax, long long hw,
+                                                        float two_eps, int K, int* __restrict__ cand_idx, int* __restrict__ cand_cnt) {
+    const int map = blockIdx.y;
+    const float* h = heat + (size_t)map * hw;
+    const float hmax = h[argmax[map]];
+    if (hmax != hmax) return;                 // NaN maximum: torch.argmax returns the first NaN, which the bf16 pass already did
+    const float thr = hmax - two_eps;
+    const long long quads = hw / 4;
+    const float4* h4 = (const float4*)h;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+        const float4 v = h4[q];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e[k] >= thr) {
+                const int slot = atomicAdd(&cand_cnt[map], 1);
+                if (slot < K) cand_idx[(size_t)map * K + slot] = (int)(q * 4 + k);
+            }
+    }
+}
+
+struct PlanArgs {
+    int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats;
+    int K, maxc, max_crops, H, W, Hc, Wc, R, map0;
+};
+
+// valid core of a crop along one axis: positions whose value AND 3x3 neighbourhood are exact
+__device__ __forceinline__ void core_range(int o, int c, int full, int R, int& lo, int& hi) {
+    lo = (o == 0) ? 0 : o + R + 1;
+    hi = (o + c == full) ? full : o + c - R - 1;
+}
+
+// ---- 2. one workgroup per heatmap; lane 0 sorts the (few) candidates and assigns them to crops
+__global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
+    if (threadIdx.x != 0) return;
+    const int map = a.map0 + blockIdx.x;
+    const int cnt = a.cand_cnt[map];
+    atomicAdd(&a.stats[0], 1ull);
+    if (cnt <= 1) { a.status[map] = 0; atomicAdd(&a.stats[1], 1ull); return; }
+    if (cnt > a.K) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+    int* ci = a.cand_idx + (size_t)map * a.K;
+    for (int i = 1; i < cnt; ++i) {             // insertion sort (the scan appends in arbitrary order)
+        const int v = ci[i];
+        int j = i - 1;
+        while (j >= 0 && ci[j] > v) { ci[j + 1] = ci[j]; --j; }
+        ci[j + 1] = v;
+    }
+    int my_crop[8], my_y0[8], my_x0[8], n_my = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const int cy = ci[k] / a.W, cx = ci[k] % a.W;
+        int found = -1;
+        for (int c = 0; c < n_my && found < 0; ++c) {
+            int ylo, yhi, xlo, xhi;
+            core_range(my_y0[c], a.Hc, a.H, a.R, ylo, yhi);
+            core_range(my_x0[c], a.Wc, a.W, a.R, xlo, xhi);
+            if (cy >= ylo && cy < yhi && cx >= xlo && cx < xhi) found = c;
+        }
+        if (found < 0) {
+            if (n_my >= a.maxc) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+            const int id = atomicAdd(a.n_crops, 1);
+            if (id >= a.max_crops) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+            int y0 = ((cy - a.Hc / 2) / 8) * 8, x0 = ((cx - a.Wc / 2) / 8) * 8;
+            y0 = y0 < 0 ? 0 : (y0 > a.H - a.Hc ? a.H - a.Hc : y0);
+            x0 = x0 < 0 ? 0 : (x0 > a.W - a.Wc ? a.W - a.Wc : x0);
+            my_crop[n_my] = id; my_y0[n_my] = y0; my_x0[n_my] = x0;
+            int* rec = a.crop_rec + 4 * id;
+            rec[0] = map; rec[1] = y0; rec[2] = x0; rec[3] = 0;
+            found = n_my++;
+            atomicAdd(&a.stats[4], 1ull);
+        }
+        a.cand_crop[(size_t)map * a.K + k] = my_crop[found];
+    }
+    a.status[map] = 1;
+    atomicAdd(&a.stats[2], 1ull);
+    atomicAdd(&a.stats[5], (unsigned long long)cnt);
+}
+
+__global__ void cert_active_kernel(const int* n_crops, int* n_active, int CH, int nchunks, int max_crops) {
+    const int c = threadIdx.x;
+    if (c >= nchunks) return;
+    int n = *n_crops;
+    n = n > max_crops ? max_crops : n;
+    int v = n - c * CH;
+    n_active[c] = v < 0 ? 0 : (v > CH ? CH : v);
+}
+
+// crop windows of a caller-supplied fp32 NCHW input (the `forward(x)` entry): -> fp32 NHWC16
+__global__ void cert_gather_kernel(const float* __restrict__ x, int in_ch, int H, int W, const int* __restrict__ crops, int crop0,
+                                   const int* __restrict__ n_active, int Hc, int Wc, float* __restrict__ out, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cx = (int)(i % Wc);
+    long long p = i / Wc;
+    const int cy = (int)(p % Hc);
+    const int j = (int)(p / Hc);
+    if (j >= *n_active) return;
+    const int* rec = crops + 4 * (crop0 + j);
+    const size_t hw = (size_t)H * W, pix = (size_t)(rec[1] + cy) * W + rec[2] + cx;
+    float* o = out + (size_t)i * 16;
+    for (int c = 0; c < 16; ++c) o[c] = c < in_ch ? x[((size_t)rec[0] * in_ch + c) * hw + pix] : 0.f;
+}
+
+// ---- 4a. fp32 value and 3x3 window of every candidate whose crop is in this chunk
+__global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ cand_crop,
+                                   const int* __restrict__ status, const int* __restrict__ crop_rec, const float* __restrict__ crop_heat,
+                                   int K, int H, int W, int Hc, int Wc, int crop0, int CH, int n_maps, float* __restrict__ cand_val, float* __restrict__ cand_win) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_maps * K) return;
+    const int map = i / K, k = i % K;
+    if (status[map] != 1 || k >= cand_cnt[map]) return;
+    const int id = cand_crop[i];
+    if (id < crop0 || id >= crop0 + CH) return;
+    const int* rec = crop_rec + 4 * id;
+    const int gy = cand_idx[i] / W, gx = cand_idx[i] % W;
+    const float* h = crop_heat + (size_t)(id - crop0) * Hc * Wc;
+    cand_val[i] = h[(size_t)(gy - rec[1]) * Wc + (gx - rec[2])];
+    for (int t = 0; t < 9; ++t) {
+        const int y = gy + t / 3 - 1, x = gx + t % 3 - 1;
+        float v = 0.f;                        // zero padding outside the IMAGE (helper_balldetection.py:55-64)
+        if (y >= 0 && y < H && x >= 0 && x < W) v = h[(size_t)(y - rec[1]) * Wc + (x - rec[2])];
+        cand_win[(size_t)i * 9 + t] = v;
+    }
+}
+
+// ---- 4b. the fp32 winner of every heatmap that needed crops
+__global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ status,
+                                    const float* __restrict__ cand_val, const float* __restrict__ cand_win, int K, int n_maps,
+                                    long long* __restrict__ argmax, float* __restrict__ win) {
+    const int map = blockIdx.x * blockDim.x + threadIdx.x;
+    if (map >= n_maps || status[map] != 1) return;
+    const int cnt = cand_cnt[map];
+    float bv = cand_val[(size_t)map * K];
+    long long bi = cand_idx[(size_t)map * K];
+    int bk = 0;
+    for (int k = 1; k < cnt; ++k) {
+        const float v = cand_val[(size_t)map * K + k];
+        const long long i = cand_idx[(size_t)map * K + k];
+        if (better(v, i, bv, bi)) { bv = v; bi = i; bk = k; }
+    }
+    argmax[map] = bi;
+    for (int t = 0; t < 9; ++t) win[(size_t)map * 9 + t] = cand_win[((size_t)map * K + bk) * 9 + t];
+}
+
+}  // namespace
+
+void cert_free(ttup_wasb* net) {
+    CertState& c = net->cert;
+    if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
+    void* ptrs[] = {c.cand_idx, c.cand_cnt, c.cand_crop, c.cand_val, c.cand_win, c.crop_rec, c.n_crops, c.n_active, c.status, c.stats, c.crop_heat};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    c.cand_idx = c.cand_cnt = c.cand_crop = c.crop_rec = c.n_crops = c.n_active = c.status = nullptr;
+    c.cand_val = c.cand_win = c.crop_heat = nullptr; c.stats = nullptr;
+    c.enabled = false;
+}
+
+int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
+    CertState& c = net->cert;
+    TTUP_HIP_CHECK(hipMemsetAsync(c.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(c.n_crops, 0, sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(c.status, 0, (size_t)batch * sizeof(int), caller));
+    return TTUP_OK;
+}
+
+int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0, int mb, hipStream_t st) {
+    CertState& c = net->cert;
+    const long long hw = (long long)net->H * net->W;
+    int nblk = (int)(hw / 4 / 256 / 8);           // 8 float4 per thread
+    nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+    hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
+                       c.cand_idx + (size_t)b0 * c.K, c.cand_cnt + b0);
+    TTUP_LAUNCH_CHECK();
+    PlanArgs a;
+    a.cand_idx = c.cand_idx; a.cand_cnt = c.cand_cnt; a.cand_crop = c.cand_crop; a.crop_rec = c.crop_rec; a.n_crops = c.n_crops;
+    a.status = c.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.max_crops;
+    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0;
+    hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int batch,
+                int64_t* argmax_dev, float* win_dev, hipStream_t st) {
+    CertState& c = net->cert;
+    ttup_wasb* cn = c.cropnet;
+    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, c.n_crops, c.n_active, c.CH, c.nchunks, c.max_crops);
+    TTUP_LAUNCH_CHECK();
+    // chunks that can hold crops of THIS call: at most maxc per heatmap
+    int nch = cdiv(batch * c.maxc < c.max_crops ? batch * c.maxc : c.max_crops, c.CH);
+    nch = nch > c.nchunks ? c.nchunks : nch;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int crop0 = ch * c.CH;
+        const int* na = c.n_active + ch;
+        cn->use_lane(0);
+        float* xin = (float*)cn->tensors[cn->t_input].ptr;
+        if (frames_dev) {
+            const int rc = launch_preprocess_crops(frames_dev, n_frames, src_h, src_w, net->H, net->W, xin, c.crop_rec, crop0, na, c.CH, c.Hc, c.Wc, net->in_ch / 3, st);
+            if (rc) return rc;
+        } else {
+            const long long total = (long long)c.CH * c.Hc * c.Wc;
+            hipLaunchKernelGGL(cert_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x_dev, net->in_ch, net->H, net->W,
+                               (const int*)c.crop_rec, crop0, na, c.Hc, c.Wc, xin, total);
+            TTUP_LAUNCH_CHECK();
+        }
+        cn->n_active = na;
+        int rc = run_ops(cn, c.CH, st);
+        if (rc == TTUP_OK) rc = launch_head(cn->tensors[cn->t_out].ptr, cn->head_w_dev, cn->head_b_dev, 1, c.crop_heat, c.CH, c.Hc, c.Wc, 16, TTUP_DTYPE_F32, st, na);
+        cn->n_active = nullptr;
+        if (rc) return rc;
+        const int nthr = batch * c.K;
+        hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)c.cand_idx, (const int*)c.cand_cnt, (const int*)c.cand_crop,
+                           (const int*)c.status, (const int*)c.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch,
+                           c.cand_val, c.cand_win);
+        TTUP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch, 64)), dim3(64), 0, st, (const int*)c.cand_idx, (const int*)c.cand_cnt, (const int*)c.status,
+                       (const float*)c.cand_val, (const float*)c.cand_win, c.K, batch, (long long*)argmax_dev, win_dev);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+}  // namespace ttup
+
+using namespace ttup;
+
+int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, int micro, int lanes, ttup_wasb** out);
+
+extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map) {
+    TTUP_REQUIRE(net, TTUP_EINVAL, "ttup_wasb_set_certify: null handle");
+    if (eps_abs < 0.f) { (void)hipDeviceSynchronize(); cert_free(net); return TTUP_OK; }
+    TTUP_REQUIRE(net->dtype == TTUP_DTYPE_BF16 && net->fused_head && net->n_out == 1, TTUP_EINVAL,
+                 "ttup_wasb_set_certify: the certified argmax applies to the bf16 ball detector (one heatmap per sample)");
+    TTUP_REQUIRE(eps_abs == eps_abs && crop >= 0 && max_crops_per_map >= 0 && max_crops_per_map <= 8, TTUP_EINVAL, "ttup_wasb_set_certify: bad argument");
+    CertState& c = net->cert;
+    if (c.enabled) { c.eps = eps_abs; if (crop == 0 && max_crops_per_map == 0) return TTUP_OK; }
+    (void)hipDeviceSynchronize();
+    cert_free(net);
+    c.eps = eps_abs;
+    c.maxc = max_crops_per_map > 0 ? max_crops_per_map : 4;
+    int side = crop > 0 ? crop : 168;
+    TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 24, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 24);
+    c.Hc = side < net->H ? side : net->H;
+    c.Wc = side < net->W ? side : net->W;
+    c.CH = net->max_batch < 64 ? net->max_batch : 64;
+    c.max_crops = net->max_batch > c.CH ? net->max_batch : c.CH;           // one crop per heatmap on average; the overflow is flagged
+    c.nchunks = cdiv(c.max_crops, c.CH);
+    TTUP_REQUIRE(c.nchunks <= 64, TTUP_EINVAL, "ttup_wasb_set_certify: max_batch %d too large", net->max_batch);
+    c.max_crops = c.nchunks * c.CH;
+    const size_t nb = (size_t)net->max_batch;
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_idx, nb * c.K * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_cnt, nb * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_crop, nb * c.K * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_val, nb * c.K * sizeof(float)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_win, nb * c.K * 9 * sizeof(float)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.n_crops, sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.n_active, (size_t)c.nchunks * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.status, nb * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.stats, 8 * sizeof(unsigned long long)));
+    TTUP_HIP_CHECK(hipMemset(c.stats, 0, 8 * sizeof(unsigned long long)));
+    TTUP_HIP_CHECK(hipMemset(c.status, 0, nb * sizeof(int)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * c.Hc * c.Wc * sizeof(float)));
+    const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
+    if (rc) { cert_free(net); return rc; }
+    c.enabled = true;
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream) {
+    TTUP_REQUIRE(net && status_dev, TTUP_EINVAL, "ttup_wasb_certify_status: null pointer");
+    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_status: the certified argmax is not enabled on this handle");
+    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_certify_status: batch %d outside [0,%d]", batch, net->max_batch);
+    TTUP_HIP_CHECK(hipMemcpyAsync(status_dev, net->cert.status, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host, int reset) {
+    TTUP_REQUIRE(net && out_host, TTUP_EINVAL, "ttup_wasb_certify_stats: null pointer");
+    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_stats: the certified argmax is not enabled on this handle");
+    TTUP_HIP_CHECK(hipDeviceSynchronize());
+    TTUP_HIP_CHECK(hipMemcpy(out_host, net->cert.stats, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (reset) TTUP_HIP_CHECK(hipMemset(net->cert.stats, 0, 8 * sizeof(long long)));
+    return TTUP_OK;
+}

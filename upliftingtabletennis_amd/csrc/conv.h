@@ -73,4 +73,8 @@ int launch_head(const void* src, const float* w_dev, const float* bias_dev, int 
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
                       void* out, int out_layout, int dtype, int first_triple, int n_triples, int frames_per_sample, hipStream_t stream);
 
+int launch_preprocess_crops(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w, float* out,
+                            const int* crops_dev, int crop0, const int* n_active_dev, int max_crops, int crop_h, int crop_w,
+                            int frames_per_sample, hipStream_t stream);
+
 }  // namespace ttup

@@ -1497,6 +1497,9 @@ struct PreArgs {
     double scale_x, scale_y;
     int nf;                // frames per sample: 3 (ball triples t,t+1,t+2) or 1 (table detector, single frame)
     const float* lut;      // [3][256]: (v/255 - mean[c]) / std[c] evaluated in fp64 on the host, rounded to fp32
+    // crop mode (certified argmax): output sample j is the crop_h x crop_w window at (y0, x0) of triple `map`, records
+    // {map, y0, x0, -} at crops[4*(crop0+j)], only the first *n_active samples are produced
+    const int* crops; const int* n_active; int crop0, crop_h, crop_w;
 };
 
 __device__ __forceinline__ int cv_round(float v) { return (int)rintf(v); }
@@ -1524,10 +1527,24 @@ __global__ void preprocess_kernel(PreArgs a) {
     // one thread per (sample, y, x): produces the 3*nf channels of that pixel
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
-    const int x = (int)(i % a.dst_w);
-    long long p = i / a.dst_w;
-    const int y = (int)(p % a.dst_h);
-    const int t = (int)(p / a.dst_h);
+    int x, y, t;
+    size_t opix;                        // output pixel index (sample-major)
+    if (a.crops) {
+        const int cx = (int)(i % a.crop_w);
+        long long p = i / a.crop_w;
+        const int cy = (int)(p % a.crop_h);
+        const int j = (int)(p / a.crop_h);
+        if (j >= *a.n_active) return;
+        const int* rec = a.crops + 4 * (a.crop0 + j);
+        t = rec[0]; y = rec[1] + cy; x = rec[2] + cx;
+        opix = ((size_t)j * a.crop_h + cy) * a.crop_w + cx;
+    } else {
+        x = (int)(i % a.dst_w);
+        long long p = i / a.dst_w;
+        y = (int)(p % a.dst_h);
+        t = (int)(p / a.dst_h);
+        opix = ((size_t)t * a.dst_h + y) * a.dst_w + x;
+    }
     const bool same = a.src_h == a.dst_h && a.src_w == a.dst_w;
     int x0 = x, x1 = x, a0 = 2048, a1 = 0, y0 = y, y1 = y, b0 = 2048, b1 = 0;
     if (!same) {
@@ -1574,7 +1591,7 @@ __global__ void preprocess_kernel(PreArgs a) {
         float* o = (float*)a.out + (size_t)t * 3 * a.nf * hw + pix;
         for (int c = 0; c < 3 * a.nf; ++c) o[c * hw] = vals[c];
     } else {
-        T* o = (T*)a.out + ((size_t)t * hw + pix) * 16;
+        T* o = (T*)a.out + opix * 16;
         if (sizeof(T) == 2) {
             u32x4* o4 = (u32x4*)o;
             o4[0] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
@@ -1594,6 +1611,7 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     a.first_triple = first_triple; a.n_triples = n_triples; a.layout = out_layout; a.nf = frames_per_sample;
     a.total = (long long)n_triples * dst_h * dst_w;
     a.scale_x = (double)src_w / dst_w; a.scale_y = (double)src_h / dst_h;
+    a.crops = nullptr; a.n_active = nullptr; a.crop0 = 0; a.crop_h = 0; a.crop_w = 0;
     if (a.total == 0) return TTUP_OK;
     if (int rc = device_normalise_lut(&a.lut)) return rc;       // one table per device
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
@@ -1601,6 +1619,23 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
         hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+// crop mode: fp32 NHWC16 windows of the pre-processed triples, chosen on the device (csrc/certify.hip)
+int launch_preprocess_crops(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w, float* out,
+                            const int* crops_dev, int crop0, const int* n_active_dev, int max_crops, int crop_h, int crop_w,
+                            int frames_per_sample, hipStream_t stream) {
+    PreArgs a;
+    a.frames = frames; a.out = out; a.src_h = src_h; a.src_w = src_w; a.dst_h = dst_h; a.dst_w = dst_w;
+    a.first_triple = 0; a.n_triples = n_frames - frames_per_sample + 1; a.layout = TTUP_LAYOUT_NHWC16; a.nf = frames_per_sample;
+    a.total = (long long)max_crops * crop_h * crop_w;
+    a.scale_x = (double)src_w / dst_w; a.scale_y = (double)src_h / dst_h;
+    a.crops = crops_dev; a.n_active = n_active_dev; a.crop0 = crop0; a.crop_h = crop_h; a.crop_w = crop_w;
+    if (a.total == 0) return TTUP_OK;
+    if (int rc = device_normalise_lut(&a.lut)) return rc;
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }

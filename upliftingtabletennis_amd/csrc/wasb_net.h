@@ -1,0 +1,88 @@
+// Internal definition of the CNN handle (ttup_wasb): a static op list over NHWC buffers, shared by csrc/wasb_net.hip (graph
+// construction, forward) and csrc/certify.hip (certified argmax).  Not part of the C ABI.
+#pragma once
+#include "conv.h"
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ttup {
+size_t upsum_head_ws_bytes(int n_maps, int H, int W);
+int launch_upsum_head(const void* base, const void* const* terms, const int* shifts, int n_terms, const float* w_dev, float bias,
+                      float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
+int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
+
+struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
+
+struct Op {
+    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD, STEM } kind = CONV;
+    int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
+    int conv = -1;            // index into packed convs
+    int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output; CONV: fused 1x1 follower (conv2) -> dst2
+    int src0 = -1, src1 = -1, residual = -1, dst = -1;
+    int relu = 0;
+    int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
+};
+
+// Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle
+struct CertState {
+    bool enabled = false;
+    float eps = 0.f;                     // bound on |bf16 heatmap - fp32 heatmap| (absolute, calibrated by the caller)
+    int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
+    int K = 32;                          // candidates kept per heatmap
+    int maxc = 4;                        // crops per heatmap
+    int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
+    struct ::ttup_wasb* cropnet = nullptr;  // fp32 handle at crop size, batch CH
+    int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
+    int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
+    unsigned long long* stats = nullptr;
+    float* crop_heat = nullptr;
+};
+}  // namespace ttup
+
+struct ttup_wasb {
+    int H = 0, W = 0, max_batch = 0, dtype = 0, micro = 1, in_ch = 9;
+    std::vector<ttup::PackedConv> convs;
+    std::vector<ttup::Tensor> tensors;
+    std::vector<ttup::Op> ops;
+    std::map<std::string, int> taps;
+    int t_input = -1, t_out = -1;
+    float* head_w_dev = nullptr; float* head_b_dev = nullptr; float head_bias = 0.f;
+    int n_out = 1;                      // heatmap channels returned: 1 (ball: channel 1 of 3, wasb.py:606) or all 13 (table, hrnet.py:586-589)
+    float* heat_scratch = nullptr;      // (micro,H,W) when the caller does not want heatmaps
+    void* refine_ws = nullptr; size_t refine_ws_bytes = 0;
+    long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
+    int last_batch = 0;
+    bool fused_head = false;      // last op computes the heatmap and the argmax partials itself (bf16 path)
+    const int* n_active = nullptr;      // fp32 crop net of the certified argmax: device-side batch of the current pass
+    std::vector<char> blob;             // the weight blob the handle was created from (the certified argmax builds its fp32 twin from it)
+    ttup::CertState cert;
+    // Lanes: independent micro-batches alternate between `lanes.size()` internal streams, each with its own activation
+    // and scratch buffers, so one micro-batch's kernel tails and launch gaps are filled by the other's kernels.
+    // `tensors[i].ptr` and the scratch pointers above always alias the lane in use (use_lane).
+    struct Lane {
+        std::vector<void*> ptr;
+        float* heat_scratch = nullptr; void* refine_ws = nullptr; long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t fork = nullptr;
+
+    void use_lane(int l) {
+        const Lane& L = lanes[l];
+        for (size_t i = 0; i < tensors.size(); ++i) tensors[i].ptr = L.ptr[i];
+        heat_scratch = L.heat_scratch; refine_ws = L.refine_ws; argmax_scratch = L.argmax_scratch; win_scratch = L.win_scratch;
+    }
+    size_t esize() const { return dtype == TTUP_DTYPE_F32 ? 4 : 2; }
+    ~ttup_wasb();
+};
+
+namespace ttup {
+int run_ops(ttup_wasb* net, int mb, hipStream_t st);
+// certified argmax (csrc/certify.hip)
+void cert_free(ttup_wasb* net);
+int cert_begin(ttup_wasb* net, int batch, hipStream_t caller);                                   // reset per-call state
+int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0, int mb, hipStream_t st);   // candidates + crop plan of one micro-batch
+int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int batch,
+                int64_t* argmax_dev, float* win_dev, hipStream_t caller);                        // fp32 crops, resolve
+}  // namespace ttup

@@ -9,35 +9,13 @@
 //   * stage-4 fused outputs 1..3 (only consumed when classify_invisible=True, never set by get_model,
 //     balldetection/train.py:268) and head channels 0 and 2 (dropped at wasb.py:606) are not computed;
 //   * the batch is processed in micro-batches so that intermediate tensors stay near the Infinity Cache.
-#include "conv.h"
+#include "wasb_net.h"
 #include <string.h>
-#include <map>
 #include <memory>
-#include <string>
-#include <vector>
-
-namespace ttup {
-size_t upsum_head_ws_bytes(int n_maps, int H, int W);
-int launch_upsum_head(const void* base, const void* const* terms, const int* shifts, int n_terms, const float* w_dev, float bias,
-                      float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
-int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
-}
 
 using namespace ttup;
 
 namespace {
-
-struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
-
-struct Op {
-    enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD, STEM } kind = CONV;
-    int chain[4] = {-1, -1, -1, -1}, n_chain = 0;          // BB_CHAIN: packed conv indices
-    int conv = -1;            // index into packed convs
-    int conv2 = -1, conv3 = -1, dst2 = -1;     // BNECK_TRANS: transition convs and second output; CONV: fused 1x1 follower (conv2) -> dst2
-    int src0 = -1, src1 = -1, residual = -1, dst = -1;
-    int relu = 0;
-    int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
-};
 
 const int STAGE_CH[4] = {16, 32, 64, 128};
 
@@ -48,56 +26,25 @@ struct BlobReader {
 
 }  // namespace
 
-struct ttup_wasb {
-    int H = 0, W = 0, max_batch = 0, dtype = 0, micro = 1, in_ch = 9;
-    std::vector<PackedConv> convs;
-    std::vector<Tensor> tensors;
-    std::vector<Op> ops;
-    std::map<std::string, int> taps;
-    int t_input = -1, t_out = -1;
-    float* head_w_dev = nullptr; float* head_b_dev = nullptr; float head_bias = 0.f;
-    int n_out = 1;                      // heatmap channels returned: 1 (ball: channel 1 of 3, wasb.py:606) or all 13 (table, hrnet.py:586-589)
-    float* heat_scratch = nullptr;      // (micro,H,W) when the caller does not want heatmaps
-    void* refine_ws = nullptr; size_t refine_ws_bytes = 0;
-    long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
-    int last_batch = 0;
-    bool fused_head = false;      // last op computes the heatmap and the argmax partials itself (bf16 path)
-    // Lanes: independent micro-batches alternate between `lanes.size()` internal streams, each with its own activation
-    // and scratch buffers, so one micro-batch's kernel tails and launch gaps are filled by the other's kernels.
-    // `tensors[i].ptr` and the scratch pointers above always alias the lane in use (use_lane).
-    struct Lane {
-        std::vector<void*> ptr;
-        float* heat_scratch = nullptr; void* refine_ws = nullptr; long long* argmax_scratch = nullptr; float* win_scratch = nullptr;
-        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    };
-    std::vector<Lane> lanes;
-    hipEvent_t fork = nullptr;
-
-    void use_lane(int l) {
-        const Lane& L = lanes[l];
-        for (size_t i = 0; i < tensors.size(); ++i) tensors[i].ptr = L.ptr[i];
-        heat_scratch = L.heat_scratch; refine_ws = L.refine_ws; argmax_scratch = L.argmax_scratch; win_scratch = L.win_scratch;
+ttup_wasb::~ttup_wasb() {
+    cert_free(this);
+    for (auto& c : convs) free_conv(&c);
+    if (lanes.empty()) {       // construction failed before the lanes were set up
+        for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
     }
-    size_t esize() const { return dtype == TTUP_DTYPE_F32 ? 4 : 2; }
-    ~ttup_wasb() {
-        for (auto& c : convs) free_conv(&c);
-        if (lanes.empty()) {       // construction failed before the lanes were set up
-            for (auto& t : tensors) if (t.ptr) (void)hipFree(t.ptr);
-        }
-        for (auto& L : lanes) {
-            for (void* q : L.ptr) if (q) (void)hipFree(q);
-            if (L.heat_scratch) (void)hipFree(L.heat_scratch);
-            if (L.refine_ws) (void)hipFree(L.refine_ws);
-            if (L.argmax_scratch) (void)hipFree(L.argmax_scratch);
-            if (L.win_scratch) (void)hipFree(L.win_scratch);
-            if (L.stream) (void)hipStreamDestroy(L.stream);
-            if (L.done) (void)hipEventDestroy(L.done);
-        }
-        if (fork) (void)hipEventDestroy(fork);
-        if (head_w_dev) (void)hipFree(head_w_dev);
-        if (head_b_dev) (void)hipFree(head_b_dev);
+    for (auto& L : lanes) {
+        for (void* q : L.ptr) if (q) (void)hipFree(q);
+        if (L.heat_scratch) (void)hipFree(L.heat_scratch);
+        if (L.refine_ws) (void)hipFree(L.refine_ws);
+        if (L.argmax_scratch) (void)hipFree(L.argmax_scratch);
+        if (L.win_scratch) (void)hipFree(L.win_scratch);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.done) (void)hipEventDestroy(L.done);
     }
-};
+    if (fork) (void)hipEventDestroy(fork);
+    if (head_w_dev) (void)hipFree(head_w_dev);
+    if (head_b_dev) (void)hipFree(head_b_dev);
+}
 
 namespace {
 
@@ -367,7 +314,7 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             ConvLaunch l;
             l.src0 = s.ptr; l.src1 = op.src1 >= 0 ? net->tensors[op.src1].ptr : nullptr;
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
-            l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu;
+            l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu; l.n_active = net->n_active;
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
             if (rc) return rc;
@@ -394,14 +341,14 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             const Tensor& d = net->tensors[op.dst];
             const void* terms[3] = {nullptr, nullptr, nullptr};
             for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
-            const int rc = launch_upsum(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, d.ptr, mb, d.h, d.w, d.c, net->dtype, st);
+            const int rc = launch_upsum(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, d.ptr, mb, d.h, d.w, d.c, net->dtype, st, net->n_active);
             if (rc) return rc;
         }
     }
     return TTUP_OK;
 }
 
-int run_ops(ttup_wasb* net, int mb, hipStream_t st) {
+int run_graph(ttup_wasb* net, int mb, hipStream_t st) {
     for (const Op& op : net->ops) { const int rc = run_op(net, op, mb, st); if (rc) return rc; }
     return TTUP_OK;
 }
@@ -426,16 +373,20 @@ int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev,
     if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
     else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, net->in_ch / 3, st);
     if (rc) return rc;
-    rc = run_ops(net, mb, st);
+    rc = run_graph(net, mb, st);
     if (rc) return rc;
     float* heat = heat_dev ? heat_dev + (size_t)b0 * K * hw : net->heat_scratch;
     if (net->fused_head) {
         const bool peaks = argmax_dev || win_dev;
         long long* am = peaks ? (argmax_dev ? (long long*)argmax_dev + b0 : net->argmax_scratch) : nullptr;
         float* wn = peaks ? (win_dev ? win_dev + (size_t)b0 * 9 : net->win_scratch) : nullptr;
-        return run_head_op(net, mb, heat, am, wn, st);
+        rc = run_head_op(net, mb, heat, am, wn, st);
+        if (rc) return rc;
+        // certified argmax: pixels within 2*eps of this bf16 maximum are the only ones that can be the fp32 argmax
+        if (net->cert.enabled && argmax_dev && win_dev) return cert_scan(net, heat, am, b0, mb, st);
+        return TTUP_OK;
     }
-    rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st);
+    rc = launch_head(net->tensors[net->t_out].ptr, net->head_w_dev, net->head_b_dev, K, heat, mb, H, W, 16, net->dtype, st, net->n_active);
     if (rc) return rc;
     if (argmax_dev || win_dev) {
         long long* am = argmax_dev ? (long long*)argmax_dev + (size_t)b0 * K : net->argmax_scratch;
@@ -451,6 +402,8 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
     const int n_micro = (batch + net->micro - 1) / net->micro;
     const int n_lanes = n_micro < (int)net->lanes.size() ? (n_micro > 0 ? n_micro : 1) : (int)net->lanes.size();
     const hipStream_t caller = st;
+    const bool certify = net->cert.enabled && net->fused_head && argmax_dev && win_dev && batch > 0;
+    if (certify) { const int rc = cert_begin(net, batch, caller); if (rc) return rc; }
     if (n_lanes > 1) {
         TTUP_HIP_CHECK(hipEventRecord(net->fork, caller));
         for (int l = 0; l < n_lanes; ++l) TTUP_HIP_CHECK(hipStreamWaitEvent(net->lanes[l].stream, net->fork, 0));
@@ -470,13 +423,19 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
     net->use_lane(last_lane);
     if (rc_all) return rc_all;
     net->last_batch = batch < net->micro ? batch : net->micro;
+    if (certify) return cert_finish(net, x_dev, frames_dev, n_frames, src_h, src_w, batch, argmax_dev, win_dev, caller);
     return TTUP_OK;
 }
 
 }  // namespace
 
+namespace ttup {
+int run_ops(ttup_wasb* net, int mb, hipStream_t st) { return run_graph(net, mb, st); }
+}
 
-extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, ttup_wasb** out) {
+// micro_override / lanes_override > 0 fix the micro-batch and the lane count (the certified argmax's fp32 crop net runs its
+// whole batch as one micro-batch on one lane); 0 = TTUP_MICRO_BATCH / TTUP_LANES or the defaults
+int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, int micro_override, int lanes_override, ttup_wasb** out) {
     TTUP_REQUIRE(blob && out, TTUP_EINVAL, "ttup_wasb_create: null pointer");
     TTUP_REQUIRE(height > 0 && width > 0 && height % 8 == 0 && width % 8 == 0, TTUP_EINVAL,
                  "ttup_wasb_create: input size %dx%d must be positive multiples of 8", height, width);
@@ -493,10 +452,11 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     TTUP_REQUIRE((in_ch == 9 || in_ch == 3) && head_out >= 1 && head_out <= 16, TTUP_EFORMAT, "wasb blob: in_ch=%d head_out=%d unsupported (ball detector 9/3, table detector 3/13)", in_ch, head_out);
     std::unique_ptr<ttup_wasb> net(new ttup_wasb);
     net->H = height; net->W = width; net->max_batch = max_batch; net->dtype = dtype; net->in_ch = in_ch;
+    net->blob.assign((const char*)blob, (const char*)blob + blob_bytes);
     net->n_out = head_out == 3 ? 1 : head_out;       // ball detector keeps the middle of its 3 channels (wasb.py:606)
     // micro-batch: enough tiles to fill 256 CUs, small enough that layer outputs stay cache-friendly
     const char* env = getenv("TTUP_MICRO_BATCH");
-    int micro = env ? atoi(env) : 8;
+    int micro = micro_override > 0 ? micro_override : (env ? atoi(env) : 8);
     if (micro < 1) micro = 1;
     net->micro = micro < max_batch ? micro : max_batch;
     rc = build(net.get(), folded);
@@ -516,7 +476,7 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     if (upsum_head_ws_bytes(net->micro, height, width) > net->refine_ws_bytes) net->refine_ws_bytes = upsum_head_ws_bytes(net->micro, height, width);
     {
         const char* le = getenv("TTUP_LANES");
-        int n_lanes = le ? atoi(le) : 2;
+        int n_lanes = lanes_override > 0 ? lanes_override : (le ? atoi(le) : 2);
         const int n_micro = (max_batch + net->micro - 1) / net->micro;
         if (n_lanes > n_micro) n_lanes = n_micro;
         if (n_lanes < 1) n_lanes = 1;
@@ -545,6 +505,10 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     TTUP_HIP_CHECK(hipDeviceSynchronize());
     *out = net.release();
     return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, ttup_wasb** out) {
+    return ttup_wasb_create_internal(blob, blob_bytes, height, width, max_batch, dtype, 0, 0, out);
 }
 
 extern "C" void ttup_wasb_destroy(ttup_wasb* net) {

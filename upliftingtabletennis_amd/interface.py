@@ -97,13 +97,30 @@ class BallDetector:
                 fr = torch.from_numpy(np.stack([np.asarray(i) for i in imgs])).to(self.device)   # (3,h,w,3) uint8
                 xs.append(wasb.preprocess_triples(fr, (w, h)))
             x = torch.cat(xs)
-            heat, _ = self.model(x)
-            pos = refine.extract_position_table(heat, self.resolution[0], self.resolution[1])   # table variant, interface.py:116
-            pred_pos.append(pos[:, 0])
+            self._calibrate(x=x)
+            # peaks from the certified argmax (the fp32 index the reference's torch.argmax returns), table-variant fit (interface.py:116)
+            heat, idx, win = self.model.forward(x, want_heatmap=True, want_peaks=True)
+            if self.model.certified:
+                self.model.fix_uncertified(idx, win, x=x)
+            pos = refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
+            pred_pos.append(pos.cpu().numpy())
             preds.append(heat.cpu().numpy())
         if not pred_pos:
             return np.zeros((0, 3)), np.zeros((0, 1, h, w), np.float32)
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
+
+    def _calibrate(self, frames=None, x=None):
+        """Certified argmax (csrc/certify.hip): the bf16 path's error bound is measured once, on the first input this detector
+        sees, against the fp32 path; from then on every returned index is the fp32 argmax."""
+        if self.model.certified or self.model.dtype != 'bf16' or os.environ.get('TTUP_NO_CERTIFY') == '1':
+            return
+        if frames is None:
+            hb, _ = self.model.forward(x[:2])
+            twin = self.model._twin()
+            err = max(float((hb[k] - twin.forward(x[k:k + 1])[0][0]).abs().max().item()) for k in range(hb.shape[0]))
+            self.model.set_certify(1.5 * err)
+        else:
+            self.model.calibrate(frames, n=2)
 
     def predict_clip(self, images):
         """Fast path for consecutive frames (what TableTennisPipeline.predict feeds the detector, interface.py:276-279):
@@ -118,7 +135,10 @@ class BallDetector:
         step = self.max_batch                      # triples per call; consecutive calls overlap by two frames
         for t0 in range(0, n - 2, step):
             fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[t0:t0 + step + 2]])).to(self.device)
+            self._calibrate(frames=fr)
             _, idx, win = self.model.forward_frames(fr, want_heatmap=False)
+            if self.model.certified:
+                self.model.fix_uncertified(idx, win, frames_u8=fr)
             out.append(refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE).cpu().numpy())
         return np.concatenate(out, axis=0)
 

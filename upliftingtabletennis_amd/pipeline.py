@@ -62,7 +62,7 @@ class StreamWorker:
     Raises RuntimeError without a HIP device (no CPU fallback)."""
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
-                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16'):
+                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True):
         from . import glue, refine, uplift, wasb, _lib
         _lib.require_gpu()
         self._glue, self._refine, self._uplift, self._lib = glue, refine, uplift, _lib
@@ -72,12 +72,34 @@ class StreamWorker:
         self.net = wasb.WASBNet(wasb_state_dict, resolution=net_wh, max_batch=max_triples, dtype=dtype, device=self.device)
         self.up = uplift.get_model('connectstage', uplift_size, 'dynamic', 'new', state_dict=uplift_state_dict,
                                    max_batch=max(64, (max_triples + traj_len - 1) // traj_len), max_len=seq_len, device=self.device)
+        # certified argmax (bit-exact fp32 indices from the bf16 path, csrc/certify.hip): calibrated on the first clip seen
+        self.certify = bool(certify) and dtype == 'bf16'
+        self.certify_eps = None
+        self.fp32_reruns = 0
 
     def detect(self, frames_u8):
         """(N,h,w,3) uint8 on the device -> (N-2,3) float64 [x, y, visibility] in 1920x1080 px (table-variant refine,
         like interface.py:116)."""
+        return self._detect(frames_u8)[0]
+
+    def _detect(self, frames_u8):
+        if self.certify and self.certify_eps is None:
+            self.certify_eps = self.net.calibrate(frames_u8, n=4)
         _, idx, win = self.net.forward_frames(frames_u8, want_heatmap=False)
-        return self._refine.refine_windows_device(idx, win, self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
+        xyv = self._refine.refine_windows_device(idx, win, self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
+        status = self.net.certify_status(idx.shape[0]) if self.certify else None
+        return xyv, idx, win, status
+
+    def _repair(self, frames_u8, xyv, idx, win, status_host):
+        """Rare slow path: heatmaps the certified argmax could not settle inside its crop budget are re-run on the full-frame
+        fp32 handle, so that every detection comes from the fp32 argmax."""
+        bad = np.nonzero(status_host == 2)[0]
+        if bad.size == 0:
+            return xyv
+        self.fp32_reruns += self.net.fix_uncertified(idx, win, frames_u8=frames_u8)
+        sel = torch.as_tensor(bad, device=self.device)
+        xyv[sel] = self._refine.refine_windows_device(idx[sel], win[sel], self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
+        return xyv
 
     def uplift_segments(self, positions, table_px, fps):
         """Cut the detections into rallies of `traj_len` frames, filter / normalise / pad each like the reference
@@ -95,7 +117,9 @@ class StreamWorker:
         return spin, p3, mask.sum(1).to(torch.int64).to(self.device)
 
     def process_clip(self, frames_u8, table_px, fps):
-        xyv = self.detect(frames_u8)
+        xyv, idx, win, status = self._detect(frames_u8)
+        if status is not None:
+            xyv = self._repair(frames_u8, xyv, idx, win, status.cpu().numpy())
         spin, p3, nvalid = self.uplift_segments(xyv.cpu().numpy(), table_px, fps)
         return {'xyv': xyv, 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
 
@@ -104,7 +128,7 @@ class StreamWorker:
     # and enqueues the uplift.  Submitting clip k+1 before collecting clip k keeps the GPU busy while the host filters
     # and pads the detections of clip k.
     def submit(self, frames_u8):
-        xyv = self.detect(frames_u8)
+        xyv, idx, win, status = self._detect(frames_u8)
         ring = self.__dict__.setdefault('_pinned', {})          # two pinned buffers per shape, used alternately
         slot = ring.setdefault(tuple(xyv.shape), {'bufs': [None, None], 'next': 0})
         i = slot['next']; slot['next'] = 1 - i
@@ -112,12 +136,22 @@ class StreamWorker:
             slot['bufs'][i] = torch.empty(xyv.shape, dtype=xyv.dtype, pin_memory=True)
         host = slot['bufs'][i]
         host.copy_(xyv, non_blocking=True)
+        st_host = None
+        if status is not None:
+            st_host = slot.setdefault('status', [None, None])
+            if st_host[i] is None:
+                st_host[i] = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+            st_host = st_host[i]
+            st_host.copy_(status, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return {'xyv': xyv, 'host': host, 'done': done}
+        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host}
 
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
+        if ticket.get('status') is not None and (ticket['status'].numpy() == 2).any():
+            ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], ticket['status'].numpy())
+            ticket['host'].copy_(ticket['xyv'])
         # the uplift (about a hundred small launches for a handful of trajectories) runs on a side stream, so it shares
         # the GPU with the detector of the clip submitted in the meantime instead of queueing behind it
         side = self.__dict__.get('_side')

@@ -28,6 +28,9 @@ class WASBNet:
         self.max_batch = int(max_batch)
         self.dtype = dtype
         self._lib = _lib.load()
+        self._state_dict = state_dict            # kept for the fp32 twin of the certified argmax (calibrate / fix_uncertified)
+        self._f32_twin = None
+        self.certified = False
         blob = weights.pack_wasb_blob(state_dict, in_ch=self.IN_CH, head_out=self.HEAD_OUT)
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -95,6 +98,70 @@ class WASBNet:
                                                     _lib.ptr(heat), _lib.ptr(idx), _lib.ptr(win), _lib.stream_ptr())
         _lib.check(rc)
         return heat, idx, win
+
+    # ---- certified argmax (csrc/certify.hip): bit-exact fp32 argmax indices from the bf16 path
+    def set_certify(self, eps_abs, crop=0, max_crops_per_map=0):
+        """eps_abs bounds |bf16 heatmap - fp32 heatmap|; < 0 switches the certification off."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_set_certify(self._handle, float(eps_abs), int(crop), int(max_crops_per_map)))
+        self.certified = eps_abs >= 0
+        self.eps = float(eps_abs)
+
+    def _twin(self):
+        if self._f32_twin is None:
+            self._f32_twin = type(self)(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='f32', device=self.device) \
+                if type(self) is not WASBNet else WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='f32', device=self.device)
+        return self._f32_twin
+
+    def calibrate(self, frames_u8, n=4, safety=1.5, crop=0, max_crops_per_map=0):
+        """Measure the bf16 path's heatmap error against the fp32 path on the first `n` triples of `frames_u8` (uint8 (N,h,w,3)
+        device tensor) and enable the certified argmax with eps = safety * max |error|.  Returns eps."""
+        frames_u8 = frames_u8.to(self.device)
+        n = max(1, min(n, frames_u8.shape[0] - 2, self.max_batch))
+        was = self.certified
+        if was:
+            self.set_certify(-1.0)
+        hb, _, _ = self.forward_frames(frames_u8[:n + 2], want_heatmap=True)
+        x = preprocess_triples(frames_u8[:n + 2], (self.W, self.H))
+        twin = self._twin()
+        err = 0.0
+        for k in range(n):
+            hf, _ = twin.forward(x[k:k + 1])
+            err = max(err, float((hb[k] - hf[0]).abs().max().item()))
+        eps = safety * err
+        self.set_certify(eps, crop, max_crops_per_map)
+        return eps
+
+    def certify_status(self, batch):
+        """Per-heatmap status of the last forward: 0 single candidate, 1 resolved on fp32 crops, 2 not certified."""
+        st = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_certify_status(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
+        return st
+
+    def certify_stats(self, reset=False):
+        out = np.zeros(8, np.int64)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_certify_stats(self._handle, out.ctypes.data_as(ctypes.c_void_p), 1 if reset else 0))
+        return dict(heatmaps=int(out[0]), single=int(out[1]), resolved=int(out[2]), not_certified=int(out[3]), crops=int(out[4]), candidates=int(out[5]))
+
+    def fix_uncertified(self, idx, win, frames_u8=None, x=None):
+        """Heatmaps the certified argmax flagged 2 (candidate / crop budget exceeded) are re-run on the full-frame fp32 path, so that
+        every returned index is the fp32 argmax.  Give the call's input: the uint8 clip (`forward_frames`) or the float tensor
+        (`forward`).  Synchronises; returns the number of frames re-run."""
+        if idx.shape[0] > self.max_batch:
+            raise ValueError('fix_uncertified covers one forward call of at most max_batch=%d heatmaps' % self.max_batch)
+        st = self.certify_status(idx.shape[0]).cpu().numpy()
+        bad = np.nonzero(st == 2)[0]
+        if bad.size:
+            twin = self._twin()
+            for t in bad:
+                t = int(t)
+                xt = x[t:t + 1] if x is not None else preprocess_triples(frames_u8[t:t + 3].to(self.device), (self.W, self.H))
+                _, i1, w1 = twin.forward(xt, want_heatmap=False, want_peaks=True)
+                idx[t] = i1[0]
+                win[t] = w1[0]
+        return int(bad.size)
 
     def read_tap(self, name, batch=1):
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
