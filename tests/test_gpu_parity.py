@@ -285,8 +285,11 @@ def test_fused_kernels_match_layerwise():
         f, p = fused.read_tap(tap, b), plain.read_tap(tap, b)
         scale = p.abs().max().item()
         assert (f - p).abs().max().item() <= 2.0 ** -5 * scale, (tap, (f - p).abs().max().item(), scale)
-        # a bf16 rounding flip early on moves a few downstream values by one bf16 step each: bounded share, tiny mean
-        assert (f != p).float().mean().item() <= 0.25, (tap, (f != p).float().mean().item())
+        # a bf16 rounding flip early on moves a few downstream values by one bf16 step each: bounded share, tiny mean.
+        # stage2_1 / stage3_2 are fuse-layer sums that the fused path finishes in the epilogue of the last stride-2 conv
+        # (fp32 accumulator + terms, ONE rounding) where the layer-wise path rounds the conv output first: more one-step flips
+        share = 0.5 if tap in ('stage2_1', 'stage3_2') else 0.25
+        assert (f != p).float().mean().item() <= share, (tap, (f != p).float().mean().item())
         assert (f - p).abs().mean().item() <= 1e-3 * scale, (tap, (f - p).abs().mean().item(), scale)
     scale = (h2.max() - h2.min()).item()
     # (each bf16 path is within 4% of the fp32 reference heatmap range; against each other they stay within 2%)

@@ -32,6 +32,8 @@ struct ConvLaunch {
     int relu = 0;
     const PackedConv* follow = nullptr;   // bf16 only: fused 1x1 follower (64 -> 32, ReLU) applied to dst, written to dst2
     void* dst2 = nullptr;
+    const void* res2 = nullptr;           // bf16 stride-2 convs: further fuse-layer terms added before the ReLU (same resolution /
+    const void* res3 = nullptr; int sh3 = 0;   // 1/2^sh3 resolution, nearest-neighbour upsampled), wasb.py:236-243
     const int* n_active = nullptr;        // f32 only: device-side batch (<= batch) decided by an earlier kernel (csrc/certify.hip)
 };
 

@@ -46,6 +46,9 @@ struct ConvKArgs {
     int relu;
     // fused 1x1 follower (F11): dst11 = relu(W11 . dst + b11), 64 -> 32 channels
     const bf16_t* w11; const float* bias11; bf16_t* dst11;
+    // further fuse-layer terms added in the epilogue (wasb.py:236-243): res2 at the output resolution (the branch's own
+    // tensor), res3 at 1/2^sh3 of it (a 1x1-conv'd lower branch, nearest-neighbour upsampled), both COUT channels
+    const bf16_t* res2; const bf16_t* res3; int sh3;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r];
-            if (a.residual) {
-                const u32x2* rp = (const u32x2*)(a.residual + o);
+            auto add_term = [&](const bf16_t* base) {
+                const u32x2* rp = (const u32x2*)base;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const u32x2 rv = rp[m];
@@ -238,7 +241,10 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                     v[m * 4 + 2] += bf16_to_f32((bf16_t)(rv.y & 0xffff));
                     v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
                 }
-            }
+            };
+            if (a.residual) add_term(a.residual + o);
+            if (a.res2) add_term(a.res2 + o);
+            if (a.res3) add_term(a.res3 + ((size_t)(b * (a.OH >> a.sh3) + (oy >> a.sh3)) * (a.OW >> a.sh3) + (ox >> a.sh3)) * COUT + g * 4 * MT);
             unsigned pk[2 * MT];
 #pragma unroll
             for (int i = 0; i < 2 * MT; ++i) pk[i] = pack2(v[2 * i], v[2 * i + 1]);
@@ -1276,6 +1282,7 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     a.tiles_x = cdiv(a.OW, TW);
     a.relu = l.relu;
     a.w11 = nullptr; a.bias11 = nullptr; a.dst11 = nullptr;
+    a.res2 = (const bf16_t*)l.res2; a.res3 = (const bf16_t*)l.res3; a.sh3 = l.sh3;
     if (F11) {
         TTUP_REQUIRE(l.follow && l.follow->cout == 32 && l.follow->cin_total == 64 && l.follow->k == 1 && l.follow->ck == 32 && l.dst2, TTUP_EINVAL, "conv: bad fused 1x1 follower");
         a.w11 = (const bf16_t*)l.follow->w_dev; a.bias11 = l.follow->bias_dev; a.dst11 = (bf16_t*)l.dst2;
@@ -1315,6 +1322,7 @@ static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t s
 
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t st) {
     if (dtype == TTUP_DTYPE_F32) {
+        TTUP_REQUIRE(!l.res2 && !l.res3, TTUP_EINVAL, "conv: extra fuse-layer terms are a bf16-path fusion");
         static const bool direct = getenv("TTUP_F32_DIRECT") != nullptr;         // cross-check of the matrix-pipe kernel
         if (!direct && conv_f32_mfma_supported(p)) return launch_conv_f32_mfma(p, l, st);
         TTUP_REQUIRE(!l.n_active, TTUP_EINVAL, "conv: a device-side batch needs the matrix-pipe fp32 kernel");
@@ -1330,6 +1338,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         TTUP_LAUNCH_CHECK();
         return TTUP_OK;
     }
+    TTUP_REQUIRE(!(l.res2 || l.res3) || (p.stride == 2 && !l.follow), TTUP_EINVAL, "conv: extra fuse-layer terms ride on the stride-2 chain convs only");
     if (l.follow) {
         TTUP_REQUIRE(p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64, TTUP_EINVAL, "conv: fused follower needs a 3x3 s1 conv with 64 outputs");
         return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);

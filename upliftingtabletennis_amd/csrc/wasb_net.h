@@ -22,6 +22,7 @@ struct Op {
     int src0 = -1, src1 = -1, residual = -1, dst = -1;
     int relu = 0;
     int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
+    int res2 = -1, res3 = -1, sh3 = 0;          // CONV (bf16, stride 2): fuse-layer terms folded into the epilogue
 };
 
 // Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle

@@ -168,7 +168,11 @@ struct Builder {
             int acc = -1;
             bool acc_is_xi = false;
             std::vector<int> up_t; std::vector<int> up_s;
+            int last_chain_op = -1;               // index in net->ops of the conv that completes the running sum (j = i-1 chain)
+            // emission order: the 1x1 convs of the lower branches (j > i) first, so that a later conv's epilogue can add them
+            for (int pass = 0; pass < 2; ++pass)
             for (int j = 0; j < nb; ++j) {
+                if ((pass == 0) != (j > i)) continue;
                 if (j == i) {
                     if (acc < 0) { acc = xs[i]; acc_is_xi = true; }
                     else {
@@ -208,12 +212,33 @@ struct Builder {
                         Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = cur; op.dst = dst; op.relu = last ? 0 : 1;
                         if (last && acc >= 0) op.residual = acc;
                         net->ops.push_back(op);
+                        if (last) last_chain_op = (int)net->ops.size() - 1;
                         cur = dst;
                     }
                     acc = cur; acc_is_xi = false;
                 }
             }
             (void)acc_is_xi;
+            // the reference adds the terms in branch order j (wasb.py:236-243): x_i (shift 0) before the upsampled lower branches
+            for (size_t k = 1; k < up_t.size(); ++k)
+                for (size_t q = k; q > 0 && up_s[q] < up_s[q - 1]; --q) { std::swap(up_s[q], up_s[q - 1]); std::swap(up_t[q], up_t[q - 1]); }
+            // bf16: y_i = relu(chains + x_i + up(...)) finishes in the epilogue of the last chain conv (one same-resolution term
+            // and one upsampled term fit): the element-wise pass over the branch disappears
+            if (fuse && i > 0 && last_chain_op >= 0 && up_t.size() <= 2 && net->ops[last_chain_op].dst == acc) {
+                int same = -1, upt = -1, ups = 0;
+                bool ok = true;
+                for (size_t k = 0; k < up_t.size(); ++k) {
+                    if (up_s[k] == 0 && same < 0) same = up_t[k];
+                    else if (up_s[k] > 0 && upt < 0) { upt = up_t[k]; ups = up_s[k]; }
+                    else ok = false;
+                }
+                if (ok) {
+                    Op& lc = net->ops[last_chain_op];
+                    lc.res2 = same; lc.res3 = upt; lc.sh3 = ups; lc.relu = 1;
+                    outs.push_back(lc.dst);
+                    continue;
+                }
+            }
             // y = relu(acc + sum of upsampled / late identity terms)
             const int dst = new_tensor(xi.c, xi.h, xi.w);
             Op op; op.kind = Op::UPSUM; op.src0 = acc; op.dst = dst; op.n_terms = (int)up_t.size();
@@ -316,6 +341,8 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu; l.n_active = net->n_active;
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
+            if (op.res2 >= 0) l.res2 = net->tensors[op.res2].ptr;
+            if (op.res3 >= 0) { l.res3 = net->tensors[op.res3].ptr; l.sh3 = op.sh3; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
             if (rc) return rc;
         } else if (op.kind == Op::STEM) {
