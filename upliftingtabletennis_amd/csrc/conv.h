@@ -54,9 +54,18 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
 int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedConv& p6, const void* a2, const void* t2,
                        void* b0, void* b1, int batch, int h, int w, hipStream_t st);
 
-// fused chain of 1 or 2 BasicBlocks (2 or 4 3x3 convs, C = 16 or 32) of one branch, bf16 only (csrc/conv.hip)
+// fused chain of 1 or 2 BasicBlocks (2 or 4 3x3 convs, C = 16 or 32) of one branch, bf16 only (csrc/conv.hip).
+// BBSum (16-channel two-block chain only): the fuse-layer sum that consumes the branch, computed in the epilogue of the last
+// conv -- ysum = relu(y + sum_k up(terms[k], 2^shifts[k])); with `heat` set the sum is not stored: the 1x1 head and the
+// per-tile argmax partial (pv / pi [map * bb_chain_tiles_per_img + tile]) are computed from it in registers, and y may be null.
+struct BBSum {
+    const void* terms[3] = {nullptr, nullptr, nullptr}; int shifts[3] = {0, 0, 0}; int n_terms = 0;
+    void* ysum = nullptr;
+    float* heat = nullptr; const float* head_w = nullptr; float head_bias = 0.f; float* pv = nullptr; long long* pi = nullptr;
+};
+int bb_chain_tiles_per_img(int h, int w);
 int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
-                    const PackedConv* follow, void* y_follow, hipStream_t st);
+                    const PackedConv* follow, void* y_follow, hipStream_t st, const BBSum* sum = nullptr);
 
 // y = relu(base + sum_k nearest_upsample(t_k, 2^shift_k)); all NHWC with c channels; base at (h,w).
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,

@@ -835,7 +835,20 @@ struct BBArgs {
     // optional 1x1 follower on the chain output (C=32 -> 16, BN folded, no ReLU: the fuse-layer conv of wasb.py:189-205 that
     // feeds the higher-resolution branch): one extra MFMA per 16-pixel group on the bf16 pairs just packed
     const bf16_t* wf; const float* bf; bf16_t* yf;
+    // C=16 two-block chain at full resolution: the fuse-layer sum that consumes the branch (wasb.py:236-243) rides in the last
+    // conv's epilogue: ysum = relu(y + sum_k up(st[k], 2^ssh[k])).  With `heat` set the sum is the stage-4 output: it is not
+    // stored at all, the 1x1 head (final_layers[0] channel 1, wasb.py:484,606) is applied to it in registers and the workgroup
+    // leaves its argmax partial (pv/pi[map * nblk + tile]); y itself (the pre-fuse branch tensor) is only stored when a.y is set.
+    const bf16_t* st[3]; int ssh[3]; int nsum; bf16_t* ysum;
+    float* heat; const float* hw; float hbias; float* pv; long long* pi;
 };
+
+struct BBBest { float v; long long i; };
+__device__ __forceinline__ bool bb_better(float v, long long i, float bv, long long bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > bv || (v == bv && i < bi);
+}
 
 // element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
 // with bits 1..2 of the column (conflict-free ds_read_b128, see lds_off).  C=16 (32 B per pixel) flips the two chunks with
@@ -855,7 +868,8 @@ template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
 template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
-                                        const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr) {
+                                        const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
+                                        const BBArgs* ex = nullptr, BBBest* best = nullptr) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
@@ -898,6 +912,9 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     bf16x8 af_f = {};
     f32x4 bias_f = {0.f, 0.f, 0.f, 0.f};
     if (CAN_FOLLOW && yf) { af_f = *(const bf16x8*)(wf + lane * 8); bias_f = *(const f32x4*)(bfp + g * 4); }
+    constexpr bool CAN_SUM = GLOBAL_OUT && C == 16;
+    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
+    if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
     for (int y = wave; y < RHO; y += 8) {
         const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
         const bf16_t* rp0 = row + n * C;
@@ -908,6 +925,27 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         if (RES_MFMA && g >= 2) {
             const bf16_t* rr = s_res + ((y + ROFF) * RWR + ROFF) * C + (((g & 1) ^ (((n + ROFF) >> 2) & 1)) << 3);
             rq0 = rr + n * C; rql = rr + (XLAST + nl) * C;
+        }
+        // fused fuse-layer sum: the (few) upsampled terms of this row's pixels are requested BEFORE the MFMA loop, so that
+        // their L2 / HBM latency hides behind the matrix work instead of stalling the epilogue
+        u32x2 tpre[XT][3];
+        if constexpr (CAN_SUM) {
+            if (ex && ex->nsum > 0) {
+                const int gyp = gy0 + y;
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+                    const int gxp = gx0 + xt * 16 + n;
+                    const bool livep = gyp >= 0 && gyp < H && gxp >= 0 && gxp < W && !(xt == XT - 1 && xt * 16 + n >= RWO);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        tpre[xt][k] = u32x2{0u, 0u};
+                        if (k < ex->nsum && livep) {
+                            const int sh = ex->ssh[k];
+                            tpre[xt][k] = *(const u32x2*)(ex->st[k] + ((size_t)(b * (H >> sh) + (gyp >> sh)) * (W >> sh) + (gxp >> sh)) * 16 + g * 4);
+                        }
+                    }
+                }
+            }
         }
         f32x4 acc[XT][MT];
 #pragma unroll
@@ -956,10 +994,55 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
             }
             if (GLOBAL_OUT) {
-                if (inside && valid) {
+                if (inside && valid && gout) {
                     bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
                     if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                     else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                }
+                if constexpr (CAN_SUM) {
+                    if (ex && (ex->nsum > 0 || ex->heat)) {
+                        // fuse-layer sum on the rounded block output, exactly what the element-wise pass read back from memory
+                        float ys[4] = {bf16_to_f32((bf16_t)(pk[0] & 0xffff)), bf16_to_f32((bf16_t)(pk[0] >> 16)),
+                                       bf16_to_f32((bf16_t)(pk[1] & 0xffff)), bf16_to_f32((bf16_t)(pk[1] >> 16))};
+                        // stage-4 tail: neither the branch tensor nor the sum is stored, so neither is rounded to bf16 -- the head
+                        // sees the fp32 values (two roundings fewer right in front of the heatmap: a smaller bf16-path error)
+                        const bool exact_tail = ex->heat && !gout && !ex->ysum;
+                        if (exact_tail) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ys[r] = v[r] > 0.f ? v[r] : 0.f;
+                        }
+                        const bool live = inside && valid;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            if (k >= ex->nsum) continue;
+                            const u32x2 tv = tpre[xt][k];
+                            ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
+                            ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
+                        }
+                        const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
+                        if (ex->ysum && live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
+                        if (ex->heat) {
+                            // head on the bf16-rounded sum: this lane's 4 channels, then across the 4 lane groups of the pixel
+                            float hy[4] = {bf16_to_f32((bf16_t)(q0 & 0xffff)), bf16_to_f32((bf16_t)(q0 >> 16)),
+                                           bf16_to_f32((bf16_t)(q1 & 0xffff)), bf16_to_f32((bf16_t)(q1 >> 16))};
+                            if (exact_tail) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) hy[r] = ys[r] > 0.f ? ys[r] : 0.f;
+                            }
+                            float part = hy[0] * hw4[0];
+                            part = fmaf(hy[1], hw4[1], part);
+                            part = fmaf(hy[2], hw4[2], part);
+                            part = fmaf(hy[3], hw4[3], part);
+                            part += __shfl_xor(part, 16, 64);
+                            part += __shfl_xor(part, 32, 64);
+                            const float hv = part + ex->hbias;
+                            if (live && g == 0) {
+                                const long long e = (long long)gy * W + gx;
+                                ex->heat[(size_t)b * H * W + e] = hv;
+                                if (bb_better(hv, e, best->v, best->i)) { best->v = hv; best->i = e; }
+                            }
+                        }
+                    }
                 }
                 if constexpr (CAN_FOLLOW) {
                     if (yf) {          // lane (n, g) holds channels 8g..8g+7 of its pixel = k-group g of the follower's only k-step
@@ -1101,7 +1184,27 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
     bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
     __syncthreads();
     TTUP_STAMP(5);
-    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
+    BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
+    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
+                                                             nullptr, nullptr, nullptr, &a, &best);
+    if (C == 16 && a.heat) {
+        // argmax partial of this tile: lanes -> wave (DPP shuffles) -> workgroup (through the now idle LDS)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_down(best.v, off, 64);
+            const long long oi = __shfl_down(best.i, off, 64);
+            if (bb_better(ov, oi, best.v, best.i)) { best.v = ov; best.i = oi; }
+        }
+        __syncthreads();                      // every wave is done with bufA / bufB
+        float* sv = (float*)smem; long long* si = (long long*)(smem + 64);
+        if (lane == 0) { sv[wave] = best.v; si[wave] = best.i; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < 8; ++k) if (bb_better(sv[k], si[k], best.v, best.i)) { best.v = sv[k]; best.i = si[k]; }
+            a.pv[(size_t)b * a.tiles_per_img + tt] = best.v;
+            a.pi[(size_t)b * a.tiles_per_img + tt] = best.i;
+        }
+    }
     TTUP_STAMP(6);
 #ifdef TTUP_TIMING
     if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz ticks for the same span
@@ -1140,13 +1243,39 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     return TTUP_OK;
 }
 
+// tile of the C=16 two-block chain (TTUP_BB2_TILE=THxTW picks one of the compiled shapes: tuning aid)
+static void bb2_tile(int* th, int* tw) {
+    static int sth = 0, stw = 0;
+    if (!sth) {
+        int a = 24, b = 32;
+        const char* e = getenv("TTUP_BB2_TILE");
+        if (e && sscanf(e, "%dx%d", &a, &b) != 2) { a = 24; b = 32; }
+        const int ok[][2] = {{24, 32}, {24, 26}, {26, 26}, {20, 26}, {16, 26}, {24, 42}, {26, 42}};
+        bool found = false;
+        for (auto& o : ok) found = found || (o[0] == a && o[1] == b);
+        if (!found) { a = 24; b = 32; }
+        stw = b; sth = a;
+    }
+    *th = sth; *tw = stw;
+}
+int bb_chain_tiles_per_img(int h, int w) { int th, tw; bb2_tile(&th, &tw); return cdiv(w, tw) * cdiv(h, th); }
+
 int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
-                    const PackedConv* follow, void* y_follow, hipStream_t st) {
+                    const PackedConv* follow, void* y_follow, hipStream_t st, const BBSum* sum) {
     TTUP_REQUIRE(n_convs == 2 || n_convs == 4, TTUP_EINVAL, "bb_chain: 2 or 4 convs expected");
     const int c = convs[0]->cout;
     BBArgs a;
     a.x = (const bf16_t*)x; a.y = (bf16_t*)y;
     a.wf = nullptr; a.bf = nullptr; a.yf = nullptr;
+    a.nsum = 0; a.ysum = nullptr; a.heat = nullptr; a.hw = nullptr; a.hbias = 0.f; a.pv = nullptr; a.pi = nullptr;
+    for (int k = 0; k < 3; ++k) { a.st[k] = nullptr; a.ssh[k] = 0; }
+    if (sum) {
+        TTUP_REQUIRE(c == 16 && n_convs == 4 && sum->n_terms >= 0 && sum->n_terms <= 3, TTUP_EINVAL, "bb_chain: the fused fuse-layer sum rides on the 16-channel two-block chain");
+        TTUP_REQUIRE(sum->ysum || (sum->heat && sum->head_w && sum->pv && sum->pi), TTUP_EINVAL, "bb_chain: fused sum needs an output");
+        a.nsum = sum->n_terms; a.ysum = (bf16_t*)sum->ysum;
+        for (int k = 0; k < sum->n_terms; ++k) { a.st[k] = (const bf16_t*)sum->terms[k]; a.ssh[k] = sum->shifts[k]; }
+        a.heat = sum->heat; a.hw = sum->head_w; a.hbias = sum->head_bias; a.pv = sum->pv; a.pi = sum->pi;
+    }
     if (follow) {
         TTUP_REQUIRE(c == 32 && n_convs == 2 && follow->cout == 16 && follow->cin_total == 32 && follow->k == 1 && follow->ck == 32 && y_follow, TTUP_EINVAL,
                      "bb_chain: the fused follower is a 1x1 32->16 conv on a 32-channel block");
@@ -1159,7 +1288,16 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
     // tile shapes tuned on MI355X: larger tiles amortise the per-tile overhead and waste fewer ragged 16-pixel MFMA groups
-    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
+    if (c == 16 && n_convs == 4) {
+        int th, tw; bb2_tile(&th, &tw);
+        if (th == 24 && tw == 26) return launch_bb2_t<16, 24, 26>(a, batch, h, w, st);
+        if (th == 26 && tw == 26) return launch_bb2_t<16, 26, 26>(a, batch, h, w, st);
+        if (th == 20 && tw == 26) return launch_bb2_t<16, 20, 26>(a, batch, h, w, st);
+        if (th == 16 && tw == 26) return launch_bb2_t<16, 16, 26>(a, batch, h, w, st);
+        if (th == 24 && tw == 42) return launch_bb2_t<16, 24, 42>(a, batch, h, w, st);
+        if (th == 26 && tw == 42) return launch_bb2_t<16, 26, 42>(a, batch, h, w, st);
+        return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
+    }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);

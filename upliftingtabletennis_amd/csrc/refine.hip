@@ -199,6 +199,12 @@ int launch_upsum_head(const void* base, const void* const* terms, const int* shi
     return TTUP_OK;
 }
 
+int launch_argmax_finish(const float* heat, int n_maps, int H, int W, int nblk, const float* pv, const long long* pi, long long* argmax, float* win, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(n_maps), dim3(64), 0, st, heat, H, W, nblk, pv, pi, argmax, win);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 static int pick_nblk(int n_maps, long long hw) {
     long long nblk = 2048 / (n_maps > 0 ? n_maps : 1);
     const long long cap = hw / 4096 > 0 ? hw / 4096 : 1;     // at least 16 KB per workgroup

@@ -11,6 +11,7 @@ size_t upsum_head_ws_bytes(int n_maps, int H, int W);
 int launch_upsum_head(const void* base, const void* const* terms, const int* shifts, int n_terms, const float* w_dev, float bias,
                       float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
 int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_argmax_finish(const float* heat, int n_maps, int H, int W, int nblk, const float* pv, const long long* pi, long long* argmax, float* win, hipStream_t st);
 
 struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
 
@@ -23,6 +24,10 @@ struct Op {
     int relu = 0;
     int terms[3] = {-1, -1, -1}, shifts[3] = {0, 0, 0}, n_terms = 0;   // UPSUM
     int res2 = -1, res3 = -1, sh3 = 0;          // CONV (bf16, stride 2): fuse-layer terms folded into the epilogue
+    // BB_CHAIN (16 channels, 4 convs) with the consuming fuse-layer sum in its epilogue: terms/shifts/n_terms as for UPSUM,
+    // dst2 = the summed output; head = 1: stage-4 output, never stored -- the 1x1 head + argmax partials are computed from it
+    // (launched by run_head_op, which knows the output buffers); dst = -1 when the pre-fuse branch tensor has no consumer
+    int head = 0;
 };
 
 // Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle

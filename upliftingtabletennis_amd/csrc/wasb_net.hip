@@ -132,21 +132,31 @@ struct Builder {
         const int t = conv(x, c, 3, 1, 1);
         return conv(t, c, 3, 1, 1, /*residual*/ x);
     }
-    int bb_chain(int x, int n_convs) {      // n_convs/2 BasicBlocks fused (bf16 path)
+    Op bb_chain_op(int x, int n_convs, bool need_dst) {      // n_convs/2 BasicBlocks fused (bf16 path); not yet in the op list
         const Tensor s = net->tensors[x];
         Op op; op.kind = Op::BB_CHAIN; op.src0 = x; op.n_chain = n_convs;
         for (int i = 0; i < n_convs; ++i) op.chain[i] = pack(next(s.c, s.c, 3, 1), nullptr, s.c);
-        op.dst = new_tensor(s.c, s.h, s.w);
+        op.dst = need_dst ? new_tensor(s.c, s.h, s.w) : -1;
+        return op;
+    }
+    int bb_chain(int x, int n_convs) {
+        const Op op = bb_chain_op(x, n_convs, true);
         net->ops.push_back(op);
         return op.dst;
     }
     // HighResolutionModule (wasb.py:227-245); returns fused outputs 0..n_out-1
-    std::vector<int> stage(std::vector<int> xs, int n_out) {
+    std::vector<int> stage(std::vector<int> xs, int n_out, bool head_mode = false) {
         const int nb = (int)xs.size();
         const bool fuse = net->dtype == TTUP_DTYPE_BF16 && !getenv("TTUP_NO_FUSE");
+        // the full-resolution branch's fuse-layer sum rides in the epilogue of its two-block chain, which is therefore emitted
+        // AFTER the lower branches and their 1x1 fuse convs (deferred below); its weights are still consumed in reference order
+        const bool fuse_sum = fuse && !getenv("TTUP_NO_FUSE_SUM") && net->tensors[xs[0]].c == 16;
+        Op deferred; bool has_deferred = false;
+        const int x0_in = xs[0];
         for (int b = 0; b < nb; ++b) {
             const Tensor xt = net->tensors[xs[b]];
-            if (fuse && xt.c == 16) xs[b] = bb_chain(xs[b], 4);                       // both blocks in one kernel
+            if (b == 0 && fuse_sum) { deferred = bb_chain_op(xs[0], 4, /*pre-fuse tensor has consumers*/ n_out > 1); has_deferred = true; xs[0] = deferred.dst; }
+            else if (fuse && xt.c == 16) xs[b] = bb_chain(xs[b], 4);                       // both blocks in one kernel
             else if (fuse && xt.c == 32) { xs[b] = bb_chain(xs[b], 2); xs[b] = bb_chain(xs[b], 2); }
             else { xs[b] = basic_block(xs[b]); xs[b] = basic_block(xs[b]); }
         }
@@ -163,7 +173,7 @@ struct Builder {
             }
         std::vector<int> outs;
         for (int i = 0; i < n_out; ++i) {
-            const Tensor xi = net->tensors[xs[i]];
+            const Tensor xi = net->tensors[i == 0 ? x0_in : xs[i]];       // same shape as x_i (xs[0] is -1 when the branch tensor is not stored)
             // running sum: starts at x_i (identity term) or at the j=0 chain for i>0, in reference order
             int acc = -1;
             bool acc_is_xi = false;
@@ -222,6 +232,17 @@ struct Builder {
             // the reference adds the terms in branch order j (wasb.py:236-243): x_i (shift 0) before the upsampled lower branches
             for (size_t k = 1; k < up_t.size(); ++k)
                 for (size_t q = k; q > 0 && up_s[q] < up_s[q - 1]; --q) { std::swap(up_s[q], up_s[q - 1]); std::swap(up_t[q], up_t[q - 1]); }
+            if (i == 0 && has_deferred) {
+                // y_0 = relu(x_0 + sum_j up(1x1(x_j))) in the epilogue of the branch's block chain
+                deferred.n_terms = (int)up_t.size();
+                if (up_t.size() > 3) { set_error("fuse: more than 3 upsample terms"); rc = TTUP_EINVAL; }
+                for (size_t k = 0; k < up_t.size() && k < 3; ++k) { deferred.terms[k] = up_t[k]; deferred.shifts[k] = up_s[k]; }
+                if (head_mode) { deferred.head = 1; deferred.dst2 = -1; }
+                else deferred.dst2 = new_tensor(xi.c, xi.h, xi.w);
+                net->ops.push_back(deferred);
+                outs.push_back(deferred.dst2);
+                continue;
+            }
             // bf16: y_i = relu(chains + x_i + up(...)) finishes in the epilogue of the last chain conv (one same-resolution term
             // and one upsampled term fit): the element-wise pass over the branch disappears
             if (fuse && i > 0 && last_chain_op >= 0 && up_t.size() <= 2 && net->ops[last_chain_op].dst == acc) {
@@ -319,9 +340,12 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     ys = b.stage(xs, 3);
     net->taps["stage3_0"] = ys[0]; net->taps["stage3_1"] = ys[1]; net->taps["stage3_2"] = ys[2];
     xs = {ys[0], ys[1], ys[2], b.conv(ys[2], 128, 3, 2, 1)};
-    ys = b.stage(xs, 1);
+    const bool head_in_chain = net->dtype == TTUP_DTYPE_BF16 && net->n_out == 1 && !getenv("TTUP_NO_FUSE") && !getenv("TTUP_NO_FUSE_SUM");
+    ys = b.stage(xs, 1, head_in_chain);
     net->t_out = ys[0];
-    if (net->dtype == TTUP_DTYPE_BF16 && net->n_out == 1 && !getenv("TTUP_NO_FUSE") && net->ops.back().kind == Op::UPSUM && net->ops.back().dst == ys[0]) {
+    if (head_in_chain && net->ops.back().kind == Op::BB_CHAIN && net->ops.back().head) {
+        net->fused_head = true;                       // stage-4 output 0 lives only in the registers of the last block chain
+    } else if (net->dtype == TTUP_DTYPE_BF16 && net->n_out == 1 && !getenv("TTUP_NO_FUSE") && net->ops.back().kind == Op::UPSUM && net->ops.back().dst == ys[0]) {
         net->ops.back().kind = Op::UPSUM_HEAD;        // stage-4 output 0 is consumed in registers and never stored
         net->fused_head = true;
     } else {
@@ -353,11 +377,21 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
         } else if (op.kind == Op::UPSUM_HEAD) {
             return TTUP_OK;       // launched by forward_micro (run_head_op), which knows the output buffers
         } else if (op.kind == Op::BB_CHAIN) {
+            if (op.head) return TTUP_OK;      // launched by forward_micro (run_head_op), which knows the output buffers
             const Tensor& s = net->tensors[op.src0];
             const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int k = 0; k < op.n_chain; ++k) cv[k] = &net->convs[op.chain[k]];
-            const int rc = launch_bb_chain(cv, op.n_chain, s.ptr, net->tensors[op.dst].ptr, mb, s.h, s.w,
-                                           op.conv2 >= 0 ? &net->convs[op.conv2] : nullptr, op.dst2 >= 0 ? net->tensors[op.dst2].ptr : nullptr, st);
+            int rc;
+            if (op.n_chain == 4 && op.n_terms > 0) {          // fuse-layer sum in the epilogue: dst2 = relu(dst + sum up(terms))
+                BBSum sum;
+                sum.n_terms = op.n_terms;
+                for (int k = 0; k < op.n_terms; ++k) { sum.terms[k] = net->tensors[op.terms[k]].ptr; sum.shifts[k] = op.shifts[k]; }
+                sum.ysum = net->tensors[op.dst2].ptr;
+                rc = launch_bb_chain(cv, 4, s.ptr, op.dst >= 0 ? net->tensors[op.dst].ptr : nullptr, mb, s.h, s.w, nullptr, nullptr, st, &sum);
+            } else {
+                rc = launch_bb_chain(cv, op.n_chain, s.ptr, net->tensors[op.dst].ptr, mb, s.h, s.w,
+                                     op.conv2 >= 0 ? &net->convs[op.conv2] : nullptr, op.dst2 >= 0 ? net->tensors[op.dst2].ptr : nullptr, st);
+            }
             if (rc) return rc;
         } else if (op.kind == Op::BNECK_TRANS) {
             const Tensor& s = net->tensors[op.src0];
@@ -383,6 +417,26 @@ int run_graph(ttup_wasb* net, int mb, hipStream_t st) {
 // the fused last op of the bf16 ball path: stage-4 fuse sum + head + argmax partials (+ window gather)
 int run_head_op(ttup_wasb* net, int mb, float* heat, long long* am, float* wn, hipStream_t st) {
     const Op& op = net->ops.back();
+    if (op.kind == Op::BB_CHAIN) {
+        // last block chain of the full-resolution branch + stage-4 fuse sum + 1x1 head + per-tile argmax partials
+        const Tensor& s = net->tensors[op.src0];
+        const PackedConv* cv[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < op.n_chain; ++k) cv[k] = &net->convs[op.chain[k]];
+        const int nblk = bb_chain_tiles_per_img(s.h, s.w);
+        TTUP_REQUIRE(net->refine_ws && net->refine_ws_bytes >= (size_t)mb * nblk * 12, TTUP_EINVAL, "head: workspace too small");
+        BBSum sum;
+        sum.n_terms = op.n_terms;
+        for (int k = 0; k < op.n_terms; ++k) { sum.terms[k] = net->tensors[op.terms[k]].ptr; sum.shifts[k] = op.shifts[k]; }
+        sum.heat = heat; sum.head_w = net->head_w_dev; sum.head_bias = net->head_bias;
+        sum.pi = (long long*)net->refine_ws; sum.pv = (float*)(sum.pi + (size_t)mb * nblk);
+        int rc = launch_bb_chain(cv, 4, s.ptr, nullptr, mb, s.h, s.w, nullptr, nullptr, st, &sum);
+        if (rc) return rc;
+        if (am || wn) {
+            TTUP_REQUIRE(am && wn, TTUP_EINVAL, "head: argmax and window outputs come together");
+            rc = launch_argmax_finish(heat, mb, s.h, s.w, nblk, sum.pv, sum.pi, am, wn, st);
+        }
+        return rc;
+    }
     const void* terms[3] = {nullptr, nullptr, nullptr};
     for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
     return launch_upsum_head(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, net->head_w_dev, net->head_bias, heat, mb, net->H, net->W,
@@ -577,7 +631,7 @@ extern "C" int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, f
 namespace {
 void op_info(const ttup_wasb* net, int i, int* o, char* name) {
     const Op& op = net->ops[i];
-    const Tensor& d = net->tensors[op.dst];
+    const Tensor& d = net->tensors[op.dst >= 0 ? op.dst : op.src0];
     const bool bf = net->dtype == TTUP_DTYPE_BF16;
     char nm[64] = "";
     if (op.kind == Op::STEM) {
@@ -585,7 +639,7 @@ void op_info(const ttup_wasb* net, int i, int* o, char* name) {
         snprintf(nm, sizeof nm, "stem_kernel");
     } else if (op.kind == Op::BB_CHAIN) {
         o[0] = 3; o[1] = op.n_chain * d.c * 9; o[2] = d.c; o[3] = 1; o[4] = 1; o[5] = d.h; o[6] = d.w; o[7] = op.n_chain;
-        if (op.n_chain == 4) snprintf(nm, sizeof nm, "bb_chain2_kernel<16>");
+        if (op.n_chain == 4) snprintf(nm, sizeof nm, "bb_chain2_kernel<16>%s", op.head ? "+sum+head" : op.n_terms > 0 ? "+sum" : "");
         else snprintf(nm, sizeof nm, "bb_chain_kernel<%d,1>%s", d.c, op.conv2 >= 0 ? "+1x1" : "");
         if (op.conv2 >= 0) o[1] += 16;          // fused 1x1 32->16 follower: 32*16 MACs per pixel = 16 per output element of the block
     } else if (op.kind == Op::BNECK_TRANS) {
@@ -620,7 +674,7 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
     net->use_lane(0);
     for (int i = 0; i < n && rc == TTUP_OK; ++i) {
         const Op& op = net->ops[i];
-        auto once = [&]() { return op.kind == Op::UPSUM_HEAD ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st); };
+        auto once = [&]() { return (op.kind == Op::UPSUM_HEAD || op.head) ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st); };
         rc = once();                       // warm-up launch of this op
         if (rc == TTUP_OK) {
             (void)hipEventRecord(e0, st);
@@ -659,7 +713,7 @@ extern "C" int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max
         (void)hipEventRecord(ev[0], st);
         for (int i = 0; i < n && rc == TTUP_OK; ++i) {
             const Op& op = net->ops[i];
-            rc = op.kind == Op::UPSUM_HEAD ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st);
+            rc = (op.kind == Op::UPSUM_HEAD || op.head) ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st);
             (void)hipEventRecord(ev[i + 1], st);
         }
         (void)hipEventSynchronize(ev[n]);
