@@ -177,6 +177,22 @@ int ttup_trajgen_simulate(const int64_t* seeds_dev, int n_seeds, int mode, int d
 int ttup_trajgen_select(const double* samples_dev, const int* n_saved_dev, int n_seeds, int mode, int direction,
                         int* n_keep_dev, double* bounces_dev, int* n_bounces_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- g1: drag + Magnus ODE fit (extension; csrc/odefit.hip)
+ * BASELINE.json north_star names a "batched RK4 + Jacobian/Gauss-Newton" fit of flight dynamics to the detected 2-D track.
+ * The reference has NO such code (its uplift is the transformer above): these entry points replace nothing and
+ * are never called by the drop-in surface; parity is unpinned, validation is by self-consistency.
+ * All arrays float64 on the device.  obs_xy (B,T,2) pixels; times (B,T) seconds, non-decreasing; mask (B,T) 0/1 or null;
+ * cam: (B or 1, 21) = rows 0..2 of Mext (world -> camera, 12 numbers) then Mint (9), one per trajectory when cam_per_traj != 0;
+ * init (B,9) starting point (r0 [m], v0 [m/s], w0 [rad/s] at times[:,0]).  Outputs: params (B,9), pos3d (B,T,3) at the time
+ * stamps, cost (B) mean squared reprojection error [px^2], iters (B) accepted Levenberg-Marquardt steps (nullable except params).
+ * h_max: largest RK4 step; an interval between two time stamps is cut into ceil(dt / h_max) equal steps. */
+int ttup_odefit_forward(const double* obs_xy_dev, const double* times_dev, const double* mask_dev, const double* cam_dev, int cam_per_traj,
+                        const double* init_dev, int batch, int len, double h_max, int max_iter, double tol,
+                        double* params_dev, double* pos3d_dev, double* cost_dev, int* iters_dev, void* stream);
+/* forward model only: params (B,9) -> pos3d (B,T,3) and / or pixels px (B,T,2) (either may be null) */
+int ttup_odefit_integrate(const double* params_dev, const double* times_dev, const double* cam_dev, int cam_per_traj, int batch, int len,
+                          double h_max, double* pos3d_dev, double* px_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
