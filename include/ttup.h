@@ -177,6 +177,17 @@ int ttup_trajgen_simulate(const int64_t* seeds_dev, int n_seeds, int mode, int d
 int ttup_trajgen_select(const double* samples_dev, const int* n_saved_dev, int n_seeds, int mode, int direction,
                         int* n_keep_dev, double* bounces_dev, int* n_bounces_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- f4: camera calibration (csrc/calib.hip)
+ * Replaces calibrate_camera (inference/utils.py:312-329 -> dataprocessing/regress_cameramatrices.py:199-231 with
+ * use_ransac=True, dataprocessing/my_dlt.py) behind TableDetector.calibrate_camera / TableTennisPipeline.calibrate_camera
+ * (interface.py:174-175, :291-299).  One workgroup per camera: DLT start, one lane per RANSAC subset, refinement on the inliers.
+ * keypoints (B,13,3) float64 [x, y, visibility]; subsets (B,n_subsets,4) int32: the keys (1..13) drawn per RANSAC iteration
+ * (keypoints 10 and 11 are added to every subset on the device); img_w/img_h: the principal point is fixed at (w//2, h//2).
+ * Outputs: mint (B,3,4), mext (B,4,4) float64 row-major, n_inliers (B), status (B): 0 ok, -1 fewer than 6 visible keypoints,
+ * -2 degenerate DLT start, -3 no inliers; start (B,8) the DLT start (fx, fy, t, euler xyz), nullable (tests). */
+int ttup_calib_forward(const double* keypoints_dev, const int* subsets_dev, int batch, int n_subsets, int img_w, int img_h, int max_iter,
+                       double* mint_dev, double* mext_dev, int* n_inliers_dev, int* status_dev, double* start_dev, void* stream);
+
 /* ---------------------------------------------------------------- g1: drag + Magnus ODE fit (extension; csrc/odefit.hip)
  * BASELINE.json north_star names a "batched RK4 + Jacobian/Gauss-Newton" fit of flight dynamics to the detected 2-D track.
  * The reference has NO such code (its uplift is the transformer above): these entry points replace nothing and

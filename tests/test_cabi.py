@@ -185,27 +185,31 @@ def test_filter_trajectory_table_matches_reference(golden):
     np.testing.assert_allclose(out, g['filter/out'], rtol=0, atol=1e-9)
 
 
-# ------------------------------------------------------------------------------------------ f4: camera calibration (host)
-def test_calibrate_camera_and_reproject_match_reference(golden):
-    """`calibrate_camera` (DLT -> 100-subset RANSAC of SciPy BFGS refinements -> refinement on the inliers) against the
-    reference's own output on the case with an outlier and an invisible keypoint; `reproject` on all three cameras.
-    Same SciPy calls in the same order: the matrices agree to 1e-9 (they are bit-equal on the build container)."""
+# ------------------------------------------------------------------------------------------ f4: camera calibration
+def test_calibration_oracle_matches_reference_and_host_glue(golden):
+    """The CPU oracle of the calibration (oracle/calib_ref.py: DLT -> 100-subset RANSAC of SciPy BFGS refinements -> refinement on
+    the inliers, the reference's own calls in the same order) against the reference's output on the case with an outlier and an
+    invisible keypoint (1e-9; bit-equal on the build container).  The product's host glue: `reproject` on all three cameras
+    equals the reference arithmetic, and the RANSAC subsets are the reference's draws (numpy PCG64, seed 42)."""
+    from oracle import calib_ref
     from upliftingtabletennis_amd import calib
     g = golden('calib.npz')
     kp = g['calib/1/keypoints']
     assert kp[7, 2] == 0
-    Mint, Mext = calib.calibrate_camera(kp)
+    Mint, Mext = calib_ref.calibrate_camera(kp)
     assert Mint.shape == (3, 4) and Mext.shape == (4, 4)
     assert np.allclose(Mint, g['calib/1/Mint'], rtol=1e-9, atol=1e-9) and np.allclose(Mext, g['calib/1/Mext'], rtol=1e-9, atol=1e-9)
     for ci in range(int(g['n'][0])):
         uv = calib.reproject(g['calib/%d/points' % ci], g['calib/%d/Mint' % ci], g['calib/%d/Mext' % ci])
-        assert np.array_equal(uv, g['calib/%d/reproj' % ci])
-        # the calibrated camera re-projects the table within the pixel noise of the keypoints
-        vis = g['calib/%d/keypoints' % ci][:, 2] == 1
-        err = np.linalg.norm(calib.reproject(calib.TABLE_POINTS, g['calib/%d/Mint' % ci], g['calib/%d/Mext' % ci]) - g['calib/%d/keypoints' % ci][:, :2], axis=1)
-        assert np.median(err[vis]) < 2.0
+        assert np.abs(uv - g['calib/%d/reproj' % ci]).max() <= 1e-9
+        assert np.array_equal(calib_ref.reproject(g['calib/%d/points' % ci], g['calib/%d/Mint' % ci], g['calib/%d/Mext' % ci]), g['calib/%d/reproj' % ci])
     with pytest.raises(AssertionError):
-        calib.calibrate_camera(np.concatenate([kp[:, :2], np.zeros((13, 1))], axis=1))       # fewer than 6 visible points
+        calib_ref.calibrate_camera(np.concatenate([kp[:, :2], np.zeros((13, 1))], axis=1))       # fewer than 6 visible points
+    vis = [k + 1 for k in range(13) if kp[k, 2] == 1]
+    sub = calib.ransac_subsets(vis)
+    rnd = np.random.default_rng(seed=42)
+    pool = [k for k in vis if k not in (10, 11)]
+    assert sub.shape == (100, 4) and np.array_equal(sub[0], rnd.choice(pool, size=4, replace=False)) and set(sub.ravel()) <= set(pool)
 
 
 # ------------------------------------------------------------------------------------------ a8: checkpoint ingestion

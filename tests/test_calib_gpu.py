@@ -1,0 +1,83 @@
+"""f4: camera calibration on the MI355X (csrc/calib.hip) through the C-ABI, against the reference's own results
+(tests/golden/calib.npz, produced by the reference's `calibrate_camera`).  /root/reference is never read here.
+
+The device minimises the reference's objective (sum of re-projection distances) over the reference's subsets with its own
+solver; SciPy's BFGS with finite-difference gradients stops on that non-smooth objective where its line search gives up, so
+the two agree to about a pixel, not to the last bit.  Measured on the three golden cameras: identical inlier sets, device
+objective 0.1-1.9 % BELOW the reference's (5.8127 vs 5.9221, 5.4582 vs 5.4631, 8.0564 vs 8.0749 px), re-projections within
+1.01 / 0.61 / 0.20 px, focal lengths within 0.13 %."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+if has_gpu():
+    from upliftingtabletennis_amd import calib
+
+TABLE = None
+
+
+def _table():
+    from upliftingtabletennis_amd import synth
+    return synth.TABLE_POINTS
+
+
+def _objective(kp, Mint, Mext):
+    vis = kp[:, 2] == 1
+    return np.linalg.norm(calib.reproject(_table()[vis], Mint, Mext) - kp[vis, :2], axis=1)
+
+
+def test_device_calibration_matches_reference_goldens(golden):
+    g = golden('calib.npz')
+    n = int(g['n'][0])
+    kps = np.stack([g['calib/%d/keypoints' % ci] for ci in range(n)])
+    mint, mext, ninl = calib.calibrate_cameras(kps)
+    for ci in range(n):
+        rMint, rMext = g['calib/%d/Mint' % ci], g['calib/%d/Mext' % ci]
+        kp = kps[ci]
+        e_dev, e_ref = _objective(kp, mint[ci], mext[ci]), _objective(kp, rMint, rMext)
+        # same inlier set as the reference's final model, and an objective on it that is at least as low (the device solver
+        # runs to the minimum; SciPy stops a little before it)
+        inl_dev, inl_ref = e_dev < 3.5, e_ref < 3.5
+        assert np.array_equal(inl_dev, inl_ref) and int(inl_ref.sum()) == int(ninl[ci])
+        assert e_dev[inl_ref].sum() <= e_ref[inl_ref].sum() * (1 + 1e-9)
+        # the two cameras re-project the table and the golden test points to the same pixels
+        pts = np.concatenate([_table(), g['calib/%d/points' % ci]])
+        d = np.linalg.norm(calib.reproject(pts, mint[ci], mext[ci]) - calib.reproject(pts, rMint, rMext), axis=1)
+        print('camera %d: %d inliers, objective device %.6f reference %.6f px, max re-projection difference %.2e px, fx %.3f vs %.3f'
+              % (ci, ninl[ci], e_dev[inl_ref].sum(), e_ref[inl_ref].sum(), d.max(), mint[ci][0, 0], rMint[0, 0]))
+        assert d.max() < 1.5
+        # the device result is a minimum of the reference's objective: SciPy's BFGS (the reference's optimiser, through the pinned
+        # oracle) started AT the device matrices does not get below it
+        from oracle import calib_ref
+        vis_idx = np.nonzero(kp[:, 2] == 1)[0]
+        inl = [(int(k) + 1, tuple(kp[k, :2])) for j, k in enumerate(vis_idx) if inl_ref[j]]
+        Mi2, Me2 = calib_ref.regress_cameramatrices((1920, 1080), inl, calib_ref.POINTS3D, startmatrices=(mint[ci], mext[ci]))
+        e_bfgs = _objective(kp, Mi2, Me2)
+        assert e_bfgs[inl_ref].sum() >= e_dev[inl_ref].sum() - 1e-6
+        assert abs(mint[ci][0, 0] - rMint[0, 0]) < 5e-3 * rMint[0, 0] and abs(mint[ci][1, 1] - rMint[1, 1]) < 5e-3 * rMint[1, 1]
+        assert mint[ci].shape == (3, 4) and mext[ci].shape == (4, 4) and mint[ci][0, 2] == 960 and mint[ci][1, 2] == 540
+        assert np.allclose(mext[ci][:3, :3] @ mext[ci][:3, :3].T, np.eye(3), atol=1e-12) and np.array_equal(mext[ci][3], [0, 0, 0, 1])
+    # single-camera entry = the hub surface
+    Mi, Me = calib.calibrate_camera(kps[1])
+    assert np.array_equal(Mi, mint[1]) and np.array_equal(Me, mext[1])
+
+
+def test_device_calibration_recovers_a_planted_camera_and_rejects_an_outlier():
+    from upliftingtabletennis_amd import synth
+    rng = np.random.default_rng(4)
+    R, c, f = synth._random_camera(rng)
+    Mext = np.eye(4); Mext[:3, :3] = R; Mext[:3, 3] = -R @ c
+    Mint = np.array([[f, 0, 960.0, 0], [0, f, 540.0, 0], [0, 0, 1, 0]])
+    kp = np.concatenate([calib.reproject(synth.TABLE_POINTS, Mint, Mext), np.ones((13, 1))], axis=1)
+    mi, me = calib.calibrate_camera(kp)                       # noiseless: exact recovery
+    assert abs(mi[0, 0] - f) < 1e-6 * f and abs(mi[1, 1] - f) < 1e-6 * f and np.abs(me - Mext).max() < 1e-7
+    bad = kp.copy(); bad[2, :2] += 40.0; bad[5, 2] = 0        # one gross outlier, one invisible keypoint
+    mints, mexts, ninl = calib.calibrate_cameras(np.stack([kp, bad]))
+    assert ninl.tolist() == [13, 11]
+    assert abs(mints[1][0, 0] - f) < 1e-6 * f and np.abs(mexts[1] - Mext).max() < 1e-7
+    with pytest.raises(AssertionError):
+        calib.calibrate_camera(np.concatenate([kp[:, :2], np.zeros((13, 1))], axis=1))
+    with pytest.raises(ValueError):
+        calib.calibrate_cameras(np.zeros((2, 12, 3)))

@@ -42,6 +42,7 @@ SIGNATURES = {
     'ttup_trajgen_max_samples': (_i, []),
     'ttup_trajgen_workspace_bytes': (_sz, [_i]),
     'ttup_trajgen_simulate': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ttup_calib_forward': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ttup_odefit_forward': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _c.c_double, _i, _c.c_double, _vp, _vp, _vp, _vp, _vp]),
     'ttup_odefit_integrate': (_i, [_vp, _vp, _vp, _i, _i, _i, _c.c_double, _vp, _vp, _vp]),
     'ttup_trajgen_select': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
