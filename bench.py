@@ -216,6 +216,26 @@ def extras(device):
     out['uplift_only_traj_s'] = {'value': round(B / dt, 1), 'unit': 'trajectories/s', 'config': 'BASELINE config 3: uplift transformer (the reference\'s uplift), B=10000, T=120',
                                  'seconds': round(dt, 4), 'tflops_fp32': round(B * 2.0 / dt / 1e3, 1)}
     del up
+    # config 1 on the GPU: the torch.hub entry point on one 48-frame host clip (numpy frames in, spin + 3-D positions out)
+    os.environ.setdefault('TTUP_SYNTHETIC_WEIGHTS', '1')
+    import warnings
+    import hubconf
+    frames48, _ = synth.synth_frames(48, H_SRC, W_SRC, seed=0)
+    images = [f for f in frames48]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hub = hubconf.full_pipeline()
+    hub.predict(images[:20], 60.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        hub.predict(images, 60.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out['hub_clip_fps'] = {'value': round(len(images) / dt, 1), 'unit': 'frames/s', 'ms_per_clip': round(dt * 1e3, 2),
+                           'config': 'BASELINE config 1 on the GPU: hubconf.full_pipeline().predict on a 48-frame 1280x720 host clip (upload, table HRNet on every '
+                                     'frame + DBSCAN filter, ball detector, refine, uplift); wall clock'}
+    del hub
     try:
         from upliftingtabletennis_amd import odefit
         out['odefit_traj_s'] = odefit.bench(device, B, T)

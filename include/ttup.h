@@ -120,6 +120,8 @@ int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float
 int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map);
 int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
 int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host8, int reset);
+/* scheduling priority of the handle's internal streams (high != 0: greatest device priority); synchronises */
+int ttup_wasb_set_priority(ttup_wasb* net, int high);
 /* micro-batch the handle was created with (TTUP_MICRO_BATCH) */
 int ttup_wasb_micro_batch(ttup_wasb* net);
 /* heatmap channels per sample returned by forward: 1 (ball) or 13 (table) */

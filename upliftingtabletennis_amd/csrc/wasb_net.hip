@@ -739,5 +739,23 @@ extern "C" int ttup_preprocess_frames(const uint8_t* frames_dev, int n_frames, i
     return launch_preprocess(frames_dev, n_frames, src_h, src_w, dst_h, dst_w, out_dev, TTUP_LAYOUT_NCHW_F32, TTUP_DTYPE_F32, 0, n_frames, 1, (hipStream_t)stream);
 }
 
+// Scheduling priority of the handle's internal lane streams (high != 0: the greatest priority of the device).  Two handles that
+// share the GPU (the hub path runs the table and the ball detector side by side) can thus be ordered: the high-priority one
+// finishes first and its host-side consumer overlaps with the other's kernels.  Synchronises; single-lane handles run on the
+// caller's stream and are not affected.
+extern "C" int ttup_wasb_set_priority(ttup_wasb* net, int high) {
+    TTUP_REQUIRE(net, TTUP_EINVAL, "ttup_wasb_set_priority: null handle");
+    if (net->lanes.size() < 2) return TTUP_OK;
+    TTUP_HIP_CHECK(hipDeviceSynchronize());
+    int least = 0, greatest = 0;
+    TTUP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (auto& L : net->lanes) {
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        L.stream = nullptr;
+        TTUP_HIP_CHECK(hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, high ? greatest : least));
+    }
+    return TTUP_OK;
+}
+
 extern "C" int ttup_wasb_micro_batch(ttup_wasb* net) { return net ? net->micro : 0; }
 extern "C" int ttup_wasb_out_channels(ttup_wasb* net) { return net ? net->n_out : 0; }

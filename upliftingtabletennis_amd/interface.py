@@ -249,8 +249,11 @@ class TableTennisPipeline:
         self.device = torch.device('cuda')
         self.ball_detector = BallDetector(model_name='wasb', max_batch=max_batch)
         self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
-        self.table_detector = TableDetector(model_name='hrnet')
+        self.table_detector = TableDetector(model_name='hrnet', max_batch=16)
         self.table_detector_aux = self.table_detector
+        # the overlapped clip path runs both detectors side by side: the table detector goes first on the GPU, so that its
+        # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
+        self.table_detector.model.set_priority(True)
         self.uplifting_model = UpliftingModel()
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
 
@@ -264,15 +267,113 @@ class TableTennisPipeline:
         for fixed-camera streams; the reference surface is `predict`."""
         return self._predict(images, fps, table_keypoints)
 
+    CHUNK = 16          # frames per upload / detector call of the overlapped clip path
+
+    def _clip_detections(self, images, want_table, table_consumer=None):
+        """Ball positions (N-2,3) and table keypoints ((N,13,3), or what `table_consumer` makes of them) of one clip with everything overlapped: the frames are staged in
+        pinned memory and uploaded ONCE in chunks on a copy stream; while chunk k+1 is staged and copied, the table detector
+        runs on chunk k on its own stream and the ball detector on the triples whose three frames are already resident on a
+        third; the host blocks only at the end.  Same values as `predict_clip` / `predict_keypoints` (same kernels per frame)."""
+        n, dev, C = len(images), self.device, self.CHUNK
+        h0, w0 = np.asarray(images[0]).shape[:2]
+        bd, td = self.ball_detector, self.table_detector
+        bw, bh = bd.model_resolution
+        tw, th = td.model_resolution
+        frames = torch.empty((n, h0, w0, 3), dtype=torch.uint8, device=dev)
+        st = self.__dict__.setdefault('_streams', None)
+        if st is None:
+            st = self._streams = {k: torch.cuda.Stream(dev) for k in ('copy', 'ball', 'table')}
+            self._pinned = [torch.empty((C, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._pin_free = [None, None]
+        if self._pinned[0].shape[1:] != (h0, w0, 3):
+            self._pinned = [torch.empty((C, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._pin_free = [None, None]
+        cur = torch.cuda.current_stream(dev)
+        for s in st.values():
+            s.wait_stream(cur)
+        uploaded = []                     # event per chunk
+        ball_out, table_out, ball_calls = [], [], []
+        t_next = 0                        # first triple not yet submitted
+
+        def submit_ball(limit_frames, final):
+            nonlocal t_next
+            # triples t .. need frames t..t+2 resident; submit full chunks (or the remainder at the end)
+            while t_next < n - 2 and (t_next + min(C, n - 2 - t_next) + 2 <= limit_frames):
+                nt = min(C, n - 2 - t_next)
+                if not final and nt < C and limit_frames < n:
+                    break
+                with torch.cuda.stream(st['ball']):
+                    st['ball'].wait_event(uploaded[(t_next + nt + 1) // C])
+                    fr = frames[t_next:t_next + nt + 2]
+                    _, idx, win = bd.model.forward_frames(fr, want_heatmap=False)
+                    status = bd.model.certify_status(nt) if bd.model.certified else None
+                    ball_calls.append((t_next, nt, idx, win, status))
+                t_next += nt
+
+        for ci, c0 in enumerate(range(0, n, C)):
+            c1 = min(c0 + C, n)
+            pin = self._pinned[ci % 2]
+            if self._pin_free[ci % 2] is not None:
+                self._pin_free[ci % 2].synchronize()          # the copy that last read this staging buffer is done
+            for k in range(c0, c1):
+                pin[k - c0].copy_(torch.from_numpy(np.ascontiguousarray(images[k])))
+            with torch.cuda.stream(st['copy']):
+                frames[c0:c1].copy_(pin[:c1 - c0], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record()
+            uploaded.append(ev)
+            self._pin_free[ci % 2] = ev
+            if ci == 0:
+                torch.cuda.current_stream(dev).wait_event(ev)
+                bd._calibrate(frames=frames[:min(c1, 4)]) if c1 >= 3 else None        # certified argmax: once per detector
+            if want_table:
+                with torch.cuda.stream(st['table']):
+                    st['table'].wait_event(ev)
+                    _, idx, win = td.model.forward_frames(frames[c0:c1], want_heatmap=False)
+                    table_out.append(refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE))
+            submit_ball(c1, final=(c1 == n))
+        frames.record_stream(st['ball']); frames.record_stream(st['table'])
+        kp = None
+        if want_table:
+            # the table detector (high-priority streams) finishes first: its keypoints come back and the host-side DBSCAN filter
+            # runs while the ball detector is still busy on the GPU
+            with torch.cuda.stream(st['table']):
+                kp_dev = torch.cat(table_out).reshape(-1, 13, 3)
+                kp_host = torch.empty(kp_dev.shape, dtype=kp_dev.dtype, pin_memory=True)
+                kp_host.copy_(kp_dev, non_blocking=True)
+                ev_t = torch.cuda.Event(); ev_t.record()
+            ev_t.synchronize()
+            kp = table_consumer(kp_host.numpy()) if table_consumer is not None else kp_host.numpy().copy()
+        for s in st.values():
+            cur.wait_stream(s)
+        for (t0, nt, idx, win, status) in ball_calls:
+            if status is not None and (status.cpu().numpy() == 2).any():
+                # rare: crop budget exceeded -> those frames on the full-frame fp32 path (the status belongs to the handle's LAST call,
+                # so re-run this call first)
+                _, idx, win = bd.model.forward_frames(frames[t0:t0 + nt + 2], want_heatmap=False)
+                bd.model.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2])
+            ball_out.append(refine.refine_windows_device(idx, win, bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
+        pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
+        return pos, kp
+
     def _predict(self, images, fps, table_keypoints):
-        if table_keypoints is None:        # 2. table detection (interface.py:281-283)
-            kp = self.table_detector.predict_keypoints(images)
-            kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict_keypoints(images)
-            table_keypoints = self.table_detector_aux.filter_trajectory(kp, kp_aux)
-        # the reference builds (prev, curr, next) triples and pushes each through the detector (interface.py:276-279);
-        # the triples are consecutive frames, so the clip path computes the same positions with every frame uploaded once
-        ball_positions = self.ball_detector.predict_clip(images)
-        ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict_clip(images)
+        overlapped = (self.ball_detector_aux is self.ball_detector and self.table_detector_aux is self.table_detector and len(images) >= 3
+                      and self.table_detector.max_batch >= self.CHUNK and self.ball_detector.max_batch >= self.CHUNK
+                      and os.environ.get('TTUP_HUB_SERIAL') != '1')
+        if overlapped:
+            ball_positions, kp = self._clip_detections(images, want_table=table_keypoints is None,
+                                                       table_consumer=lambda k: self.table_detector_aux.filter_trajectory(k, k))
+            ball_positions_aux = ball_positions
+            if table_keypoints is None:
+                table_keypoints = kp
+        else:
+            if table_keypoints is None:        # 2. table detection (interface.py:281-283)
+                kp = self.table_detector.predict_keypoints(images)
+                kp_aux = kp if self.table_detector_aux is self.table_detector else self.table_detector_aux.predict_keypoints(images)
+                table_keypoints = self.table_detector_aux.filter_trajectory(kp, kp_aux)
+            # the reference builds (prev, curr, next) triples and pushes each through the detector (interface.py:276-279);
+            # the triples are consecutive frames, so the clip path computes the same positions with every frame uploaded once
+            ball_positions = self.ball_detector.predict_clip(images)
+            ball_positions_aux = ball_positions if self.ball_detector_aux is self.ball_detector else self.ball_detector_aux.predict_clip(images)
         filtered, _, times_ball = self.ball_detector.filter_trajectory(ball_positions, ball_positions_aux, fps)
         ball_coords, table_coords, times, mask = glue._uplifting_transform(filtered, np.asarray(table_keypoints, dtype=np.float64), times_ball)
         return self.uplifting_model.predict_without_normalization(ball_coords, table_coords, mask, times)

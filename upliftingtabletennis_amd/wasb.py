@@ -163,6 +163,11 @@ class WASBNet:
                 win[t] = w1[0]
         return int(bad.size)
 
+    def set_priority(self, high=True):
+        """Run this handle's kernels ahead of (high) / behind other handles sharing the GPU."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_set_priority(self._handle, 1 if high else 0))
+
     def read_tap(self, name, batch=1):
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self._lib.ttup_wasb_read_tap(self._handle, name.encode(), batch, None, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w), None))
