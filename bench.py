@@ -109,7 +109,9 @@ def roofline(pipe):
     ops = wasb.time_ops(pipe.net, reps=5, in_graph=True)
     groups = {}
     for o in ops:
-        g = groups.setdefault(o['kernel'], {'kernel': o['kernel'], 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'shape': (o['h'], o['w'])})
+        # group by the HIP kernel that runs (the '+sum', '+sum+head', '+1x1' suffixes name epilogue variants of the same kernel)
+        name = o['kernel'].split('+')[0]
+        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'shape': (o['h'], o['w'])})
         g['launches'] += 1; g['ms'] += o['ms']; g['flops'] += o['flops']
     table = sorted(groups.values(), key=lambda g: -g['ms'])
     tot_ms = sum(o['ms'] for o in ops)
