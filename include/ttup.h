@@ -119,6 +119,10 @@ int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float
  * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved, 0, 0}. */
 int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map);
 int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
+/* crops the following forward calls may use (default: max_batch, i.e. one per heatmap): the call enqueues ceil(budget / 64) fp32
+ * passes sized on the device, so a caller that knows its typical crop count (stats / status of earlier calls) saves the empty
+ * passes; heatmaps beyond the budget are flagged 2 */
+int ttup_wasb_certify_budget(ttup_wasb* net, int max_crops);
 int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host8, int reset);
 /* scheduling priority of the handle's internal streams (high != 0: greatest device priority); synchronises */
 int ttup_wasb_set_priority(ttup_wasb* net, int high);

@@ -93,10 +93,12 @@ def test_wasb_fullsize_planted_argmax_and_refine(golden):
     fr = torch.from_numpy(frames).cuda()
     heat, idx, win = net.forward_frames(fr, want_heatmap=True)
     assert np.array_equal(idx.cpu().numpy(), g['argmax'])
-    # u8 fast path == float path fed with the separately pre-processed tensor
+    # u8 fast path vs float path fed with the separately pre-processed tensor: same peaks; the heatmaps differ by bf16 rounding
+    # flips only (the fast path's stem takes the 9 input channels in per-frame slot order, i.e. another fp32 summation order)
     x = wasb.preprocess_triples(fr, (w, h))
     heat2, idx2, win2 = net.forward(x, want_peaks=True)
-    assert torch.equal(idx, idx2) and torch.equal(heat, heat2)
+    assert torch.equal(idx, idx2)
+    assert (heat - heat2).abs().max().item() <= 2e-2 * (heat2.max() - heat2.min()).item()
     sub = heat.cpu().numpy()[:, :, ::16, ::16]
     assert np.abs(sub - g['sub16']).max() <= 4e-2 * float(g['top2'].max())       # 4% of the peak height
     for variant, key in ((_lib.REFINE_BALL, 'ball'), (_lib.REFINE_TABLE, 'table')):

@@ -204,7 +204,7 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     TTUP_LAUNCH_CHECK();
     PlanArgs a;
     a.cand_idx = c.cand_idx; a.cand_cnt = c.cand_cnt; a.cand_crop = c.cand_crop; a.crop_rec = c.crop_rec; a.n_crops = c.n_crops;
-    a.status = c.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.max_crops;
+    a.status = c.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
     a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
@@ -215,10 +215,10 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
                 int64_t* argmax_dev, float* win_dev, hipStream_t st) {
     CertState& c = net->cert;
     ttup_wasb* cn = c.cropnet;
-    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, c.n_crops, c.n_active, c.CH, c.nchunks, c.max_crops);
+    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, c.n_crops, c.n_active, c.CH, c.nchunks, c.budget);
     TTUP_LAUNCH_CHECK();
-    // chunks that can hold crops of THIS call: at most maxc per heatmap
-    int nch = cdiv(batch * c.maxc < c.max_crops ? batch * c.maxc : c.max_crops, c.CH);
+    // fp32 passes that can hold crops of THIS call: at most maxc per heatmap, at most the caller's budget
+    int nch = cdiv(batch * c.maxc < c.budget ? batch * c.maxc : c.budget, c.CH);
     nch = nch > c.nchunks ? c.nchunks : nch;
     for (int ch = 0; ch < nch; ++ch) {
         const int crop0 = ch * c.CH;
@@ -278,6 +278,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     c.nchunks = cdiv(c.max_crops, c.CH);
     TTUP_REQUIRE(c.nchunks <= 64, TTUP_EINVAL, "ttup_wasb_set_certify: max_batch %d too large", net->max_batch);
     c.max_crops = c.nchunks * c.CH;
+    c.budget = c.max_crops;
     const size_t nb = (size_t)net->max_batch;
     TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_idx, nb * c.K * sizeof(int)));
     TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_cnt, nb * sizeof(int)));
@@ -295,6 +296,13 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
     if (rc) { cert_free(net); return rc; }
     c.enabled = true;
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_budget(ttup_wasb* net, int max_crops) {
+    TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_budget: the certified argmax is not enabled on this handle");
+    TTUP_REQUIRE(max_crops >= 1, TTUP_EINVAL, "ttup_wasb_certify_budget: budget must be positive");
+    net->cert.budget = max_crops < net->cert.max_crops ? max_crops : net->cert.max_crops;
     return TTUP_OK;
 }
 

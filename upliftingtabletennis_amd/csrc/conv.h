@@ -47,8 +47,11 @@ bool conv_f32_mfma_supported(const PackedConv& p);
 int launch_conv_f32_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t stream);
 
 // fused stem: conv1 + conv2 + Bottleneck conv1, bf16 only, persistent with all weights resident in LDS (csrc/conv.hip)
+// frames_per_sample = 0: x0 is the (B,H,W,16) input tensor; 1 / 3: x0 is the per-frame pre-processed clip (B+nf-1,H,W,4) and p1 is
+// packed in the slot order f*4 + c (see stem_kernel)
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
-                int batch, int h, int w, hipStream_t st);
+                int batch, int h, int w, hipStream_t st, int frames_per_sample = 0);
+#define TTUP_LAYOUT_NHWC4_FRAME 2      // internal: launch_preprocess output = one bf16 (c0,c1,c2,0) record per frame pixel
 
 // fused Bottleneck tail (conv3 + downsample + add + relu) + both transition1 convs, bf16 only (csrc/conv.hip)
 int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedConv& p6, const void* a2, const void* t2,

@@ -428,7 +428,7 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
 // Reference: wasb.py:446-451 (stem), :88-90 (Bottleneck conv1).  Intermediates are rounded to bf16 where the layer-wise
 // path stores them, so results are bit-identical.
 struct StemArgs {
-    const bf16_t* x0;                 // (B,H,W,16)
+    const bf16_t* x0;                 // (B,H,W,16), or in frames mode (NF > 0) the pre-processed frames (B+NF-1,H,W,4): sample b = frames b..b+NF-1
     const bf16_t* w1; const float* b1;      // conv1: CK=16 packing, 5 k-steps x 4 m-tiles
     const bf16_t* w2; const float* b2;      // conv2: CK=32 packing, 2 chunks x 9 k-steps x 4 m-tiles
     const bf16_t* w3; const float* b3;      // follower 1x1 64->32: 2 k-steps x 2 m-tiles
@@ -436,10 +436,16 @@ struct StemArgs {
     int H, W, tiles_x, tiles_per_img, total_tiles;
 };
 
+// NF = 0: X0 comes as (B,H,W,16) records.  NF = 1 / 3 (frames mode): every frame is pre-processed ONCE into a 4-channel record
+// (3 colours + 0) and a sample's X0 pixel is assembled in LDS from the NF frames it spans (slot f*4 + c; conv1's weights are
+// packed in that channel order): the 16-channel per-triple tensor -- 3 copies of every frame plus 7 zero channels -- is never
+// written or read (28.8 -> 7.2 MB of pre-processing output per frame, 28.8 -> 21.6 MB of stem input).
+template <int NF>
 __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     constexpr int XH = 12, XW = 36, TH1 = 10, TW1 = 34, NP1 = TH1 * TW1;       // X0 region, conv1 output region
     constexpr int W1_U = 5 * 4 * 64, W2_U = 2 * 9 * 4 * 64;                      // 16-byte units
-    constexpr int X_UNITS = XH * XW * 2;                                        // 864 units of 16 B
+    constexpr int X_UNITS = NF ? XH * XW * NF : XH * XW * 2;                    // 8-byte (frames mode) or 16-byte units
+    constexpr int X_PT = (X_UNITS + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* s_w1 = (bf16_t*)smem;                     // 20,480 B
     bf16_t* s_w2 = s_w1 + W1_U * 8;                   // 73,728 B
@@ -473,19 +479,36 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     for (int dx = 0; dx < 3; ++dx) bB[dx] = s_t1 + lds_off<32, TW1>(0, n + dx, g);
 
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    u32x4 px[2];
+    u32x4 px[NF ? 1 : 2];
+    u32x2 pf[NF ? X_PT : 1];
+    if (NF) {         // slots no frame writes (the fourth record of a triple, three of four for a single frame) stay zero
+        for (int u = tid; u < XH * XW * 2; u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
     auto issue = [&](int it) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
         const int gy0 = (t / a.tiles_x) * 8 - 2, gx0 = (t % a.tiles_x) * 32 - 2;
+        if (NF) {
+#pragma unroll
+            for (int k = 0; k < X_PT; ++k) {
+                const int u = tid + k * 512;
+                const int f = u % (NF ? NF : 1), pix = u / (NF ? NF : 1);
+                const int gy = gy0 + pix / XW, gx = gx0 + pix % XW;
+                pf[k] = u32x2{0u, 0u};
+                if (u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    pf[k] = *(const u32x2*)(a.x0 + (((size_t)(b + f) * a.H + gy) * a.W + gx) * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int u = tid + k * 512;
             const int c8 = u & 1, pix = u >> 1;
             const int gy = gy0 + pix / XW, gx = gx0 + pix % XW;
-            px[k] = u32x4{0u, 0u, 0u, 0u};
+            px[k & (NF ? 0 : 1)] = u32x4{0u, 0u, 0u, 0u};
             if (u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                px[k] = *(const u32x4*)(a.x0 + ((size_t)(b * a.H + gy) * a.W + gx) * 16 + c8 * 8);
+                px[k & (NF ? 0 : 1)] = *(const u32x4*)(a.x0 + ((size_t)(b * a.H + gy) * a.W + gx) * 16 + c8 * 8);
         }
     };
     if (my_tiles > 0) issue(0);
@@ -497,8 +520,16 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         // The X0 tile was last read in conv1 of the previous tile, which every wave left before the barrier in the middle
         // of that iteration: it can be overwritten without waiting.  ONE barrier then covers "X0 tile complete" and
         // "previous conv2 done reading the T1 tile" (and the weights on the first pass).
+        if (NF) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k]; }
+            for (int k = 0; k < X_PT; ++k) {
+                const int u = tid + k * 512;
+                if (u < X_UNITS) *(u32x2*)(s_x + (u / (NF ? NF : 1)) * 16 + (u % (NF ? NF : 1)) * 4) = pf[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k & (NF ? 0 : 1)]; }
+        }
         TTUP_STAMP_IT(0, it, 1);
         __syncthreads();
         if (it + 1 < my_tiles) issue(it + 1);
@@ -602,7 +633,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 }
 
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
-                int batch, int h, int w, hipStream_t st) {
+                int batch, int h, int w, hipStream_t st, int frames_per_sample) {
     TTUP_REQUIRE(p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16, TTUP_EINVAL, "stem: unexpected conv1 shape");
     TTUP_REQUIRE(p2.cout == 64 && p2.cin_total == 64 && p2.k == 3 && p2.stride == 1 && p2.ck == 32, TTUP_EINVAL, "stem: unexpected conv2 shape");
     TTUP_REQUIRE(p3.cout == 32 && p3.cin_total == 64 && p3.k == 1 && p3.ck == 32, TTUP_EINVAL, "stem: unexpected follower shape");
@@ -612,10 +643,14 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
     a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
     constexpr size_t SMEM = (size_t)(5 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * 340 * 32 + 432 * 16) * 2;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    if (int rc = ensure_max_lds((const void*)stem_kernel, SMEM)) return rc;
+    TTUP_REQUIRE(frames_per_sample == 0 || frames_per_sample == 1 || frames_per_sample == 3, TTUP_EINVAL, "stem: frames per sample must be 0 (X0 records), 1 or 3");
+    const void* kfn = frames_per_sample == 3 ? (const void*)stem_kernel<3> : frames_per_sample == 1 ? (const void*)stem_kernel<1> : (const void*)stem_kernel<0>;
+    if (int rc = ensure_max_lds(kfn, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(512), SMEM, st, a);
+    if (frames_per_sample == 3) hipLaunchKernelGGL(stem_kernel<3>, dim3(grid), dim3(512), SMEM, st, a);
+    else if (frames_per_sample == 1) hipLaunchKernelGGL(stem_kernel<1>, dim3(grid), dim3(512), SMEM, st, a);
+    else hipLaunchKernelGGL(stem_kernel<0>, dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -1734,6 +1769,10 @@ __global__ void preprocess_kernel(PreArgs a) {
         }
     }
     const size_t hw = (size_t)a.dst_h * a.dst_w, pix = (size_t)y * a.dst_w + x;
+    if (a.layout == TTUP_LAYOUT_NHWC4_FRAME) {          // one 4-channel bf16 record per frame pixel (stem frames mode)
+        *(u32x2*)((bf16_t*)a.out + opix * 4) = u32x2{pack2(vals[0], vals[1]), pack2(vals[2], 0.f)};
+        return;
+    }
     if (a.layout == TTUP_LAYOUT_NCHW_F32) {
         float* o = (float*)a.out + (size_t)t * 3 * a.nf * hw + pix;
         for (int c = 0; c < 3 * a.nf; ++c) o[c * hw] = vals[c];
@@ -1762,7 +1801,8 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     if (a.total == 0) return TTUP_OK;
     if (int rc = device_normalise_lut(&a.lut)) return rc;       // one table per device
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
-    if (dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32)
+    TTUP_REQUIRE(out_layout != TTUP_LAYOUT_NHWC4_FRAME || (frames_per_sample == 1 && dtype == TTUP_DTYPE_BF16), TTUP_EINVAL, "per-frame records are bf16, one frame per sample");
+    if ((dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32) && out_layout != TTUP_LAYOUT_NHWC4_FRAME)
         hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);

@@ -13,7 +13,7 @@ int launch_upsum_head(const void* base, const void* const* terms, const int* shi
 int refine_argmax(const float* heat, int n_maps, int H, int W, long long* argmax, float* win, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_argmax_finish(const float* heat, int n_maps, int H, int W, int nblk, const float* pv, const long long* pi, long long* argmax, float* win, hipStream_t st);
 
-struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; };
+struct Tensor { void* ptr = nullptr; int c = 0, h = 0, w = 0; int extra = 0; };     // (micro + extra, h, w, c)
 
 struct Op {
     enum Kind { CONV, UPSUM, BNECK_TRANS, BB_CHAIN, UPSUM_HEAD, STEM } kind = CONV;
@@ -28,6 +28,7 @@ struct Op {
     // dst2 = the summed output; head = 1: stage-4 output, never stored -- the 1x1 head + argmax partials are computed from it
     // (launched by run_head_op, which knows the output buffers); dst = -1 when the pre-fuse branch tensor has no consumer
     int head = 0;
+    int conv1f = -1;                            // STEM: conv1 packed for the frames mode (channel slot f*4 + c)
 };
 
 // Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle
@@ -38,6 +39,7 @@ struct CertState {
     int K = 32;                          // candidates kept per heatmap
     int maxc = 4;                        // crops per heatmap
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
+    int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
     struct ::ttup_wasb* cropnet = nullptr;  // fp32 handle at crop size, batch CH
     int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
     int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
@@ -53,6 +55,8 @@ struct ttup_wasb {
     std::vector<ttup::Op> ops;
     std::map<std::string, int> taps;
     int t_input = -1, t_out = -1;
+    int t_frames = -1;                  // bf16 stem frames mode: (micro + nf - 1, H, W, 4) per-frame pre-processed records
+    bool frames_mode = false;           // what the stem op reads in the current pass (set by forward_micro)
     float* head_w_dev = nullptr; float* head_b_dev = nullptr; float head_bias = 0.f;
     int n_out = 1;                      // heatmap channels returned: 1 (ball: channel 1 of 3, wasb.py:606) or all 13 (table, hrnet.py:586-589)
     float* heat_scratch = nullptr;      // (micro,H,W) when the caller does not want heatmaps

@@ -283,13 +283,31 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
     int stem_a1 = -1;
     if (fuse_c1 && !getenv("TTUP_NO_STEM")) {
         // conv1 + conv2 + Bottleneck conv1 in one persistent kernel; the first 64-channel tensor never reaches HBM
-        const int p1 = b.pack(b.next(64, net->in_ch, 3, 1), nullptr, 16);
+        const FoldedConv& c1 = b.next(64, net->in_ch, 3, 1);
+        const int p1 = b.pack(c1, nullptr, 16);
+        // the same conv for the stem's frames mode: input slot f*4 + c holds colour c of frame f (slot 3 of every frame and the
+        // slots past the last frame carry zero weights)
+        FoldedConv c1f = c1;
+        c1f.cin = 16; c1f.w.assign((size_t)64 * 16 * 9, 0.f);
+        for (int co = 0; co < 64 && b.rc == TTUP_OK; ++co)
+            for (int ci = 0; ci < net->in_ch; ++ci)
+                for (int t = 0; t < 9; ++t) c1f.w[((size_t)co * 16 + (ci / 3) * 4 + ci % 3) * 9 + t] = c1.w[((size_t)co * net->in_ch + ci) * 9 + t];
+        const int p1f = b.pack(c1f, nullptr, 16);
         const int p2 = b.pack(b.next(64, 64, 3, 1), nullptr, 0);
         const int p3 = b.pack(b.next(32, 64, 1, 1), nullptr, 0);
         x = b.new_tensor(64, H, W); net->taps["stem2"] = x;
         stem_a1 = b.new_tensor(32, H, W);
         Op op; op.kind = Op::STEM; op.conv = p1; op.conv2 = p2; op.conv3 = p3; op.src0 = net->t_input; op.dst = x; op.dst2 = stem_a1;
+        op.conv1f = p1f;
         net->ops.push_back(op);
+        if (!getenv("TTUP_NO_FRAMES_MODE")) {
+            // (micro + nf - 1) frames of (H, W, 4) bf16: allocated through the tensor list so that every lane gets its own copy
+            Tensor t; t.c = 4; t.h = H; t.w = W; t.extra = net->in_ch / 3 - 1;
+            const size_t bytes = (size_t)(net->micro + net->in_ch / 3 - 1) * H * W * 4 * 2;
+            if (hipMalloc(&t.ptr, bytes) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); b.rc = TTUP_ENOMEM; t.ptr = nullptr; }
+            net->tensors.push_back(t);
+            net->t_frames = (int)net->tensors.size() - 1;
+        }
     } else {
         {
             const FoldedConv& f = b.next(64, net->in_ch, 3, 1);
@@ -371,8 +389,9 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             if (rc) return rc;
         } else if (op.kind == Op::STEM) {
             const Tensor& s = net->tensors[op.src0];
-            const int rc = launch_stem(net->convs[op.conv], net->convs[op.conv2], net->convs[op.conv3], s.ptr, net->tensors[op.dst].ptr,
-                                       net->tensors[op.dst2].ptr, mb, s.h, s.w, st);
+            const bool fm = net->frames_mode && net->t_frames >= 0 && op.conv1f >= 0;
+            const int rc = launch_stem(net->convs[fm ? op.conv1f : op.conv], net->convs[op.conv2], net->convs[op.conv3], fm ? net->tensors[net->t_frames].ptr : s.ptr,
+                                       net->tensors[op.dst].ptr, net->tensors[op.dst2].ptr, mb, s.h, s.w, st, fm ? net->in_ch / 3 : 0);
             if (rc) return rc;
         } else if (op.kind == Op::UPSUM_HEAD) {
             return TTUP_OK;       // launched by forward_micro (run_head_op), which knows the output buffers
@@ -451,8 +470,12 @@ int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev,
     const int mb = batch - b0 < net->micro ? batch - b0 : net->micro;
     net->use_lane(lane);
     int rc;
+    const int nf = net->in_ch / 3;
+    net->frames_mode = !x_dev && net->t_frames >= 0;
     if (x_dev) rc = launch_nchw_to_nhwc(x_dev + (size_t)b0 * net->in_ch * hw, net->tensors[net->t_input].ptr, mb, net->in_ch, 16, H, W, net->dtype, st);
-    else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, net->in_ch / 3, st);
+    else if (net->frames_mode)      // every frame of the micro-batch (mb + nf - 1 of them) is pre-processed once; the stem assembles the samples
+        rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_frames].ptr, TTUP_LAYOUT_NHWC4_FRAME, net->dtype, b0, mb + nf - 1, 1, st);
+    else rc = launch_preprocess(frames_dev, n_frames, src_h, src_w, H, W, net->tensors[net->t_input].ptr, TTUP_LAYOUT_NHWC16, net->dtype, b0, mb, nf, st);
     if (rc) return rc;
     rc = run_graph(net, mb, st);
     if (rc) return rc;
@@ -569,7 +592,7 @@ int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, i
             for (size_t i = 0; i < net->tensors.size(); ++i) {
                 const Tensor& t = net->tensors[i];
                 if (l == 0) { L.ptr[i] = t.ptr; continue; }      // lane 0 adopts the buffers the builder allocated
-                TTUP_HIP_CHECK(hipMalloc(&L.ptr[i], (size_t)net->micro * t.h * t.w * t.c * net->esize()));
+                TTUP_HIP_CHECK(hipMalloc(&L.ptr[i], (size_t)(net->micro + t.extra) * t.h * t.w * t.c * net->esize()));
             }
             TTUP_HIP_CHECK(hipMalloc((void**)&L.heat_scratch, (size_t)net->micro * net->n_out * hw * sizeof(float)));
             TTUP_HIP_CHECK(hipMalloc(&L.refine_ws, net->refine_ws_bytes));

@@ -149,6 +149,10 @@ class StreamWorker:
 
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
+        if ticket.get('status') is not None:
+            # crop budget of the next clips: twice what this clip needed (+ slack); clips that outgrow it are flagged and repaired below
+            need = int((ticket['status'].numpy() == 1).sum())
+            self.net.certify_budget(2 * need + 16)
         if ticket.get('status') is not None and (ticket['status'].numpy() == 2).any():
             ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], ticket['status'].numpy())
             ticket['host'].copy_(ticket['xyv'])

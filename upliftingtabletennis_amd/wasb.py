@@ -132,6 +132,10 @@ class WASBNet:
         self.set_certify(eps, crop, max_crops_per_map)
         return eps
 
+    def certify_budget(self, max_crops):
+        """Crops the following forward calls may use (saves empty fp32 passes when the typical count is known)."""
+        _lib.check(self._lib.ttup_wasb_certify_budget(self._handle, int(max_crops)))
+
     def certify_status(self, batch):
         """Per-heatmap status of the last forward: 0 single candidate, 1 resolved on fp32 crops, 2 not certified."""
         st = torch.empty((batch,), dtype=torch.int32, device=self.device)
