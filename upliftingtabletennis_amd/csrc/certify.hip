@@ -179,32 +179,43 @@ __global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int*
 void cert_free(ttup_wasb* net) {
     CertState& c = net->cert;
     if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
-    void* ptrs[] = {c.cand_idx, c.cand_cnt, c.cand_crop, c.cand_val, c.cand_win, c.crop_rec, c.n_crops, c.n_active, c.status, c.stats, c.crop_heat};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    c.cand_idx = c.cand_cnt = c.cand_crop = c.crop_rec = c.n_crops = c.n_active = c.status = nullptr;
-    c.cand_val = c.cand_win = c.crop_heat = nullptr; c.stats = nullptr;
+    for (auto& sl : c.slot) {
+        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.crop_rec, sl.n_crops, sl.n_active, sl.status};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        sl = CertState::Slot();
+    }
+    if (c.stats) (void)hipFree(c.stats);
+    if (c.crop_heat) (void)hipFree(c.crop_heat);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    if (c.lanes_done) (void)hipEventDestroy(c.lanes_done);
+    c.stats = nullptr; c.crop_heat = nullptr; c.stream = nullptr; c.lanes_done = nullptr;
     c.enabled = false;
 }
 
 int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
     CertState& c = net->cert;
-    TTUP_HIP_CHECK(hipMemsetAsync(c.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
-    TTUP_HIP_CHECK(hipMemsetAsync(c.n_crops, 0, sizeof(int), caller));
-    TTUP_HIP_CHECK(hipMemsetAsync(c.status, 0, (size_t)batch * sizeof(int), caller));
+    c.cur ^= 1;
+    CertState::Slot& sl = c.slot[c.cur];
+    TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // the call that last used this slot has finished its fp32 passes
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.n_crops, 0, sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.status, 0, (size_t)batch * sizeof(int), caller));
     return TTUP_OK;
 }
 
 int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0, int mb, hipStream_t st) {
     CertState& c = net->cert;
+    CertState::Slot& sl = c.slot[c.cur];
     const long long hw = (long long)net->H * net->W;
     int nblk = (int)(hw / 4 / 256 / 8);           // 8 float4 per thread
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
-                       c.cand_idx + (size_t)b0 * c.K, c.cand_cnt + b0);
+                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0);
     TTUP_LAUNCH_CHECK();
     PlanArgs a;
-    a.cand_idx = c.cand_idx; a.cand_cnt = c.cand_cnt; a.cand_crop = c.cand_crop; a.crop_rec = c.crop_rec; a.n_crops = c.n_crops;
-    a.status = c.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
+    a.cand_idx = sl.cand_idx; a.cand_cnt = sl.cand_cnt; a.cand_crop = sl.cand_crop; a.crop_rec = sl.crop_rec; a.n_crops = sl.n_crops;
+    a.status = sl.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
     a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
@@ -212,26 +223,32 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
 }
 
 int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int batch,
-                int64_t* argmax_dev, float* win_dev, hipStream_t st) {
+                int64_t* argmax_dev, float* win_dev, hipStream_t caller) {
     CertState& c = net->cert;
+    CertState::Slot& sl = c.slot[c.cur];
     ttup_wasb* cn = c.cropnet;
-    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, c.n_crops, c.n_active, c.CH, c.nchunks, c.budget);
+    // the fp32 passes run on the handle's own stream, behind everything the caller's stream has seen (the bf16 micro-batches
+    // have been joined into it): a following call issued on ANOTHER caller stream overlaps with them
+    hipStream_t st = c.stream;
+    TTUP_HIP_CHECK(hipEventRecord(c.lanes_done, caller));
+    TTUP_HIP_CHECK(hipStreamWaitEvent(st, c.lanes_done, 0));
+    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, sl.n_crops, sl.n_active, c.CH, c.nchunks, c.budget);
     TTUP_LAUNCH_CHECK();
     // fp32 passes that can hold crops of THIS call: at most maxc per heatmap, at most the caller's budget
     int nch = cdiv(batch * c.maxc < c.budget ? batch * c.maxc : c.budget, c.CH);
     nch = nch > c.nchunks ? c.nchunks : nch;
     for (int ch = 0; ch < nch; ++ch) {
         const int crop0 = ch * c.CH;
-        const int* na = c.n_active + ch;
+        const int* na = sl.n_active + ch;
         cn->use_lane(0);
         float* xin = (float*)cn->tensors[cn->t_input].ptr;
         if (frames_dev) {
-            const int rc = launch_preprocess_crops(frames_dev, n_frames, src_h, src_w, net->H, net->W, xin, c.crop_rec, crop0, na, c.CH, c.Hc, c.Wc, net->in_ch / 3, st);
+            const int rc = launch_preprocess_crops(frames_dev, n_frames, src_h, src_w, net->H, net->W, xin, sl.crop_rec, crop0, na, c.CH, c.Hc, c.Wc, net->in_ch / 3, st);
             if (rc) return rc;
         } else {
             const long long total = (long long)c.CH * c.Hc * c.Wc;
             hipLaunchKernelGGL(cert_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x_dev, net->in_ch, net->H, net->W,
-                               (const int*)c.crop_rec, crop0, na, c.Hc, c.Wc, xin, total);
+                               (const int*)sl.crop_rec, crop0, na, c.Hc, c.Wc, xin, total);
             TTUP_LAUNCH_CHECK();
         }
         cn->n_active = na;
@@ -240,14 +257,16 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
         cn->n_active = nullptr;
         if (rc) return rc;
         const int nthr = batch * c.K;
-        hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)c.cand_idx, (const int*)c.cand_cnt, (const int*)c.cand_crop,
-                           (const int*)c.status, (const int*)c.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch,
-                           c.cand_val, c.cand_win);
+        hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.cand_crop,
+                           (const int*)sl.status, (const int*)sl.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch,
+                           sl.cand_val, sl.cand_win);
         TTUP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch, 64)), dim3(64), 0, st, (const int*)c.cand_idx, (const int*)c.cand_cnt, (const int*)c.status,
-                       (const float*)c.cand_val, (const float*)c.cand_win, c.K, batch, (long long*)argmax_dev, win_dev);
+    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.status,
+                       (const float*)sl.cand_val, (const float*)sl.cand_win, c.K, batch, (long long*)argmax_dev, win_dev);
     TTUP_LAUNCH_CHECK();
+    TTUP_HIP_CHECK(hipEventRecord(sl.done, st));
+    TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // outputs are final in the caller's stream order
     return TTUP_OK;
 }
 
@@ -280,18 +299,23 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     c.max_crops = c.nchunks * c.CH;
     c.budget = c.max_crops;
     const size_t nb = (size_t)net->max_batch;
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_idx, nb * c.K * sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_cnt, nb * sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_crop, nb * c.K * sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_val, nb * c.K * sizeof(float)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.cand_win, nb * c.K * 9 * sizeof(float)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.n_crops, sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.n_active, (size_t)c.nchunks * sizeof(int)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.status, nb * sizeof(int)));
+    for (auto& sl : c.slot) {
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_idx, nb * c.K * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_cnt, nb * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_crop, nb * c.K * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_val, nb * c.K * sizeof(float)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_win, nb * c.K * 9 * sizeof(float)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_crops, sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_active, (size_t)c.nchunks * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.status, nb * sizeof(int)));
+        TTUP_HIP_CHECK(hipMemset(sl.status, 0, nb * sizeof(int)));
+        TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    TTUP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    TTUP_HIP_CHECK(hipEventCreateWithFlags(&c.lanes_done, hipEventDisableTiming));
     TTUP_HIP_CHECK(hipMalloc((void**)&c.stats, 8 * sizeof(unsigned long long)));
     TTUP_HIP_CHECK(hipMemset(c.stats, 0, 8 * sizeof(unsigned long long)));
-    TTUP_HIP_CHECK(hipMemset(c.status, 0, nb * sizeof(int)));
     TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * c.Hc * c.Wc * sizeof(float)));
     const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
     if (rc) { cert_free(net); return rc; }
@@ -310,7 +334,7 @@ extern "C" int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_d
     TTUP_REQUIRE(net && status_dev, TTUP_EINVAL, "ttup_wasb_certify_status: null pointer");
     TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_status: the certified argmax is not enabled on this handle");
     TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_certify_status: batch %d outside [0,%d]", batch, net->max_batch);
-    TTUP_HIP_CHECK(hipMemcpyAsync(status_dev, net->cert.status, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    TTUP_HIP_CHECK(hipMemcpyAsync(status_dev, net->cert.slot[net->cert.cur].status, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return TTUP_OK;
 }
 

@@ -41,10 +41,18 @@ struct CertState {
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
     struct ::ttup_wasb* cropnet = nullptr;  // fp32 handle at crop size, batch CH
-    int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
-    int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
+    // Per-call state, two slots used alternately: the fp32 passes of call k run on the handle's own stream (`stream`) while the
+    // bf16 micro-batches of call k+1 -- issued on another caller stream -- already fill slot (k+1)&1
+    struct Slot {
+        int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
+        int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
+        hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
+    } slot[2];
+    int cur = 0;                            // slot of the call being issued / last issued
     unsigned long long* stats = nullptr;
     float* crop_heat = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t lanes_done = nullptr;
 };
 }  // namespace ttup
 

@@ -128,6 +128,18 @@ class StreamWorker:
     # and enqueues the uplift.  Submitting clip k+1 before collecting clip k keeps the GPU busy while the host filters
     # and pads the detections of clip k.
     def submit(self, frames_u8):
+        # consecutive clips are issued on two alternating streams: the fp32 crop passes of the certified argmax (the handle's own
+        # stream, behind clip k's bf16 pass) then overlap with the bf16 micro-batches of clip k+1 instead of delaying them
+        subs = self.__dict__.setdefault('_sub', None)
+        if subs is None:
+            subs = self._sub = {'streams': [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], 'next': 0}
+        sub = subs['streams'][subs['next']]
+        subs['next'] ^= 1
+        sub.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(sub):
+            return self._submit(frames_u8, sub)
+
+    def _submit(self, frames_u8, sub):
         xyv, idx, win, status = self._detect(frames_u8)
         ring = self.__dict__.setdefault('_pinned', {})          # two pinned buffers per shape, used alternately
         slot = ring.setdefault(tuple(xyv.shape), {'bufs': [None, None], 'next': 0})
@@ -145,10 +157,13 @@ class StreamWorker:
             st_host.copy_(status, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host}
+        for t in (xyv, idx, win, frames_u8) + ((status,) if status is not None else ()):
+            t.record_stream(sub)
+        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host, 'stream': sub}
 
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
+        torch.cuda.current_stream(self.device).wait_stream(ticket['stream'])
         if ticket.get('status') is not None:
             # crop budget of the next clips: twice what this clip needed (+ slack); clips that outgrow it are flagged and repaired below
             need = int((ticket['status'].numpy() == 1).sum())
