@@ -50,8 +50,9 @@ def gather_records(records, dist=None, dst=0):
         mx = max(sizes + [1])
         pad = torch.zeros((mx,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
         pad[:v.shape[0]] = v
-        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-        dist.gather(pad, bufs, dst=dst)
+        # all_gather (every backend implements it on device tensors; the records are a few KB) and keep the result on `dst` only
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
         if rank == dst:
             out[k] = [b[:s] for b, s in zip(bufs, sizes)]
     return out
