@@ -11,7 +11,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; S=$O/summary
 rm -rf $O; mkdir -p $S
 cd $R
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt2 -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 4 > $S/${TAG}_bench_lanes2.json 2> $O/kt2.err
-TTUP_LANES=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt1 -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 4 > $S/${TAG}_bench_lanes1.json 2> $O/kt1.err
+# one lane and no fp32 crop passes: nothing overlaps, the per-kernel averages are isolated launch durations (= roofline.launch_ms)
+TTUP_LANES=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt1 -o kt -- python3 bench.py --no-cpu-baseline --no-extras --no-certify --steps 4 > $S/${TAG}_bench_lanes1.json 2> $O/kt1.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/ktu -o kt -- python3 tools/bench_uplift.py > $O/ktu.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- python3 tools/prof_cnn.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- python3 tools/prof_cnn.py > $O/pmc_write.log 2>&1
