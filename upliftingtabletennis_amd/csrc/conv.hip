@@ -966,7 +966,15 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         u32x2 tpre[XT][3];
         if constexpr (CAN_SUM) {
             if (ex && ex->nsum > 0) {
-                const int gyp = gy0 + y;
+                // the row part of every address is the same for the whole wave: it goes through the scalar unit
+                const int gyp = __builtin_amdgcn_readfirstlane(gy0 + y);
+                const bf16_t* trow[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int sh = k < ex->nsum ? ex->ssh[k] : 0;
+                    const int gyc = gyp < 0 ? 0 : gyp;
+                    trow[k] = (k < ex->nsum ? ex->st[k] : ex->st[0]) + ((size_t)(b * (H >> sh) + (gyc >> sh)) * (W >> sh)) * 16 + g * 4;
+                }
 #pragma unroll
                 for (int xt = 0; xt < XT; ++xt) {
                     const int gxp = gx0 + xt * 16 + n;
@@ -974,10 +982,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         tpre[xt][k] = u32x2{0u, 0u};
-                        if (k < ex->nsum && livep) {
-                            const int sh = ex->ssh[k];
-                            tpre[xt][k] = *(const u32x2*)(ex->st[k] + ((size_t)(b * (H >> sh) + (gyp >> sh)) * (W >> sh) + (gxp >> sh)) * 16 + g * 4);
-                        }
+                        if (k < ex->nsum && livep) tpre[xt][k] = *(const u32x2*)(trow[k] + ((gxp >> ex->ssh[k]) << 4));
                     }
                 }
             }
