@@ -5,7 +5,7 @@
 `scipy.spatial.transform.Rotation`).
 
 Pinned: tests/golden/calib.npz was produced by the reference's own `calibrate_camera` (tools/make_goldens.py:gen_calib) and
-this restatement reproduces it bit for bit on the build container (tests/test_oracle_golden.py).  The product path is the
+this restatement reproduces it bit for bit on the build container (tests/test_cabi.py::test_calibration_oracle_matches_reference_and_host_glue).  The product path is the
 device solver csrc/calib.hip behind upliftingtabletennis_amd/calib.py; nothing there imports this file.
 """
 import numpy as np
