@@ -60,6 +60,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libttup.so not found at %s: build it with `python -m upliftingtabletennis_amd.build` '
                                '(hipcc, gfx950).  There is no CPU fallback.' % LIB_PATH)
+        # torch first: its wheel bundles the HIP runtime the process must share (one libamdhip64 per process); loading
+        # libttup.so before torch would pull in /opt/rocm's copy and leave the two runtimes with separate device state
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
