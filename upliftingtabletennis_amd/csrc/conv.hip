@@ -76,6 +76,19 @@ __device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
     return ((iy * IW + ix) * (CK / 8) + c8) * 8;
 }
 
+// Copy UNITS 16-byte units from global memory into LDS with a 512-thread workgroup: every thread issues ALL of its loads before
+// its first LDS store, i.e. one memory round trip for the block (a plain `for (u = tid; u < n; u += 512) dst[u] = src[u]` loop
+// compiles to load / wait / store per iteration: UNITS / 512 serial round trips at the start of every persistent kernel).
+template <int UNITS>
+__device__ __forceinline__ void stage_block_512(bf16_t* dst, const bf16_t* src, int tid) {
+    constexpr int PT = (UNITS + 511) / 512;
+    u32x4 v[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) { const int u = tid + k * 512; v[k] = u32x4{0u, 0u, 0u, 0u}; if (u < UNITS) v[k] = ((const u32x4*)src)[u]; }
+#pragma unroll
+    for (int k = 0; k < PT; ++k) { const int u = tid + k * 512; if (u < UNITS) ((u32x4*)dst)[u] = v[k]; }
+}
+
 // Persistent, software-pipelined version: a workgroup walks work items (tile, channel chunk); the global loads of
 // item i+1 (halo tile chunk + that chunk's weight fragments) are issued into registers BEFORE the MFMA loop of item i
 // and written to LDS after it, so HBM/L2 latency hides behind the matrix work (single LDS buffer, two barriers per item).
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     bf16_t* s_in = s_w + W_U * 8;                               // [2 chunks][340 px][32 ch]  43,520 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    for (int u = tid; u < W_U; u += 512) ((u32x4*)s_w)[u] = ((const u32x4*)a.wpack)[u];
+    stage_block_512<W_U>(s_w, a.wpack, tid);
     f32x4 bias[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) bias[m] = *(const f32x4*)(a.bias + g * 16 + m * 4);
@@ -453,8 +466,8 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 ch]            13,824 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
-    for (int u = tid; u < W2_U; u += 512) ((u32x4*)s_w2)[u] = ((const u32x4*)a.w2)[u];
+    stage_block_512<W1_U>(s_w1, a.w1, tid);
+    stage_block_512<W2_U>(s_w2, a.w2, tid);
     // Follower weights with the K order permuted to the conv2 accumulator layout: a lane owns channels g*16 .. g*16+15 of
     // its pixel, so k-step k takes channels 16g + 8k + j from lane group g -- the bf16 pairs it has just packed -- and the
     // T2 tile never goes through LDS.  In the standard packing those channels sit at k-step g>>1, lane group 2(g&1)+k.
@@ -691,8 +704,8 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     float* s_b1 = (float*)(s_w5 + W5_U * 8);                    // 512 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    for (int u = tid; u < W1_U; u += 512) ((u32x4*)s_w1)[u] = ((const u32x4*)a.w1)[u];
-    for (int u = tid; u < W5_U; u += 512) ((u32x4*)s_w5)[u] = ((const u32x4*)a.w5)[u];
+    stage_block_512<W1_U>(s_w1, a.w1, tid);
+    stage_block_512<W5_U>(s_w5, a.w5, tid);
     if (tid < 128) s_b1[tid] = a.b1[tid];
     const int cc = wave & 3, m6 = wave >> 2;
     bf16x8 af6[9];
@@ -895,6 +908,16 @@ template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
     return pix * C + ((c8 ^ ((x >> 2) & 1)) << 3);
 }
 
+// Weight fragments + bias of one 16-channel conv, loaded by the CALLER: the chain kernel requests the next conv's fragments from
+// L2 before the barrier that ends the current conv, so their latency (the first MFMA of a conv needs all of them) hides behind
+// the barrier wait instead of following it.
+struct BBFrag16 { bf16x8 af[5]; f32x4 bias; };
+__device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag, const float* biasp, int lane) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) f.af[s] = *(const bf16x8*)(wfrag + (s * 64 + lane) * 8);
+    f.bias = *(const f32x4*)(biasp + (lane >> 4) * 4);
+}
+
 // One 3x3 conv of the chain.  Input buffer: row stride RWI pixels, region origin at (IOFF,IOFF).  Output region RHO x RWO.
 // SECOND: second conv of a BasicBlock -> adds the block input (buffer s_res, row stride RWR, origin offset ROFF) and the
 // result either overwrites that buffer in place (ORW = RWR, OOFF = ROFF: each pixel is read and written by the same lane)
@@ -904,16 +927,21 @@ template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int 
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
-                                        const BBArgs* ex = nullptr, BBBest* best = nullptr) {
+                                        const BBArgs* ex = nullptr, BBBest* best = nullptr, const BBFrag16* pre = nullptr) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
     const int n = lane & 15, g = lane >> 4;
     bf16x8 af[KSTEPS][MT];
+    if (C == 16 && pre) {
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
+        for (int s = 0; s < KSTEPS; ++s) af[s][0] = pre->af[s < 5 ? s : 4];
+    } else {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[s][m] = *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[s][m] = *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
+    }
     // C=16, second conv of a block: the unused tenth tap of the last k-step (lanes g >= 2, zero weights) carries the block
     // input through an identity matrix, so the residual add happens inside the MFMA (exact: bf16 * 1.0 into the fp32 sum)
     constexpr bool RES_MFMA = SECOND && C == 16;
@@ -924,8 +952,11 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         af[KSTEPS - 1][0] = __builtin_bit_cast(bf16x8, idm);
     }
     f32x4 bias[MT];
+    if (C == 16 && pre) bias[0] = pre->bias;
+    else {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) bias[m] = *(const f32x4*)(biasp + g * 4 * MT + m * 4);
+        for (int m = 0; m < MT; ++m) bias[m] = *(const f32x4*)(biasp + g * 4 * MT + m * 4);
+    }
     int koff[KSTEPS];                     // per-lane tap/channel offset of every k-step (elements)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
@@ -1190,7 +1221,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
 // Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
 template <int C, int TH, int TW>
-__global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
+__global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int L = 4;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
     constexpr int SZ_A = R0H * R0W * C;
@@ -1205,28 +1236,49 @@ __global__ __launch_bounds__(512) void bb_chain2_kernel(BBArgs a) {
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     TTUP_STAMP(0);
-    for (int u = tid; u < R0H * R0W * (C / 8); u += 512) {
-        const int c8 = u % (C / 8), pix = u / (C / 8);
-        const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
-        *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v;
+    BBFrag16 fr;
+    {
+        // all of the thread's loads are issued before the first LDS store: ONE memory round trip for the tile, not one per unit
+        constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 511) / 512;
+        u32x4 v[IN_PT];
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u % (C / 8), pix = u / (C / 8);
+            const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v[k] = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u % (C / 8), pix = u / (C / 8);
+            if (u < IN_UNITS) *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v[k];
+        }
     }
+    if (C == 16) bb_load_frag16(fr, a.w[0], a.bias[0], lane);          // first conv's fragments: in flight across the barrier
     __syncthreads();
     TTUP_STAMP(1);
-    bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
+    const BBFrag16* pre = C == 16 ? &fr : nullptr;
+    bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane,
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, pre);
     TTUP_STAMP(2);
+    if (C == 16) bb_load_frag16(fr, a.w[1], a.bias[1], lane);          // next conv's fragments: requested BEFORE the barrier
     __syncthreads();
     TTUP_STAMP(3);
-    bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane);
+    bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane,
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, pre);
+    if (C == 16) bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
     TTUP_STAMP(4);
-    bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+    bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane,
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, pre);
+    if (C == 16) bb_load_frag16(fr, a.w[3], a.bias[3], lane);
     __syncthreads();
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
     bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
-                                                             nullptr, nullptr, nullptr, &a, &best);
+                                                             nullptr, nullptr, nullptr, &a, &best, pre);
     if (C == 16 && a.heat) {
         // argmax partial of this tile: lanes -> wave (DPP shuffles) -> workgroup (through the now idle LDS)
 #pragma unroll
