@@ -79,14 +79,16 @@ __device__ __forceinline__ int lds_off(int iy, int ix, int c8) {
 // Copy UNITS 16-byte units from global memory into LDS with a 512-thread workgroup: every thread issues ALL of its loads before
 // its first LDS store, i.e. one memory round trip for the block (a plain `for (u = tid; u < n; u += 512) dst[u] = src[u]` loop
 // compiles to load / wait / store per iteration: UNITS / 512 serial round trips at the start of every persistent kernel).
+template <int UNITS> struct StageRegs { u32x4 v[(UNITS + 511) / 512]; };
 template <int UNITS>
-__device__ __forceinline__ void stage_block_512(bf16_t* dst, const bf16_t* src, int tid) {
-    constexpr int PT = (UNITS + 511) / 512;
-    u32x4 v[PT];
+__device__ __forceinline__ void stage_load_512(StageRegs<UNITS>& r, const bf16_t* src, int tid) {
 #pragma unroll
-    for (int k = 0; k < PT; ++k) { const int u = tid + k * 512; v[k] = u32x4{0u, 0u, 0u, 0u}; if (u < UNITS) v[k] = ((const u32x4*)src)[u]; }
+    for (int k = 0; k < (UNITS + 511) / 512; ++k) { const int u = tid + k * 512; r.v[k] = u32x4{0u, 0u, 0u, 0u}; if (u < UNITS) r.v[k] = ((const u32x4*)src)[u]; }
+}
+template <int UNITS>
+__device__ __forceinline__ void stage_store_512(bf16_t* dst, const StageRegs<UNITS>& r, int tid) {
 #pragma unroll
-    for (int k = 0; k < PT; ++k) { const int u = tid + k * 512; if (u < UNITS) ((u32x4*)dst)[u] = v[k]; }
+    for (int k = 0; k < (UNITS + 511) / 512; ++k) { const int u = tid + k * 512; if (u < UNITS) ((u32x4*)dst)[u] = r.v[k]; }
 }
 
 // Persistent, software-pipelined version: a workgroup walks work items (tile, channel chunk); the global loads of
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     bf16_t* s_in = s_w + W_U * 8;                               // [2 chunks][340 px][32 ch]  43,520 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    stage_block_512<W_U>(s_w, a.wpack, tid);
+    StageRegs<W_U> wregs;
+    stage_load_512<W_U>(wregs, a.wpack, tid);           // weights and the first tile travel together: one round trip before the loop
     f32x4 bias[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) bias[m] = *(const f32x4*)(a.bias + g * 16 + m * 4);
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
         }
     };
     if (my_tiles > 0) issue(0);
+    stage_store_512<W_U>(s_w, wregs, tid);
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
@@ -466,8 +470,9 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 ch]            13,824 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    stage_block_512<W1_U>(s_w1, a.w1, tid);
-    stage_block_512<W2_U>(s_w2, a.w2, tid);
+    StageRegs<W1_U> w1regs; StageRegs<W2_U> w2regs;
+    stage_load_512<W1_U>(w1regs, a.w1, tid);            // stored to LDS after the first tile's loads have been issued (below)
+    stage_load_512<W2_U>(w2regs, a.w2, tid);
     // Follower weights with the K order permuted to the conv2 accumulator layout: a lane owns channels g*16 .. g*16+15 of
     // its pixel, so k-step k takes channels 16g + 8k + j from lane group g -- the bf16 pairs it has just packed -- and the
     // T2 tile never goes through LDS.  In the standard packing those channels sit at k-step g>>1, lane group 2(g&1)+k.
@@ -525,6 +530,8 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         }
     };
     if (my_tiles > 0) issue(0);
+    stage_store_512<W1_U>(s_w1, w1regs, tid);
+    stage_store_512<W2_U>(s_w2, w2regs, tid);
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = blockIdx.x + it * gridDim.x;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
@@ -704,9 +711,10 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     float* s_b1 = (float*)(s_w5 + W5_U * 8);                    // 512 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    stage_block_512<W1_U>(s_w1, a.w1, tid);
-    stage_block_512<W5_U>(s_w5, a.w5, tid);
-    if (tid < 128) s_b1[tid] = a.b1[tid];
+    StageRegs<W1_U> w1regs; StageRegs<W5_U> w5regs;
+    stage_load_512<W1_U>(w1regs, a.w1, tid);            // stored to LDS after the first tile's loads have been issued (below)
+    stage_load_512<W5_U>(w5regs, a.w5, tid);
+    const float b1v = tid < 128 ? a.b1[tid] : 0.f;
     const int cc = wave & 3, m6 = wave >> 2;
     bf16x8 af6[9];
 #pragma unroll
@@ -737,6 +745,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         }
     };
     if (my_tiles > 0) issue_pix(0);
+    stage_store_512<W1_U>(s_w1, w1regs, tid);
+    stage_store_512<W5_U>(s_w5, w5regs, tid);
+    if (tid < 128) s_b1[tid] = b1v;
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = blockIdx.x + it * gridDim.x;
@@ -1175,9 +1186,21 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) ((u32x4*)(s_wt + slot * W_UNITS * 8))[u] = pwt[k]; }
     };
     if (RESIDENT) {
-        for (int cv = 0; cv < 2 * NB; ++cv) { load_wt(cv); store_wt(cv); }
-    } else if (!WGLOBAL && my_tiles > 0) load_wt(0);
-    if (my_tiles > 0) issue_in(0);
+        // the first tile and both convs' weights travel together: one round trip before the loop
+        if (my_tiles > 0) issue_in(0);
+        u32x4 pw2[2 * NB][W_PT];
+#pragma unroll
+        for (int cv = 0; cv < 2 * NB; ++cv)
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; pw2[cv][k] = u32x4{0u, 0u, 0u, 0u}; if (u < W_UNITS) pw2[cv][k] = ((const u32x4*)a.w[cv])[u]; }
+#pragma unroll
+        for (int cv = 0; cv < 2 * NB; ++cv)
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) ((u32x4*)(s_wt + cv * W_UNITS * 8))[u] = pw2[cv][k]; }
+    } else {
+        if (!WGLOBAL && my_tiles > 0) load_wt(0);
+        if (my_tiles > 0) issue_in(0);
+    }
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = blockIdx.x + it * gridDim.x;

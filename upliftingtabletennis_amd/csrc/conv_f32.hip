@@ -38,52 +38,86 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvF32Args a) {
     const int cin = a.c0 + a.c1, nchunk = cin / CK, wstr = a.wstr;
     const int batch = a.n_active ? *a.n_active : a.batch;
     const int total = a.tiles_per_img * (batch < a.batch ? batch : a.batch);
-    const int w_units = TAPS * CK * (a.cout / 4);                 // float4 units of one weight chunk
-    const int cq = a.cout / 4;
-    for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    constexpr int CQ = MT * 4;                                     // float4 units per weight row
+    constexpr int W_UNITS = TAPS * CK * CQ, W_PT = (W_UNITS + 255) / 256;
+    constexpr int X_UNITS = NPIX * 2, X_PT = (X_UNITS + 255) / 256;
+    const int my_tiles = total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int n_items = my_tiles * nchunk;
+    // Software pipeline over (tile, channel chunk) items: the global loads of item i+1 (input chunk + weight chunk) are issued
+    // into registers before the MFMA loop of item i and written to LDS after it -- one memory round trip per item, hidden
+    // behind the matrix work (a plain load / store loop costs one round trip per 256-unit slice: up to 11 per item).
+    f32x4 px[X_PT], pw[W_PT];
+    auto issue = [&](int item) {
+        const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * TH * S - PAD, gx0 = (t % a.tiles_x) * TW * S - PAD;
+        const int cb = chunk * CK;
+        const bool first = cb < a.c0;
+        const float* src = first ? a.src0 : a.src1;
+        const int csrc = first ? a.c0 : a.c1, ch0 = first ? cb : cb - a.c0;
+#pragma unroll
+        for (int k = 0; k < X_PT; ++k) {
+            const int u = tid + k * 256;
+            const int p = u >> 1, half = u & 1;
+            const int gy = gy0 + p / IW, gx = gx0 + p % IW;
+            px[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) px[k] = *(const f32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + half * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) {
+            const int u = tid + k * 256;
+            const int row = u / CQ, q = u % CQ;                   // row = tap * CK + c
+            pw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < W_UNITS) pw[k] = *(const f32x4*)(a.w + ((size_t)((row / CK) * cin + cb + row % CK) * a.cout) + q * 4);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < X_PT; ++k) {
+            const int u = tid + k * 256;
+            if (u < X_UNITS) {
+                const int p = u >> 1, half = u & 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_x[(half * 4 + j) * NPAD + p] = px[k][j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) {
+            const int u = tid + k * 256;
+            if (u < W_UNITS) *(f32x4*)(s_w + (u / CQ) * wstr + (u % CQ) * 4) = pw[k];
+        }
+    };
+    f32x4 acc[MT][2];
+    if (n_items > 0) issue(0);
+    for (int item = 0; item < n_items; ++item) {
+        const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
         const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
-        const int gy0 = oy0 * S - PAD, gx0 = ox0 * S - PAD;
-        f32x4 acc[MT][2];
+        __syncthreads();                       // every wave finished reading the previous item's LDS image
+        commit();
+        __syncthreads();
+        if (item + 1 < n_items) issue(item + 1);
+        if (chunk == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-            const int cb = chunk * CK;
-            const bool first = cb < a.c0;
-            const float* src = first ? a.src0 : a.src1;
-            const int csrc = first ? a.c0 : a.c1, ch0 = first ? cb : cb - a.c0;
-            __syncthreads();                       // previous chunk / tile fully consumed
-            for (int u = tid; u < NPIX * 2; u += 256) {
-                const int px = u >> 1, half = u & 1;
-                const int gy = gy0 + px / IW, gx = gx0 + px % IW;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const f32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + half * 4);
+            for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s_x[(half * 4 + j) * NPAD + px] = v[j];
-            }
-            for (int u = tid; u < w_units; u += 256) {
-                const int row = u / cq, q = u % cq;               // row = tap * CK + c
-                const int tap = row / CK, c = row % CK;
-                *(f32x4*)(s_w + row * wstr + q * 4) = *(const f32x4*)(a.w + ((size_t)(tap * cin + cb + c) * a.cout) + q * 4);
-            }
-            __syncthreads();
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / KS, dx = tap % KS;
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int dy = tap / KS, dx = tap % KS;
+            for (int kk = 0; kk < CK / 4; ++kk) {
+                const float* xp = s_x + (kk * 4 + g) * NPAD + ((2 * wave) * S + dy) * IW + n * S + dx;
+                const float b0 = xp[0], b1 = xp[S * IW];
+                const float* wp = s_w + (tap * CK + kk * 4 + g) * wstr + n;
 #pragma unroll
-                for (int kk = 0; kk < CK / 4; ++kk) {
-                    const float* xp = s_x + (kk * 4 + g) * NPAD + ((2 * wave) * S + dy) * IW + n * S + dx;
-                    const float b0 = xp[0], b1 = xp[S * IW];
-                    const float* wp = s_w + (tap * CK + kk * 4 + g) * wstr + n;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float af = wp[m * 16];
-                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[m][0], 0, 0, 0);
-                        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[m][1], 0, 0, 0);
-                    }
+                for (int m = 0; m < MT; ++m) {
+                    const float af = wp[m * 16];
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[m][1], 0, 0, 0);
                 }
             }
         }
+        if (chunk != nchunk - 1) continue;
         // epilogue: lane (n, g) holds couts m*16 + 4g .. +3 of pixel (row 2*wave + t, column n)
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
