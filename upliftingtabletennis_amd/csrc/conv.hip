@@ -901,6 +901,9 @@ struct BBArgs {
     const bf16_t* st[3]; int ssh[3]; int nsum; bf16_t* ysum;
     float* heat; const float* hw; float hbias; float* pv; long long* pi;
 };
+// the tile's slices of the fuse-layer terms staged in LDS by the chain kernel (element offset of term k, pixels per row); a
+// separate by-value struct: writing into the kernel-argument struct would move all of it to scratch memory
+struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; };
 
 struct BBBest { float v; long long i; };
 __device__ __forceinline__ bool bb_better(float v, long long i, float bv, long long bi) {
@@ -938,7 +941,8 @@ template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int 
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
-                                        const BBArgs* ex = nullptr, BBBest* best = nullptr, const BBFrag16* pre = nullptr) {
+                                        const BBArgs* ex = nullptr, BBBest* best = nullptr, const BBFrag16* pre = nullptr,
+                                        const BBTermLds* tl = nullptr) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
@@ -1002,32 +1006,6 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         if (RES_MFMA && g >= 2) {
             const bf16_t* rr = s_res + ((y + ROFF) * RWR + ROFF) * C + (((g & 1) ^ (((n + ROFF) >> 2) & 1)) << 3);
             rq0 = rr + n * C; rql = rr + (XLAST + nl) * C;
-        }
-        // fused fuse-layer sum: the (few) upsampled terms of this row's pixels are requested BEFORE the MFMA loop, so that
-        // their L2 / HBM latency hides behind the matrix work instead of stalling the epilogue
-        u32x2 tpre[XT][3];
-        if constexpr (CAN_SUM) {
-            if (ex && ex->nsum > 0) {
-                // the row part of every address is the same for the whole wave: it goes through the scalar unit
-                const int gyp = __builtin_amdgcn_readfirstlane(gy0 + y);
-                const bf16_t* trow[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int sh = k < ex->nsum ? ex->ssh[k] : 0;
-                    const int gyc = gyp < 0 ? 0 : gyp;
-                    trow[k] = (k < ex->nsum ? ex->st[k] : ex->st[0]) + ((size_t)(b * (H >> sh) + (gyc >> sh)) * (W >> sh)) * 16 + g * 4;
-                }
-#pragma unroll
-                for (int xt = 0; xt < XT; ++xt) {
-                    const int gxp = gx0 + xt * 16 + n;
-                    const bool livep = gyp >= 0 && gyp < H && gxp >= 0 && gxp < W && !(xt == XT - 1 && xt * 16 + n >= RWO);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        tpre[xt][k] = u32x2{0u, 0u};
-                        if (k < ex->nsum && livep) tpre[xt][k] = *(const u32x2*)(trow[k] + ((gxp >> ex->ssh[k]) << 4));
-                    }
-                }
-            }
         }
         f32x4 acc[XT][MT];
 #pragma unroll
@@ -1097,7 +1075,9 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             if (k >= ex->nsum) continue;
-                            const u32x2 tv = tpre[xt][k];
+                            // the tile's slice of term k sits in LDS (staged during the previous conv): no memory round trip here
+                            const int sh = ex->ssh[k];
+                            const u32x2 tv = *(const u32x2*)(tl->s_terms + tl->toff[k] + ((((gy0 + y) >> sh) - (gy0 >> sh)) * tl->tw[k] + ((gx >> sh) - (gx0 >> sh))) * 16 + g * 4);
                             ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
                             ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
                         }
@@ -1294,14 +1274,44 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     if (C == 16) bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
     TTUP_STAMP(4);
+    // The fuse-layer terms that the last conv's epilogue adds (1x1-conv'd lower branches at 1/2, 1/4, 1/8 resolution): the tile's
+    // slices (12x16 + 6x8 + 3x4 pixels of 16 channels = 8 KB at most) are requested now, travel while conv3 runs, and are parked in
+    // the tail of bufB that conv3's 26x34 output leaves free -- the epilogue then reads them from LDS instead of paying a memory
+    // round trip per output row.
+    constexpr int T_FREE = ((TH + 6) * (TW + 6) - (TH + 2) * (TW + 2)) * C;       // elements of bufB behind conv3's output
+    static_assert(C != 16 || (TH % 8 == 0 && TW % 8 == 0), "term slices are aligned to the tile for 8-aligned tiles");
+    bf16_t* s_terms = bufB + (TH + 2) * (TW + 2) * C;
+    u32x4 treg = u32x4{0u, 0u, 0u, 0u};
+    int tunit = -1;
+    BBTermLds tlds;
+    tlds.s_terms = s_terms;
+    if (C == 16) {
+        int base = 0;                 // in 16-byte units (two per pixel)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tlds.toff[k] = 0; tlds.tw[k] = 1;
+            if (k < a.nsum) {
+                const int sh = a.ssh[k], hk = TH >> sh, wk = TW >> sh;
+                tlds.toff[k] = base * 8; tlds.tw[k] = wk;
+                const int u = tid - base;
+                if (u >= 0 && u < hk * wk * 2) {
+                    const int px = u >> 1, ty = (oy0 >> sh) + px / wk, tx = (ox0 >> sh) + px % wk;
+                    if (ty < (a.H >> sh) && tx < (a.W >> sh)) treg = *(const u32x4*)(a.st[k] + ((size_t)(b * (a.H >> sh) + ty) * (a.W >> sh) + tx) * 16 + (u & 1) * 8);
+                    tunit = tid;
+                }
+                base += hk * wk * 2;
+            }
+        }
+    }
     bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr, pre);
+    if (C == 16 && tunit >= 0) { static_assert(C != 16 || T_FREE * 2 >= 504 * 16, "bufB tail holds the term slices"); ((u32x4*)s_terms)[tunit] = treg; }
     if (C == 16) bb_load_frag16(fr, a.w[3], a.bias[3], lane);
     __syncthreads();
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
     bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
-                                                             nullptr, nullptr, nullptr, &a, &best, pre);
+                                                             nullptr, nullptr, nullptr, &a, &best, pre, &tlds);
     if (C == 16 && a.heat) {
         // argmax partial of this tile: lanes -> wave (DPP shuffles) -> workgroup (through the now idle LDS)
 #pragma unroll
@@ -1358,22 +1368,7 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     return TTUP_OK;
 }
 
-// tile of the C=16 two-block chain (TTUP_BB2_TILE=THxTW picks one of the compiled shapes: tuning aid)
-static void bb2_tile(int* th, int* tw) {
-    static int sth = 0, stw = 0;
-    if (!sth) {
-        int a = 24, b = 32;
-        const char* e = getenv("TTUP_BB2_TILE");
-        if (e && sscanf(e, "%dx%d", &a, &b) != 2) { a = 24; b = 32; }
-        const int ok[][2] = {{24, 32}, {24, 26}, {26, 26}, {20, 26}, {16, 26}, {24, 42}, {26, 42}};
-        bool found = false;
-        for (auto& o : ok) found = found || (o[0] == a && o[1] == b);
-        if (!found) { a = 24; b = 32; }
-        stw = b; sth = a;
-    }
-    *th = sth; *tw = stw;
-}
-int bb_chain_tiles_per_img(int h, int w) { int th, tw; bb2_tile(&th, &tw); return cdiv(w, tw) * cdiv(h, th); }
+int bb_chain_tiles_per_img(int h, int w) { return cdiv(w, 32) * cdiv(h, 24); }      // tile grid of the C=16 two-block chain (24x32)
 
 int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
                     const PackedConv* follow, void* y_follow, hipStream_t st, const BBSum* sum) {
@@ -1403,16 +1398,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
     // tile shapes tuned on MI355X: larger tiles amortise the per-tile overhead and waste fewer ragged 16-pixel MFMA groups
-    if (c == 16 && n_convs == 4) {
-        int th, tw; bb2_tile(&th, &tw);
-        if (th == 24 && tw == 26) return launch_bb2_t<16, 24, 26>(a, batch, h, w, st);
-        if (th == 26 && tw == 26) return launch_bb2_t<16, 26, 26>(a, batch, h, w, st);
-        if (th == 20 && tw == 26) return launch_bb2_t<16, 20, 26>(a, batch, h, w, st);
-        if (th == 16 && tw == 26) return launch_bb2_t<16, 16, 26>(a, batch, h, w, st);
-        if (th == 24 && tw == 42) return launch_bb2_t<16, 24, 42>(a, batch, h, w, st);
-        if (th == 26 && tw == 42) return launch_bb2_t<16, 26, 42>(a, batch, h, w, st);
-        return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
-    }
+    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
