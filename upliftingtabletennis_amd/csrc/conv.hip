@@ -903,13 +903,38 @@ struct BBArgs {
 };
 // the tile's slices of the fuse-layer terms staged in LDS by the chain kernel (element offset of term k, pixels per row); a
 // separate by-value struct: writing into the kernel-argument struct would move all of it to scratch memory
-struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; };
+struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; f32x4 hw4; };
 
 struct BBBest { float v; long long i; };
 __device__ __forceinline__ bool bb_better(float v, long long i, float bv, long long bi) {
     const bool vn = v != v, bn = bv != bv;
     if (vn || bn) return vn && (!bn || i < bi);
     return v > bv || (v == bv && i < bi);
+}
+
+// (value, index) as one unsigned key: greater key = greater value (NaN greatest, -0 == +0), then lower index (index < 2^31)
+__device__ __forceinline__ unsigned long long bb_key(float v, int e) {
+    v += 0.0f;                                              // -0 -> +0
+    const unsigned bits = __float_as_uint(v);
+    unsigned k = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+    if (v != v) k = 0xffffffffu;
+    return ((unsigned long long)k << 32) | (unsigned)(~e);
+}
+__device__ __forceinline__ float bb_key_value(unsigned long long key) {
+    const unsigned k = (unsigned)(key >> 32);
+    if (k == 0xffffffffu) return __uint_as_float(0x7fc00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+// lane i <- lane i + n of the same 16-lane row (0 where that lane does not exist): DPP row_shl, no LDS traffic
+__device__ __forceinline__ unsigned long long bb_dpp_shl(unsigned long long x, int n) {
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    switch (n) {
+        case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x108, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xf, 0xf, false); break;
+        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0xf, false); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x102, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x102, 0xf, 0xf, false); break;
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, false); break;
+    }
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
@@ -937,7 +962,11 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // result either overwrites that buffer in place (ORW = RWR, OOFF = ROFF: each pixel is read and written by the same lane)
 // or goes to global memory.  A wave owns whole output rows (y = wave, wave+8, ...); the 16-pixel groups of a row are
 // unrolled so every LDS address is a per-lane base plus an immediate.
-template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF>
+// MODE (last conv of the C=16 chain only): 0 = the fuse-sum / head epilogue reads its configuration from BBArgs at run time;
+// 1..3 = compile-time fuse sum of MODE terms, branch tensor and sum both stored; 7 = stage-4 tail (3 terms, nothing stored but
+// the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
+// a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
+template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
@@ -995,7 +1024,9 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     if (CAN_FOLLOW && yf) { af_f = *(const bf16x8*)(wf + lane * 8); bias_f = *(const f32x4*)(bfp + g * 4); }
     constexpr bool CAN_SUM = GLOBAL_OUT && C == 16;
     f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
-    if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
+    if (CAN_SUM && MODE == 7) hw4 = tl->hw4;
+    else if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
+    const float head_one = (n == 0) ? 1.f : 0.f;          // A operand of the head's cross-lane sum (row 0 of a 16x4 matrix of ones)
     for (int y = wave; y < RHO; y += 8) {
         const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
         const bf16_t* rp0 = row + n * C;
@@ -1054,12 +1085,48 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
             }
             if (GLOBAL_OUT) {
-                if (inside && valid && gout) {
+                if (MODE != 7 && inside && valid && (MODE > 0 || gout)) {
                     bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
                     if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                     else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
-                if constexpr (CAN_SUM) {
+                if constexpr (CAN_SUM && MODE > 0) {
+                    constexpr int NS = MODE == 7 ? 3 : MODE;
+                    constexpr bool HEAD = MODE == 7;
+                    float ys[4];
+                    if (HEAD) {          // neither the branch tensor nor the sum is stored: no rounding in front of the head
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ys[r] = v[r] > 0.f ? v[r] : 0.f;
+                    } else {
+                        ys[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); ys[1] = bf16_to_f32((bf16_t)(pk[0] >> 16));
+                        ys[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); ys[3] = bf16_to_f32((bf16_t)(pk[1] >> 16));
+                    }
+                    const bool live = inside && valid;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int sh = ex->ssh[k];
+                        const u32x2 tv = *(const u32x2*)(tl->s_terms + tl->toff[k] + ((((gy0 + y) >> sh) - (gy0 >> sh)) * tl->tw[k] + ((gx >> sh) - (gx0 >> sh))) * 16 + g * 4);
+                        ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
+                        ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
+                    }
+                    if (!HEAD) {
+                        const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
+                        if (live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
+                    } else {
+                        float part = (ys[0] > 0.f ? ys[0] : 0.f) * hw4[0];
+                        part = fmaf(ys[1] > 0.f ? ys[1] : 0.f, hw4[1], part);
+                        part = fmaf(ys[2] > 0.f ? ys[2] : 0.f, hw4[2], part);
+                        part = fmaf(ys[3] > 0.f ? ys[3] : 0.f, hw4[3], part);
+                        // sum over the pixel's 4 lane groups on the matrix pipe (exact fp32): D[0][n] = sum_g 1 * part(n, g)
+                        const f32x4 hd = __builtin_amdgcn_mfma_f32_16x16x4f32(head_one, part, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        const float hv = hd[0] + ex->hbias;
+                        if (live && g == 0) {
+                            const int e = gy * W + gx;          // rises along the lane's walk: a later equal value never replaces an earlier one
+                            ex->heat[(size_t)b * H * W + e] = hv;
+                            if (hv > best->v || (hv != hv && best->v == best->v)) { best->v = hv; best->i = e; }
+                        }
+                    }
+                } else if constexpr (CAN_SUM) {
                     if (ex && (ex->nsum > 0 || ex->heat)) {
                         // fuse-layer sum on the rounded block output, exactly what the element-wise pass read back from memory
                         float ys[4] = {bf16_to_f32((bf16_t)(pk[0] & 0xffff)), bf16_to_f32((bf16_t)(pk[0] >> 16)),
@@ -1223,7 +1290,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
 
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
 // Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
-template <int C, int TH, int TW>
+template <int C, int TH, int TW, int MODE>
 __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int L = 4;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
@@ -1285,6 +1352,8 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     int tunit = -1;
     BBTermLds tlds;
     tlds.s_terms = s_terms;
+    tlds.hw4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (C == 16 && MODE == 7) tlds.hw4 = *(const f32x4*)(a.hw + (lane >> 4) * 4);      // head weights of the lane's 4 channels: in flight during conv3
     if (C == 16) {
         int base = 0;                 // in 16-byte units (two per pixel)
 #pragma unroll
@@ -1310,10 +1379,36 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     __syncthreads();
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
-    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
-                                                             nullptr, nullptr, nullptr, &a, &best, pre, &tlds);
-    if (C == 16 && a.heat) {
-        // argmax partial of this tile: lanes -> wave (DPP shuffles) -> workgroup (through the now idle LDS)
+    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0, MODE>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
+                                                                   nullptr, nullptr, nullptr, &a, &best, pre, &tlds);
+#ifdef TTUP_TIMING_SPLIT
+    TTUP_STAMP(6);
+#endif
+    if (MODE == 7 && lane < 16 && best.i == 0x7fffffffffffffffLL && oy0 + wave < a.H && ox0 + lane < a.W)
+        best.i = (long long)(oy0 + wave) * a.W + ox0 + lane;      // nothing above -inf seen: the lane's first pixel is its first maximum
+    if (C == 16 && MODE == 7) {
+        // argmax partial of this tile.  (value, index) pairs become one 64-bit key -- order-preserving bits of the value (NaN on
+        // top, -0 = +0 as torch.argmax has it) above the complemented index -- so that "greater value, then lower index" is an
+        // unsigned max: 4 DPP row shifts over the 16 lanes that hold heatmap values, one LDS slot per wave (behind the tile
+        // buffers: no barrier before writing it), one barrier, 3 more shifts in wave 0.
+        unsigned long long key = 0ull;           // below every real key
+        if (lane < 16 && best.i != 0x7fffffffffffffffLL) key = bb_key(best.v, (int)best.i);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) { const unsigned long long o = bb_dpp_shl(key, off); key = o > key ? o : key; }
+        unsigned long long* slots = (unsigned long long*)(smem + (size_t)(SZ_A + (TH + 6) * (TW + 6) * C) * 2);
+        if (lane == 0) slots[wave] = key;
+        __syncthreads();
+        if (wave == 0) {
+            key = lane < 8 ? slots[lane] : 0ull;
+#pragma unroll
+            for (int off = 4; off >= 1; off >>= 1) { const unsigned long long o = bb_dpp_shl(key, off); key = o > key ? o : key; }
+            if (lane == 0) {
+                a.pv[(size_t)b * a.tiles_per_img + tt] = bb_key_value(key);
+                a.pi[(size_t)b * a.tiles_per_img + tt] = (long long)(~(unsigned)key);
+            }
+        }
+    } else if (C == 16 && a.heat) {
+        // run-time form: lanes -> wave (shuffles) -> workgroup (through the now idle LDS)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const float ov = __shfl_down(best.v, off, 64);
@@ -1330,21 +1425,23 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
             a.pi[(size_t)b * a.tiles_per_img + tt] = best.i;
         }
     }
+#ifndef TTUP_TIMING_SPLIT
     TTUP_STAMP(6);
+#endif
 #ifdef TTUP_TIMING
     if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz ticks for the same span
 #endif
 }
 
-template <int C, int TH, int TW>
+template <int C, int TH, int TW, int MODE>
 static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
-    constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2;
+    constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2 + 64;       // + one argmax slot per wave
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW>, SMEM)) return rc;
+    if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW, MODE>, SMEM)) return rc;
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
-    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW>), dim3(k.total_tiles), dim3(512), SMEM, st, k);
+    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW, MODE>), dim3(k.total_tiles), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -1398,7 +1495,17 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         a.w[i] = (const bf16_t*)p.w_dev; a.bias[i] = p.bias_dev;
     }
     // tile shapes tuned on MI355X: larger tiles amortise the per-tile overhead and waste fewer ragged 16-pixel MFMA groups
-    if (c == 16 && n_convs == 4) return launch_bb2_t<16, 24, 32>(a, batch, h, w, st);
+    if (c == 16 && n_convs == 4) {
+        // the epilogue forms the network uses are compiled out (MODE of bb_conv); anything else takes the run-time form
+        static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
+        const bool sum_stored = !generic && a.nsum >= 1 && a.nsum <= 3 && a.y && a.ysum && !a.heat;
+        const bool tail = !generic && a.nsum == 3 && a.heat && !a.y && !a.ysum;
+        if (tail) return launch_bb2_t<16, 24, 32, 7>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 1) return launch_bb2_t<16, 24, 32, 1>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 2) return launch_bb2_t<16, 24, 32, 2>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 3) return launch_bb2_t<16, 24, 32, 3>(a, batch, h, w, st);
+        return launch_bb2_t<16, 24, 32, 0>(a, batch, h, w, st);
+    }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
