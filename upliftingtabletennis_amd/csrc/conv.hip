@@ -1027,17 +1027,32 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     if (CAN_SUM && MODE == 7) hw4 = tl->hw4;
     else if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
     const float head_one = (n == 0) ? 1.f : 0.f;          // A operand of the head's cross-lane sum (row 0 of a 16x4 matrix of ones)
-    for (int y = wave; y < RHO; y += 8) {
-        const bf16_t* row = s_in + ((y + IOFF) * RWI + IOFF) * C;
-        const bf16_t* rp0 = row + n * C;
-        const bf16_t* rpl = row + (XLAST + nl) * C;      // clamped lanes (x >= RWO) may read a wrong chunk of an in-bounds pixel: their results are discarded
+    // fixed trip count, fully unrolled: the row offsets become immediates of the LDS instructions instead of a dozen per-lane
+    // address registers that each need an add per row
+    // per-lane fragment addresses of the wave's FIRST row, one per k-step (full groups / clamped last group); the rows that
+    // follow are compile-time offsets from them
+    const bf16_t* pk0[KSTEPS];
+    const bf16_t* pkl[KSTEPS];
+    {
+        const bf16_t* row0 = s_in + ((wave + IOFF) * RWI + IOFF) * C;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) { pk0[s] = row0 + n * C + koff[s]; pkl[s] = row0 + (XLAST + nl) * C + koff[s]; }
         // last k-step of RES_MFMA: lanes g >= 2 read the block input at the output pixel instead of the (zero-weight) tap
-        const bf16_t* rq0 = rp0 + koff[KSTEPS - 1];
-        const bf16_t* rql = rpl + koff[KSTEPS - 1];
         if (RES_MFMA && g >= 2) {
-            const bf16_t* rr = s_res + ((y + ROFF) * RWR + ROFF) * C + (((g & 1) ^ (((n + ROFF) >> 2) & 1)) << 3);
-            rq0 = rr + n * C; rql = rr + (XLAST + nl) * C;
+            const bf16_t* rr = s_res + ((wave + ROFF) * RWR + ROFF) * C + (((g & 1) ^ (((n + ROFF) >> 2) & 1)) << 3);
+            pk0[KSTEPS - 1] = rr + n * C; pkl[KSTEPS - 1] = rr + (XLAST + nl) * C;
         }
+    }
+    // the residual buffer's row stride may differ from the input's: its row step is applied to lanes g >= 2 only
+    constexpr int ROWSTEP = 8 * RWI * C, RES_ROWSTEP = 8 * RWR * C;
+#ifndef TTUP_NO_ROW_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int yj = 0; yj < (RHO + 7) / 8; ++yj) {
+        const int y = wave + 8 * yj;
+        if (y >= RHO) break;
         f32x4 acc[XT][MT];
 #pragma unroll
         for (int xt = 0; xt < XT; ++xt)
@@ -1048,8 +1063,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
             bf16x8 bfr[XT];
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt) {
-                if (RES_MFMA && s == KSTEPS - 1) bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rq0 + xt * 16 * C) : *(const bf16x8*)rql;
-                else bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(rp0 + koff[s] + xt * 16 * C) : *(const bf16x8*)(rpl + koff[s]);
+                if (RES_MFMA && s == KSTEPS - 1 && RES_ROWSTEP != ROWSTEP) {
+                    const int step = yj * (g >= 2 ? RES_ROWSTEP : ROWSTEP);
+                    bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + step + xt * 16 * C) : *(const bf16x8*)(pkl[s] + step);
+                } else bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + yj * ROWSTEP + xt * 16 * C) : *(const bf16x8*)(pkl[s] + yj * ROWSTEP);
             }
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt)
@@ -1207,7 +1224,7 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     bf16_t* bufA = (bf16_t*)smem;              // block input region (later overwritten in place by the block output)
     bf16_t* bufB = bufA + SZ_A;                // intermediate of the current block
     bf16_t* s_wt = bufB + SZ_B;                // weights: L slots (resident) or one rotating slot
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row tests and row addresses on the scalar unit
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
     u32x4 pin[IN_PT], pwt[W_PT];
@@ -1298,7 +1315,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* bufA = (bf16_t*)smem;
     bf16_t* bufB = bufA + SZ_A;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row tests and row addresses on the scalar unit
     const int tl = blockIdx.x;
     const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
     const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
