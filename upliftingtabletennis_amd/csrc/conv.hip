@@ -905,6 +905,8 @@ struct BBArgs {
 // separate by-value struct: writing into the kernel-argument struct would move all of it to scratch memory
 struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; f32x4 hw4; };
 
+// ReLU on the sign bit (one integer max, like relu_pk on bf16 pairs): negative values and -0 become +0, +NaN stays NaN
+__device__ __forceinline__ float relu_f32(float v) { const int b = __float_as_int(v); return __int_as_float(b > 0 ? b : 0); }
 struct BBBest { float v; long long i; };
 __device__ __forceinline__ bool bb_better(float v, long long i, float bv, long long bi) {
     const bool vn = v != v, bn = bv != bv;
@@ -1045,6 +1047,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     }
     // the residual buffer's row stride may differ from the input's: its row step is applied to lanes g >= 2 only
     constexpr int ROWSTEP = 8 * RWI * C, RES_ROWSTEP = 8 * RWR * C;
+    bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((wave + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
 #ifndef TTUP_NO_ROW_UNROLL
 #pragma unroll
 #else
@@ -1085,7 +1088,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r];
             if (SECOND && !RES_MFMA) {       // + block input; the lane's 4*MT channels start at g*4*MT
-                const bf16_t* rp = s_res + ((y + ROFF) * RWR + x + ROFF) * C + res_ch;
+                const bf16_t* rp = s_res + ((wave + ROFF) * RWR + n + ROFF) * C + res_ch + (yj * 8 * RWR + xt * 16) * C;
                 const u32x4 rv = *(const u32x4*)rp;
                 const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -1113,7 +1116,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                     float ys[4];
                     if (HEAD) {          // neither the branch tensor nor the sum is stored: no rounding in front of the head
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ys[r] = v[r] > 0.f ? v[r] : 0.f;
+                        for (int r = 0; r < 4; ++r) ys[r] = relu_f32(v[r]);
                     } else {
                         ys[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); ys[1] = bf16_to_f32((bf16_t)(pk[0] >> 16));
                         ys[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); ys[3] = bf16_to_f32((bf16_t)(pk[1] >> 16));
@@ -1130,10 +1133,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                         const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
                         if (live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
                     } else {
-                        float part = (ys[0] > 0.f ? ys[0] : 0.f) * hw4[0];
-                        part = fmaf(ys[1] > 0.f ? ys[1] : 0.f, hw4[1], part);
-                        part = fmaf(ys[2] > 0.f ? ys[2] : 0.f, hw4[2], part);
-                        part = fmaf(ys[3] > 0.f ? ys[3] : 0.f, hw4[3], part);
+                        float part = relu_f32(ys[0]) * hw4[0];
+                        part = fmaf(relu_f32(ys[1]), hw4[1], part);
+                        part = fmaf(relu_f32(ys[2]), hw4[2], part);
+                        part = fmaf(relu_f32(ys[3]), hw4[3], part);
                         // sum over the pixel's 4 lane groups on the matrix pipe (exact fp32): D[0][n] = sum_g 1 * part(n, g)
                         const f32x4 hd = __builtin_amdgcn_mfma_f32_16x16x4f32(head_one, part, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                         const float hv = hd[0] + ex->hbias;
@@ -1198,7 +1201,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                     }
                 }
             } else if (valid) {
-                bf16_t* o = s_out + ((y + OOFF) * ORW + x + OOFF) * C + out_ch;
+                bf16_t* o = so0 + (yj * 8 * ORW + xt * 16) * C;
                 if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                 else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
@@ -1325,23 +1328,33 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     TTUP_STAMP(0);
     BBFrag16 fr;
     {
-        // all of the thread's loads are issued before the first LDS store: ONE memory round trip for the tile, not one per unit
-        constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 511) / 512;
+        // all of the thread's loads are issued before the first LDS store: ONE memory round trip for the tile, not one per unit.
+        // A thread keeps one 16-byte column unit and walks rows (row lane rl, then every RL-th row): the global and the LDS
+        // address of every further row are the first row's plus a constant -- no per-unit division, one bounds test per row.
+        constexpr int CU = R0W * (C / 8);                 // 16-byte units per tile row
+        constexpr int RL = 512 / CU;                      // row lanes
+        constexpr int IN_PT = (R0H + RL - 1) / RL;
+        static_assert(RL >= 1, "tile row wider than the workgroup");
+        const int cu = tid % CU, rl = tid / CU;
+        const int col = cu / (C / 8), c8 = cu % (C / 8);
+        const int gx = ox0 - L + col, gyb = oy0 - L + rl;
+        const bool col_ok = rl < RL && gx >= 0 && gx < a.W;
+        const bf16_t* src = a.x + ((long long)(b * a.H + gyb) * a.W + gx) * C + c8 * 8;      // may point outside for halo rows / columns: only dereferenced when valid
+        const long long row_step = (long long)RL * a.W * C;
         u32x4 v[IN_PT];
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 512;
-            const int c8 = u % (C / 8), pix = u / (C / 8);
-            const int gy = oy0 - L + pix / R0W, gx = ox0 - L + pix % R0W;
-            v[k] = u32x4{0u, 0u, 0u, 0u};
-            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v[k] = *(const u32x4*)(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8);
+            const int gy = gyb + k * RL;
+            // branch-free: an invalid unit reads the tensor's first bytes and is zeroed afterwards (a branch around the load
+            // would make every load wait for the one before it)
+            const bool ok = col_ok && rl + k * RL < R0H && gy >= 0 && gy < a.H;
+            const u32x4 t = *(const u32x4*)(ok ? src + k * row_step : a.x);
+            v[k] = u32x4{ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u};
         }
+        bf16_t* dst = bufA + bb_off<C>(rl * R0W + col, col, c8);
 #pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 512;
-            const int c8 = u % (C / 8), pix = u / (C / 8);
-            if (u < IN_UNITS) *(u32x4*)(bufA + bb_off<C>(pix, pix % R0W, c8)) = v[k];
-        }
+        for (int k = 0; k < IN_PT; ++k)
+            if (rl < RL && rl + k * RL < R0H) *(u32x4*)(dst + k * RL * R0W * C) = v[k];
     }
     if (C == 16) bb_load_frag16(fr, a.w[0], a.bias[0], lane);          // first conv's fragments: in flight across the barrier
     __syncthreads();
