@@ -1047,6 +1047,15 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     }
     // the residual buffer's row stride may differ from the input's: its row step is applied to lanes g >= 2 only
     constexpr int ROWSTEP = 8 * RWI * C, RES_ROWSTEP = 8 * RWR * C;
+    int tx[3] = {0, 0, 0};
+    if constexpr (CAN_SUM && MODE > 0) {
+#pragma unroll
+        for (int k = 0; k < (MODE == 7 ? 3 : MODE); ++k) {
+            // element offset of term k's slice (shift k + 1) in the staged block: the slices follow each other
+            const int toff = (k == 0 ? 0 : k == 1 ? (RHO >> 1) * (RWO >> 1) : (RHO >> 1) * (RWO >> 1) + (RHO >> 2) * (RWO >> 2)) * 16;
+            tx[k] = toff + (n >> (k + 1)) * 16 + g * 4;
+        }
+    }
     bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((wave + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
 #ifndef TTUP_NO_ROW_UNROLL
 #pragma unroll
@@ -1124,8 +1133,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                     const bool live = inside && valid;
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        const int sh = ex->ssh[k];
-                        const u32x2 tv = *(const u32x2*)(tl->s_terms + tl->toff[k] + ((((gy0 + y) >> sh) - (gy0 >> sh)) * tl->tw[k] + ((gx >> sh) - (gx0 >> sh))) * 16 + g * 4);
+                        // the tile origin is a multiple of 8 >= 2^sh: the term pixel of (y, x) is (y >> sh, x >> sh) of the slice --
+                        // a per-lane column part (tx, set up once) plus a wave-uniform row / group part
+                        const int sh = k + 1;
+                        const u32x2 tv = *(const u32x2*)(tl->s_terms + tx[k] + ((y >> sh) * (RWO >> sh) + ((xt * 16) >> sh)) * 16);
                         ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
                         ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
                     }
@@ -1384,7 +1395,23 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     tlds.s_terms = s_terms;
     tlds.hw4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (C == 16 && MODE == 7) tlds.hw4 = *(const f32x4*)(a.hw + (lane >> 4) * 4);      // head weights of the lane's 4 channels: in flight during conv3
-    if (C == 16) {
+    if (C == 16 && MODE > 0) {
+        // compiled-out form: term k has shift k + 1 (checked by the launcher), so a thread's term, slice pixel and LDS unit follow
+        // from its index with shifts alone; one branch-free load per thread (a unit outside the image reads the term's first bytes:
+        // it is only ever added to outputs that are not stored)
+        constexpr int NS = MODE == 7 ? 3 : MODE;
+        constexpr int B1 = (TH >> 1) * (TW >> 1) * 2, B2 = B1 + (TH >> 2) * (TW >> 2) * 2, B3 = B2 + (TH >> 3) * (TW >> 3) * 2;
+        constexpr int BN = NS == 1 ? B1 : NS == 2 ? B2 : B3;
+        const int k = tid < B1 ? 0 : tid < B2 ? 1 : 2, sh = k + 1;
+        const int u = tid - (k == 0 ? 0 : k == 1 ? B1 : B2);
+        const int px = u >> 1, lw = __builtin_ctz(TW) - sh;
+        const int ty = (oy0 >> sh) + (px >> lw), tx = (ox0 >> sh) + (px & ((TW >> sh) - 1));
+        const int hs = a.H >> sh, ws = a.W >> sh;
+        const bf16_t* tp = k == 0 ? a.st[0] : k == 1 ? a.st[1] : a.st[2];
+        const bool ok = tid < BN && ty < hs && tx < ws;
+        treg = *(const u32x4*)(ok ? tp + ((long long)(b * hs + ty) * ws + tx) * 16 + (u & 1) * 8 : a.st[0]);
+        tunit = tid < BN ? tid : -1;
+    } else if (C == 16) {
         int base = 0;                 // in 16-byte units (two per pixel)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1394,7 +1421,9 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
                 tlds.toff[k] = base * 8; tlds.tw[k] = wk;
                 const int u = tid - base;
                 if (u >= 0 && u < hk * wk * 2) {
-                    const int px = u >> 1, ty = (oy0 >> sh) + px / wk, tx = (ox0 >> sh) + px % wk;
+                    static_assert(C != 16 || (TW & (TW - 1)) == 0, "slice width is a power of two: row / column of a slice pixel are a shift and a mask");
+                    const int lw = __builtin_ctz(TW) - sh;            // log2(wk)
+                    const int px = u >> 1, ty = (oy0 >> sh) + (px >> lw), tx = (ox0 >> sh) + (px & (wk - 1));
                     if (ty < (a.H >> sh) && tx < (a.W >> sh)) treg = *(const u32x4*)(a.st[k] + ((size_t)(b * (a.H >> sh) + ty) * (a.W >> sh) + tx) * 16 + (u & 1) * 8);
                     tunit = tid;
                 }
@@ -1528,8 +1557,10 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
     if (c == 16 && n_convs == 4) {
         // the epilogue forms the network uses are compiled out (MODE of bb_conv); anything else takes the run-time form
         static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
-        const bool sum_stored = !generic && a.nsum >= 1 && a.nsum <= 3 && a.y && a.ysum && !a.heat;
-        const bool tail = !generic && a.nsum == 3 && a.heat && !a.y && !a.ysum;
+        bool shifts_ok = true;          // the compiled-out forms assume term k at 1/2^(k+1) resolution (HRNet's fuse layers)
+        for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
+        const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.y && a.ysum && !a.heat;
+        const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
         if (tail) return launch_bb2_t<16, 24, 32, 7>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 1) return launch_bb2_t<16, 24, 32, 1>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 2) return launch_bb2_t<16, 24, 32, 2>(a, batch, h, w, st);
