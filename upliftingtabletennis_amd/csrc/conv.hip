@@ -25,7 +25,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 //   TTUP_STAMP_IT(id,it,k) persistent kernels: kernel id (0 stem, 1 bneck, 2 32-channel block), tile iteration it < 64 of workgroups < 32
 __device__ unsigned long long ttup_tbuf[8192 * 8];
 __device__ unsigned long long ttup_tbuf_it[3 * 32 * 64 * 8];
-#define TTUP_STAMP(k) do { if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TTUP_BID ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#define TTUP_STAMP(k) do { if (tid == 0 && TTUP_BID < 8192) ttup_tbuf[TTUP_BID * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TTUP_STAMP_IT(id, it, k) do { if (tid == 0 && blockIdx.x < 32 && (it) < 64) ttup_tbuf_it[(((id) * 32 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TTUP_STAMP(k) do { } while (0)
@@ -952,7 +953,16 @@ template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
 // Weight fragments + bias of one 16-channel conv, loaded by the CALLER: the chain kernel requests the next conv's fragments from
 // L2 before the barrier that ends the current conv, so their latency (the first MFMA of a conv needs all of them) hides behind
 // the barrier wait instead of following it.
-struct BBFrag16 { bf16x8 af[5]; f32x4 bias; };
+struct BBFrag16 { bf16x8 af[5]; f32x4 bias; bf16x8 idm; };
+// A fragment of the 16x16 identity for lanes g >= 2 (row n, columns (g & 1) * 8 .. + 7): the residual add of a block's second
+// conv rides in the unused half of its last k-step.  Built once per kernel (it costs ~35 vector instructions).
+__device__ __forceinline__ bf16x8 bb_identity_frag(int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    unsigned short idm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) idm[j] = (n == (g & 1) * 8 + j) ? 0x3F80 : 0;
+    return __builtin_bit_cast(bf16x8, idm);
+}
 __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag, const float* biasp, int lane) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) f.af[s] = *(const bf16x8*)(wfrag + (s * 64 + lane) * 8);
@@ -991,12 +1001,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     // C=16, second conv of a block: the unused tenth tap of the last k-step (lanes g >= 2, zero weights) carries the block
     // input through an identity matrix, so the residual add happens inside the MFMA (exact: bf16 * 1.0 into the fp32 sum)
     constexpr bool RES_MFMA = SECOND && C == 16;
-    if (RES_MFMA && g >= 2) {
-        unsigned short idm[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) idm[j] = (n == (g & 1) * 8 + j) ? 0x3F80 : 0;
-        af[KSTEPS - 1][0] = __builtin_bit_cast(bf16x8, idm);
-    }
+    if (RES_MFMA && g >= 2) af[KSTEPS - 1][0] = pre ? pre->idm : bb_identity_frag(lane);
     f32x4 bias[MT];
     if (C == 16 && pre) bias[0] = pre->bias;
     else {
@@ -1330,9 +1335,9 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     bf16_t* bufA = (bf16_t*)smem;
     bf16_t* bufB = bufA + SZ_A;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row tests and row addresses on the scalar unit
-    const int tl = blockIdx.x;
-    const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-    const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+    // 3-D grid (tile column, tile row, image): no division to find the tile
+    const int b = blockIdx.z, tt = blockIdx.y * a.tiles_x + blockIdx.x;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
 #ifdef TTUP_TIMING
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1367,6 +1372,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
         for (int k = 0; k < IN_PT; ++k)
             if (rl < RL && rl + k * RL < R0H) *(u32x4*)(dst + k * RL * R0W * C) = v[k];
     }
+    fr.idm = bb_identity_frag(lane);
     if (C == 16) bb_load_frag16(fr, a.w[0], a.bias[0], lane);          // first conv's fragments: in flight across the barrier
     __syncthreads();
     TTUP_STAMP(1);
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     TTUP_STAMP(6);
 #endif
 #ifdef TTUP_TIMING
-    if (tid == 0 && blockIdx.x < 8192) ttup_tbuf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz ticks for the same span
+    if (tid == 0 && TTUP_BID < 8192) ttup_tbuf[TTUP_BID * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz ticks for the same span
 #endif
 }
 
@@ -1500,7 +1506,7 @@ static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
-    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW, MODE>), dim3(k.total_tiles), dim3(512), SMEM, st, k);
+    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW, MODE>), dim3(k.tiles_x, cdiv(h, TH), batch), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
