@@ -1946,25 +1946,24 @@ __device__ __forceinline__ void axis_tap_y(int d, double scale, int src_n, int& 
 
 template <typename T>
 __global__ void preprocess_kernel(PreArgs a) {
-    // one thread per (sample, y, x): produces the 3*nf channels of that pixel
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.total) return;
+    // one thread per (sample, y, x): produces the 3*nf channels of that pixel.  Whole frames run on a 3-D grid (column block,
+    // row, sample) -- no index division, which used to be most of this kernel's instructions; crop windows keep a linear index
     int x, y, t;
     size_t opix;                        // output pixel index (sample-major)
     if (a.crops) {
-        const int cx = (int)(i % a.crop_w);
-        long long p = i / a.crop_w;
-        const int cy = (int)(p % a.crop_h);
-        const int j = (int)(p / a.crop_h);
+        const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (unsigned)a.total) return;
+        const int cx = (int)(i % (unsigned)a.crop_w);
+        const unsigned p = i / (unsigned)a.crop_w;
+        const int cy = (int)(p % (unsigned)a.crop_h);
+        const int j = (int)(p / (unsigned)a.crop_h);
         if (j >= *a.n_active) return;
         const int* rec = a.crops + 4 * (a.crop0 + j);
         t = rec[0]; y = rec[1] + cy; x = rec[2] + cx;
         opix = ((size_t)j * a.crop_h + cy) * a.crop_w + cx;
     } else {
-        x = (int)(i % a.dst_w);
-        long long p = i / a.dst_w;
-        y = (int)(p % a.dst_h);
-        t = (int)(p / a.dst_h);
+        x = blockIdx.x * blockDim.x + threadIdx.x; y = blockIdx.y; t = blockIdx.z;
+        if (x >= a.dst_w) return;
         opix = ((size_t)t * a.dst_h + y) * a.dst_w + x;
     }
     const bool same = a.src_h == a.dst_h && a.src_w == a.dst_w;
@@ -2040,12 +2039,13 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     a.crops = nullptr; a.n_active = nullptr; a.crop0 = 0; a.crop_h = 0; a.crop_w = 0;
     if (a.total == 0) return TTUP_OK;
     if (int rc = device_normalise_lut(&a.lut)) return rc;       // one table per device
-    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    TTUP_REQUIRE(dst_h <= 65535 && n_triples <= 65535, TTUP_EINVAL, "preprocess: grid limit (rows, samples <= 65535)");
+    const dim3 grid((unsigned)cdiv(dst_w, 256), (unsigned)dst_h, (unsigned)n_triples);
     TTUP_REQUIRE(out_layout != TTUP_LAYOUT_NHWC4_FRAME || (frames_per_sample == 1 && dtype == TTUP_DTYPE_BF16), TTUP_EINVAL, "per-frame records are bf16, one frame per sample");
     if ((dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32) && out_layout != TTUP_LAYOUT_NHWC4_FRAME)
-        hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(preprocess_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -2062,6 +2062,7 @@ int launch_preprocess_crops(const uint8_t* frames, int n_frames, int src_h, int 
     a.crops = crops_dev; a.n_active = n_active_dev; a.crop0 = crop0; a.crop_h = crop_h; a.crop_w = crop_w;
     if (a.total == 0) return TTUP_OK;
     if (int rc = device_normalise_lut(&a.lut)) return rc;
+    TTUP_REQUIRE(a.total < (1ll << 32), TTUP_EINVAL, "preprocess crops: more than 2^32 crop pixels");
     hipLaunchKernelGGL(preprocess_kernel<float>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
