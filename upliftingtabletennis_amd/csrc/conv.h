@@ -35,6 +35,9 @@ struct ConvLaunch {
     const void* res2 = nullptr;           // bf16 stride-2 convs: further fuse-layer terms added before the ReLU (same resolution /
     const void* res3 = nullptr; int sh3 = 0;   // 1/2^sh3 resolution, nearest-neighbour upsampled), wasb.py:236-243
     const int* n_active = nullptr;        // f32 only: device-side batch (<= batch) decided by an earlier kernel (csrc/certify.hip)
+    // bf16 64 -> 64 3x3 only: linear 1x1 followers (fuse-layer convs 64 -> 16 / 64 -> 32, no ReLU) applied to dst
+    const PackedConv* lin16 = nullptr; void* lin16_dst = nullptr;
+    const PackedConv* lin32 = nullptr; void* lin32_dst = nullptr;
 };
 
 // host-side packing (called from ttup_wasb_create)

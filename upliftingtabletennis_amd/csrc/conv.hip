@@ -50,6 +50,10 @@ struct ConvKArgs {
     // further fuse-layer terms added in the epilogue (wasb.py:236-243): res2 at the output resolution (the branch's own
     // tensor), res3 at 1/2^sh3 of it (a 1x1-conv'd lower branch, nearest-neighbour upsampled), both COUT channels
     const bf16_t* res2; const bf16_t* res3; int sh3;
+    // conv64_kernel: linear 1x1 followers on the tile just produced (the fuse-layer convs 64 -> 16 / 64 -> 32 that feed the
+    // higher-resolution branches, wasb.py:189-205: conv + BN, no ReLU)
+    const bf16_t* wl16; const float* bl16; bf16_t* dl16;
+    const bf16_t* wl32; const float* bl32; bf16_t* dl32;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -324,6 +328,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 // (73.7 KB) stay in LDS for the life of the persistent workgroup, the whole 64-channel halo tile (10x34 px, 43.5 KB) is
 // staged at once (register-prefetched one tile ahead), so a tile is 18 k-steps between two barriers and no weight byte
 // moves inside the loop -- the generic kernel re-stages 36.8 KB of weights per (tile, chunk) item.
+// L16 / L32: the 64 -> 16 / 64 -> 32 fuse-layer 1x1 convs ride in the epilogue (2 MFMAs per m-tile and pixel group on the bf16
+// pairs just packed, follower K order permuted to the accumulator layout as in the stem): the branch tensor is not read again.
+template <bool L16, bool L32>
 __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     constexpr int IH = 10, IW = 34, NPIX = IH * IW;
     constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units
@@ -338,6 +345,23 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     f32x4 bias[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) bias[m] = *(const f32x4*)(a.bias + g * 16 + m * 4);
+    // follower fragments: a lane owns channels g*16 .. g*16+15 of its pixel, k-step k takes channels 16g + 8k + j from lane group
+    // g; in the standard packing those sit at k-step g>>1, lane group 2(g&1)+k
+    bf16x8 al16[2], al32[2][2];
+    f32x4 bl16 = {0.f, 0.f, 0.f, 0.f}, bl32[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (L16) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) al16[k] = *(const bf16x8*)(a.wl16 + ((g >> 1) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
+        bl16 = *(const f32x4*)(a.bl16 + g * 4);
+    }
+    if (L32) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) al32[k][m] = *(const bf16x8*)(a.wl32 + (((g >> 1) * 2 + m) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) bl32[m] = *(const f32x4*)(a.bl32 + g * 8 + m * 4);
+    }
     const bf16_t* bB[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) bB[dx] = s_in + lds_off<32, IW>(0, n + dx, g);
@@ -396,8 +420,10 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
-            if (oy >= a.H || ox >= a.W) continue;
-            const size_t o = ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16;
+            const bool ok = oy < a.H && ox < a.W;
+            if (!(L16 || L32) && !ok) continue;           // with followers every lane stays for the MFMAs; only the stores are masked
+            const size_t opix = ok ? (size_t)(b * a.H + oy) * a.W + ox : 0;
+            const size_t o = opix * 64 + g * 16;
             float v[16];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -412,15 +438,40 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
                     for (int k = 0; k < 4; ++k) { v[q * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
                 }
             }
+            u32x4 pk[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                u32x4 pk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[i] = a.relu ? relu_pk(w) : w; }
-                *(u32x4*)(a.dst + o + q * 8) = pk;
+                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[q][i] = a.relu ? relu_pk(w) : w; }
+                if (ok) *(u32x4*)(a.dst + o + q * 8) = pk[q];
+            }
+            if (L16) {
+                f32x4 c = bl16;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al16[k], __builtin_bit_cast(bf16x8, pk[k]), c, 0, 0, 0);
+                if (ok) *(u32x2*)(a.dl16 + opix * 16 + g * 4) = u32x2{pack2(c[0], c[1]), pack2(c[2], c[3])};
+            }
+            if (L32) {
+                f32x4 c[2] = {bl32[0], bl32[1]};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al32[k][m], __builtin_bit_cast(bf16x8, pk[k]), c[m], 0, 0, 0);
+                if (ok) *(u32x4*)(a.dl32 + opix * 32 + g * 8) = u32x4{pack2(c[0][0], c[0][1]), pack2(c[0][2], c[0][3]), pack2(c[1][0], c[1][1]), pack2(c[1][2], c[1][3])};
             }
         }
     }
+}
+
+template <bool L16, bool L32>
+static int launch_conv64_t(const ConvKArgs& a, hipStream_t st) {
+    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
+    if (int rc = ensure_max_lds((const void*)conv64_kernel<L16, L32>, SMEM)) return rc;
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL((conv64_kernel<L16, L32>), dim3(grid), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
 }
 
 static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
@@ -429,13 +480,18 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     a.src0 = (const bf16_t*)l.src0; a.wpack = (const bf16_t*)p.w_dev; a.bias = p.bias_dev; a.residual = (const bf16_t*)l.residual; a.dst = (bf16_t*)l.dst;
     a.H = l.h; a.W = l.w; a.OH = l.h; a.OW = l.w; a.relu = l.relu;
     a.tiles_x = cdiv(l.w, 32); a.tiles_per_img = a.tiles_x * cdiv(l.h, 8); a.total_tiles = a.tiles_per_img * l.batch;
-    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
-    if (int rc = ensure_max_lds((const void*)conv64_kernel, SMEM)) return rc;
-    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
-    if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL(conv64_kernel, dim3(grid), dim3(512), SMEM, st, a);
-    TTUP_LAUNCH_CHECK();
-    return TTUP_OK;
+    if (l.lin16) {
+        TTUP_REQUIRE(l.lin16->cout == 16 && l.lin16->cin_total == 64 && l.lin16->k == 1 && l.lin16->ck == 32 && l.lin16_dst, TTUP_EINVAL, "conv64: bad 64->16 follower");
+        a.wl16 = (const bf16_t*)l.lin16->w_dev; a.bl16 = l.lin16->bias_dev; a.dl16 = (bf16_t*)l.lin16_dst;
+    }
+    if (l.lin32) {
+        TTUP_REQUIRE(l.lin32->cout == 32 && l.lin32->cin_total == 64 && l.lin32->k == 1 && l.lin32->ck == 32 && l.lin32_dst, TTUP_EINVAL, "conv64: bad 64->32 follower");
+        a.wl32 = (const bf16_t*)l.lin32->w_dev; a.bl32 = l.lin32->bias_dev; a.dl32 = (bf16_t*)l.lin32_dst;
+    }
+    if (l.lin16 && l.lin32) return launch_conv64_t<true, true>(a, st);
+    if (l.lin16) return launch_conv64_t<true, false>(a, st);
+    if (l.lin32) return launch_conv64_t<false, true>(a, st);
+    return launch_conv64_t<false, false>(a, st);
 }
 
 // ------------------------------------------------------------------ fused stem: conv1 + conv2 (+ Bottleneck conv1)
@@ -1757,6 +1813,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);
     }
     if (p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64 && p.cin_total == 64 && p.c0 == 64 && !l.src1) return launch_conv64(p, l, st);
+    TTUP_REQUIRE(!l.lin16 && !l.lin32, TTUP_EINVAL, "conv: linear 1x1 followers ride on the 64 -> 64 3x3 kernel only");
     if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
     if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);
     if (p.k == 1 && p.stride == 1 && p.ck == 32) return dispatch_cout<32, 1, 1, 8, 32>(p, l, st);

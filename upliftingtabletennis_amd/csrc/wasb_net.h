@@ -29,6 +29,8 @@ struct Op {
     // (launched by run_head_op, which knows the output buffers); dst = -1 when the pre-fuse branch tensor has no consumer
     int head = 0;
     int conv1f = -1;                            // STEM: conv1 packed for the frames mode (channel slot f*4 + c)
+    // CONV (64 -> 64 3x3, bf16): fuse-layer 1x1 convs on its output riding in its epilogue (packed conv index, output tensor)
+    int lin16 = -1, lin16_dst = -1, lin32 = -1, lin32_dst = -1;
 };
 
 // Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle

@@ -208,6 +208,19 @@ struct Builder {
                             break;
                         }
                     }
+                    // 64 -> 16 / 64 -> 32 on the output of the branch's last 64 -> 64 conv: rides in that conv's epilogue
+                    if (!attached && fuse && sj.c == 64 && (STAGE_CH[i] == 16 || STAGE_CH[i] == 32) && !getenv("TTUP_NO_FUSE_LIN")) {
+                        for (int k = (int)net->ops.size() - 1; k >= 0 && !attached; --k) {
+                            Op& po = net->ops[k];
+                            if (po.dst != xs[j]) continue;
+                            const PackedConv& pp = net->convs[po.conv >= 0 ? po.conv : 0];
+                            if (po.kind == Op::CONV && po.conv >= 0 && po.conv2 < 0 && pp.k == 3 && pp.stride == 1 && pp.cout == 64 && pp.cin_total == 64 && pp.c0 == 64 && po.src1 < 0) {
+                                if (STAGE_CH[i] == 16 && po.lin16 < 0) { po.lin16 = pc; po.lin16_dst = dst; attached = true; }
+                                else if (STAGE_CH[i] == 32 && po.lin32 < 0) { po.lin32 = pc; po.lin32_dst = dst; attached = true; }
+                            }
+                            break;
+                        }
+                    }
                     Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = xs[j]; op.dst = dst; op.relu = 0;
                     if (!attached) net->ops.push_back(op);
                     up_t.push_back(dst); up_s.push_back(j - i);
@@ -383,6 +396,8 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu; l.n_active = net->n_active;
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
+            if (op.lin16 >= 0) { l.lin16 = &net->convs[op.lin16]; l.lin16_dst = net->tensors[op.lin16_dst].ptr; }
+            if (op.lin32 >= 0) { l.lin32 = &net->convs[op.lin32]; l.lin32_dst = net->tensors[op.lin32_dst].ptr; }
             if (op.res2 >= 0) l.res2 = net->tensors[op.res2].ptr;
             if (op.res3 >= 0) { l.res3 = net->tensors[op.res3].ptr; l.sh3 = op.sh3; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
@@ -673,7 +688,7 @@ void op_info(const ttup_wasb* net, int i, int* o, char* name) {
         const PackedConv& pc = net->convs[op.conv];
         o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
         if (!bf) snprintf(nm, sizeof nm, "conv_direct_f32_kernel");
-        else if (pc.k == 3 && pc.stride == 1 && pc.cout == 64 && pc.cin_total == 64 && op.conv2 < 0) snprintf(nm, sizeof nm, "conv64_kernel");
+        else if (pc.k == 3 && pc.stride == 1 && pc.cout == 64 && pc.cin_total == 64 && op.conv2 < 0) snprintf(nm, sizeof nm, "conv64_kernel%s", (op.lin16 >= 0 || op.lin32 >= 0) ? "+1x1" : "");
         else snprintf(nm, sizeof nm, "conv_mfma_kernel<%d,%d,%d,%d>", pc.ck, pc.cout, pc.k, pc.stride);
     } else {
         o[0] = op.kind == Op::UPSUM_HEAD ? 5 : 1; o[1] = op.n_terms; o[2] = d.c; o[3] = 0; o[4] = 0; o[5] = d.h; o[6] = d.w; o[7] = d.c;
