@@ -93,9 +93,10 @@ def _traffic(kernel_base):
     """HBM bytes per launch of a kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     runs; MI355X_MICROARCH.md, HBM).  None when the profile does not hold the kernel."""
     try:
-        for e in json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE))):
-            if kernel_base in e['kernel']:
-                return e['hbm_bytes']
+        # a kernel's epilogue variants are separate template instances in the profile: launch-weighted mean over all of them
+        hits = [e for e in json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE))) if kernel_base in e['kernel']]
+        if hits:
+            return int(sum(e['hbm_bytes'] * e['launches'] for e in hits) / sum(e['launches'] for e in hits))
     except Exception:
         pass
     return None
