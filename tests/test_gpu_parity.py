@@ -298,6 +298,50 @@ def test_fused_kernels_match_layerwise():
     assert (h1 - h2).abs().max().item() <= 2e-2 * scale, ((h1 - h2).abs().max().item(), scale)
 
 
+def test_conv64_fuse_followers_are_bit_identical():
+    """The 64->16 / 64->32 fuse-layer convs riding in the last 64->64 conv's epilogue consume the bf16 values that conv stores
+    (same K products, the accumulator-order K permutation only reorders an fp32 sum of 64 terms): heatmaps within one bf16 step
+    of the stand-alone 1x1 kernels' and the same argmax; ragged size so that masked stores of the followers are exercised."""
+    h, w, b = 104, 168, 3
+    sd = weights.random_wasb_state_dict(29)
+    x = torch.from_numpy(np.random.default_rng(29).standard_normal((b, 9, h, w)).astype(np.float32))
+    fused = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    os.environ['TTUP_NO_FUSE_LIN'] = '1'
+    try:
+        alone = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    finally:
+        del os.environ['TTUP_NO_FUSE_LIN']
+    n_f = len(wasb.time_ops(fused, reps=1)); n_a = len(wasb.time_ops(alone, reps=1))
+    assert n_a - n_f == 3, (n_f, n_a)                       # stage 3: 64->16 and 64->32, stage 4: 64->16
+    h1, i1, _ = fused.forward(x, want_peaks=True)
+    h2, i2, _ = alone.forward(x, want_peaks=True)
+    scale = (h2.max() - h2.min()).item()
+    assert (h1 - h2).abs().max().item() <= 4e-3 * scale, ((h1 - h2).abs().max().item(), scale)
+    assert torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize('bias', [float('-inf'), float('nan'), float('inf'), -0.0])
+def test_fused_head_argmax_special_values(bias):
+    """The stage-4 tail keeps its per-tile argmax partial as a 64-bit key (order-preserving value bits, NaN on top, -0 == +0,
+    complemented index).  A head bias of -inf / NaN / +inf makes every heatmap value equal: the index must be the FIRST pixel, as
+    torch.argmax has it -- -inf is the case where no value ever beats the running maximum's start value.  Two tile rows and
+    columns, ragged edges."""
+    h, w, b = 40, 72, 2
+    sd = weights.random_wasb_state_dict(31)
+    if bias == 0.0:                                      # all-zero head: every value is +0 or -0 (bias -0: 0*w + -0)
+        sd['model.final_layers.0.weight'] = np.zeros_like(sd['model.final_layers.0.weight'])
+    sd['model.final_layers.0.bias'] = np.full_like(sd['model.final_layers.0.bias'], bias)
+    x = torch.from_numpy(np.random.default_rng(31).standard_normal((b, 9, h, w)).astype(np.float32))
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    heat, idx, _ = net.forward(x, want_peaks=True)
+    flat = heat.reshape(b, -1)
+    if bias != bias:
+        assert torch.isnan(flat).all()
+    else:
+        assert (flat == bias).all()
+    assert (idx.cpu() == 0).all(), idx
+
+
 @pytest.mark.parametrize('hw', [(72, 104), (40, 56), (8, 8), (136, 24)])
 def test_wasb_ragged_sizes_against_oracle(hw):
     """Sizes that are multiples of 8 but not of the 8x32 / 16x32 tiles: every kernel's edge masking and zero padding."""
