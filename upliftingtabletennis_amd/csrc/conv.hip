@@ -1031,8 +1031,8 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // or goes to global memory.  A wave owns whole output rows (y = wave, wave+8, ...); the 16-pixel groups of a row are
 // unrolled so every LDS address is a per-lane base plus an immediate.
 // MODE (last conv of the C=16 chain only): 0 = the fuse-sum / head epilogue reads its configuration from BBArgs at run time;
-// 1..3 = compile-time fuse sum of MODE terms, branch tensor and sum both stored; 7 = stage-4 tail (3 terms, nothing stored but
-// the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
+// 1..3 = compile-time fuse sum of MODE terms (sum stored, branch tensor stored when it has consumers); 4 = plain chain;
+// 7 = stage-4 tail (3 terms, nothing stored but the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
 // a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
 template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     // the residual buffer's row stride may differ from the input's: its row step is applied to lanes g >= 2 only
     constexpr int ROWSTEP = 8 * RWI * C, RES_ROWSTEP = 8 * RWR * C;
     int tx[3] = {0, 0, 0};
-    if constexpr (CAN_SUM && MODE > 0) {
+    if constexpr (CAN_SUM && MODE > 0 && MODE != 4) {
 #pragma unroll
         for (int k = 0; k < (MODE == 7 ? 3 : MODE); ++k) {
             // element offset of term k's slice (shift k + 1) in the staged block: the slices follow each other
@@ -1118,11 +1118,9 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         }
     }
     bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((wave + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
-#ifndef TTUP_NO_ROW_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
+    // (the run-time epilogue form, MODE 0 with the fuse sum, is a cross-check path and stays rolled: unrolled it spills)
+    constexpr int ROW_UNROLL = (GLOBAL_OUT && C == 16 && MODE == 0) ? 1 : (RHO + 7) / 8;
+#pragma unroll ROW_UNROLL
     for (int yj = 0; yj < (RHO + 7) / 8; ++yj) {
         const int y = wave + 8 * yj;
         if (y >= RHO) break;
@@ -1175,12 +1173,14 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
             }
             if (GLOBAL_OUT) {
-                if (MODE != 7 && inside && valid && (MODE > 0 || gout)) {
+                if (MODE != 7 && inside && valid && gout) {
                     bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
                     if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                     else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
-                if constexpr (CAN_SUM && MODE > 0) {
+                if constexpr (CAN_SUM && MODE == 4) {
+                    // plain chain: nothing rides in the epilogue
+                } else if constexpr (CAN_SUM && MODE > 0) {
                     constexpr int NS = MODE == 7 ? 3 : MODE;
                     constexpr bool HEAD = MODE == 7;
                     float ys[4];
@@ -1457,7 +1457,9 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     tlds.s_terms = s_terms;
     tlds.hw4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (C == 16 && MODE == 7) tlds.hw4 = *(const f32x4*)(a.hw + (lane >> 4) * 4);      // head weights of the lane's 4 channels: in flight during conv3
-    if (C == 16 && MODE > 0) {
+    if (C == 16 && MODE == 4) {
+        // plain chain: no fuse-layer terms
+    } else if (C == 16 && MODE > 0) {
         // compiled-out form: term k has shift k + 1 (checked by the launcher), so a thread's term, slice pixel and LDS unit follow
         // from its index with shifts alone; one branch-free load per thread (a unit outside the image reads the term's first bytes:
         // it is only ever added to outputs that are not stored)
@@ -1621,8 +1623,9 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
         bool shifts_ok = true;          // the compiled-out forms assume term k at 1/2^(k+1) resolution (HRNet's fuse layers)
         for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
-        const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.y && a.ysum && !a.heat;
+        const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.ysum && !a.heat;      // a.y (the pre-fuse tensor) optional
         const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
+        if (!generic && a.nsum == 0 && !a.heat && !a.ysum && a.y) return launch_bb2_t<16, 24, 32, 4>(a, batch, h, w, st);
         if (tail) return launch_bb2_t<16, 24, 32, 7>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 1) return launch_bb2_t<16, 24, 32, 1>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 2) return launch_bb2_t<16, 24, 32, 2>(a, batch, h, w, st);
