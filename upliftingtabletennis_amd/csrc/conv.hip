@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
                 a.pi[(size_t)b * a.tiles_per_img + tt] = (long long)(~(unsigned)key);
             }
         }
-    } else if (C == 16 && a.heat) {
+    } else if (C == 16 && MODE == 0 && a.heat) {
         // run-time form: lanes -> wave (shuffles) -> workgroup (through the now idle LDS)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
