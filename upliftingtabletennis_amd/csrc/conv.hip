@@ -813,35 +813,39 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         TTUP_STAMP_IT(1, it, 0);
         __syncthreads();            // previous tile's reduction has read its partial sums (weights visible on the first pass)
         TTUP_STAMP_IT(1, it, 1);
-        // ---------------- phase 1: layer1 halo tile
+        // ---------------- phase 1: layer1 halo tile.  Output-channel pairs outermost: a weight fragment read from LDS serves all
+        // (up to three) pixel groups of the wave -- 24 fragment reads per wave and tile instead of 72 (the kernel is LDS-bound);
+        // every accumulator still sums its three K chunks in the same order
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int j = wave + 8 * t, pix = j * 16 + n;
-            if (j >= NT1) continue;
-            f32x4 acc[8];
+        for (int q = 0; q < 4; ++q) {
+            f32x4 acc[3][2];
+            const f32x4 bq0 = *(const f32x4*)(s_b1 + g * 32 + q * 8), bq1 = *(const f32x4*)(s_b1 + g * 32 + q * 8 + 4);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m] = *(const f32x4*)(s_b1 + g * 32 + m * 4);
+            for (int t = 0; t < 3; ++t) { acc[t][0] = bq0; acc[t][1] = bq1; }
 #pragma unroll
             for (int chunk = 0; chunk < 3; ++chunk) {
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
+                const bf16x8 af0 = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q) * 64 + lane) * 8);
+                const bf16x8 af1 = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q + 1) * 64 + lane) * 8);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const bf16x8 af = *(const bf16x8*)(s_w1 + ((chunk * 8 + m) * 64 + lane) * 8);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
+                for (int t = 0; t < 3; ++t) {
+                    if (wave + 8 * t >= NT1) continue;             // wave-uniform: waves 6 and 7 own two groups
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, pb[t][chunk]);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr, acc[t][1], 0, 0, 0);
                 }
             }
-            if (pix < NPIX) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int j = wave + 8 * t, pix = j * 16 + n;
+                if (j >= NT1 || pix >= NPIX) continue;
                 const bool inside = p_in[t];
+                u32x4 pk;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u32x4 pk;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
-                        pk[i] = inside ? w : 0u;
-                    }
-                    *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = pk;
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w = relu_pk(pack2(acc[t][i >> 1][2 * (i & 1)], acc[t][i >> 1][2 * (i & 1) + 1]));
+                    pk[i] = inside ? w : 0u;
                 }
+                *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = pk;
             }
         }
         TTUP_STAMP_IT(1, it, 2);
