@@ -1013,7 +1013,7 @@ template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
 // Weight fragments + bias of one 16-channel conv, loaded by the CALLER: the chain kernel requests the next conv's fragments from
 // L2 before the barrier that ends the current conv, so their latency (the first MFMA of a conv needs all of them) hides behind
 // the barrier wait instead of following it.
-struct BBFrag16 { bf16x8 af[5]; f32x4 bias; bf16x8 idm; };
+struct BBFrag16 { bf16x8 af[5]; f32x4 bias; };
 // A fragment of the 16x16 identity for lanes g >= 2 (row n, columns (g & 1) * 8 .. + 7): the residual add of a block's second
 // conv rides in the unused half of its last k-step.  Built once per kernel (it costs ~35 vector instructions).
 __device__ __forceinline__ bf16x8 bb_identity_frag(int lane) {
@@ -1023,9 +1023,22 @@ __device__ __forceinline__ bf16x8 bb_identity_frag(int lane) {
     for (int j = 0; j < 8; ++j) idm[j] = (n == (g & 1) * 8 + j) ? 0x3F80 : 0;
     return __builtin_bit_cast(bf16x8, idm);
 }
+// K order of the 16-channel chain convs (two taps per k-step, first tap on lane groups 0-1, second on 2-3):
+//   (0,0)|(0,1)   (1,0)|(1,1)   (2,0)|(2,1)   (0,2)|(1,2)   (2,2)|pad
+// so that the pixel fragment of the first three steps depends on the input row only (row y+dy, columns x | x+1): a wave walking
+// consecutive output rows reads it once for three rows, and the fourth step's fragment (column x+2 of rows r | r+1) doubles as
+// the fifth step of the row two above.  The weights stay in the standard packing (taps 2s | 2s+1 per step): tap t of lane group
+// half c8 is at step t/2, lane group 2(t&1) + c8 -- a gather at load time, no second packing.
+__device__ __forceinline__ int bb_tap16(int s, int h) {          // tap of k-step s, half h (9 = the zero pad)
+    return s < 3 ? 3 * s + h : (s == 3 ? (h ? 5 : 2) : (h ? 9 : 8));
+}
+__device__ __forceinline__ bf16x8 bb_weight_frag16(const bf16_t* wfrag, int s, int lane) {
+    const int i = lane & 15, g = lane >> 4, tap = bb_tap16(s, g >> 1);
+    return *(const bf16x8*)(wfrag + ((tap >> 1) * 64 + i + 16 * (2 * (tap & 1) + (g & 1))) * 8);
+}
 __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag, const float* biasp, int lane) {
 #pragma unroll
-    for (int s = 0; s < 5; ++s) f.af[s] = *(const bf16x8*)(wfrag + (s * 64 + lane) * 8);
+    for (int s = 0; s < 5; ++s) f.af[s] = bb_weight_frag16(wfrag, s, lane);
     f.bias = *(const f32x4*)(biasp + (lane >> 4) * 4);
 }
 
@@ -1038,12 +1051,13 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // 1..3 = compile-time fuse sum of MODE terms (sum stored, branch tensor stored when it has consumers); 4 = plain chain;
 // 7 = stage-4 tail (3 terms, nothing stored but the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
 // a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
+template <int R> struct BBRow { static constexpr int value = R; };
 template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
                                         const BBArgs* ex = nullptr, BBBest* best = nullptr, const BBFrag16* pre = nullptr,
-                                        const BBTermLds* tl = nullptr) {
+                                        const BBTermLds* tl = nullptr, bf16x8 idm_pre = bf16x8{}) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
@@ -1056,12 +1070,12 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[s][m] = *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
+            for (int m = 0; m < MT; ++m) af[s][m] = (C == 16) ? bb_weight_frag16(wfrag, s < 5 ? s : 4, lane) : *(const bf16x8*)(wfrag + ((s * MT + m) * 64 + lane) * 8);
     }
     // C=16, second conv of a block: the unused tenth tap of the last k-step (lanes g >= 2, zero weights) carries the block
     // input through an identity matrix, so the residual add happens inside the MFMA (exact: bf16 * 1.0 into the fp32 sum)
     constexpr bool RES_MFMA = SECOND && C == 16;
-    if (RES_MFMA && g >= 2) af[KSTEPS - 1][0] = pre ? pre->idm : bb_identity_frag(lane);
+    if (RES_MFMA && g >= 2) af[KSTEPS - 1][0] = pre ? idm_pre : bb_identity_frag(lane);      // (by value: a field of *pre would pin the struct in memory)
     f32x4 bias[MT];
     if (C == 16 && pre) bias[0] = pre->bias;
     else {
@@ -1094,6 +1108,11 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     if (CAN_SUM && MODE == 7) hw4 = tl->hw4;
     else if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
     const float head_one = (n == 0) ? 1.f : 0.f;          // A operand of the head's cross-lane sum (row 0 of a 16x4 matrix of ones)
+    // C=16: a wave owns a BAND of consecutive output rows (pixel fragments shared between them, see bb_tap16); C=32: rows
+    // wave, wave+8, ... (two output tiles per fragment read already)
+    constexpr bool BAND = (C == 16);
+    constexpr int RB = (RHO + 7) / 8;
+    const int yb = BAND ? wave * RB : wave;      // the wave's first row
     // fixed trip count, fully unrolled: the row offsets become immediates of the LDS instructions instead of a dozen per-lane
     // address registers that each need an add per row
     // per-lane fragment addresses of the wave's FIRST row, one per k-step (full groups / clamped last group); the rows that
@@ -1121,165 +1140,225 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
             tx[k] = toff + (n >> (k + 1)) * 16 + g * 4;
         }
     }
-    bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((wave + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
-    // (the run-time epilogue form, MODE 0 with the fuse sum, is a cross-check path and stays rolled: unrolled it spills)
-    constexpr int ROW_UNROLL = (GLOBAL_OUT && C == 16 && MODE == 0) ? 1 : (RHO + 7) / 8;
-#pragma unroll ROW_UNROLL
-    for (int yj = 0; yj < (RHO + 7) / 8; ++yj) {
-        const int y = wave + 8 * yj;
-        if (y >= RHO) break;
-        f32x4 acc[XT][MT];
-#pragma unroll
-        for (int xt = 0; xt < XT; ++xt)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[xt][m] = bias[m];
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            bf16x8 bfr[XT];
-#pragma unroll
-            for (int xt = 0; xt < XT; ++xt) {
-                if (RES_MFMA && s == KSTEPS - 1 && RES_ROWSTEP != ROWSTEP) {
-                    const int step = yj * (g >= 2 ? RES_ROWSTEP : ROWSTEP);
-                    bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + step + xt * 16 * C) : *(const bf16x8*)(pkl[s] + step);
-                } else bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + yj * ROWSTEP + xt * 16 * C) : *(const bf16x8*)(pkl[s] + yj * ROWSTEP);
-            }
-#pragma unroll
-            for (int xt = 0; xt < XT; ++xt)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[xt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][m], bfr[xt], acc[xt][m], 0, 0, 0);
-        }
+    bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((yb + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
+    // epilogue of one 16-pixel group of row y (orow = its row offset from the wave's first row): bias/ReLU/rounding, zero padding
+    // of the next conv, stores, and whatever rides in the last conv's epilogue
+    auto epi = [&](int xt, int orow, int y, const f32x4 (&accx)[MT]) __attribute__((always_inline)) {
         const int gy = gy0 + y;
         const bool row_in = gy >= 0 && gy < H;
+        const int x = xt * 16 + n;
+        const bool valid = !(xt == XT - 1 && x >= RWO);       // ragged last group: computed (the follower MFMA needs the whole wave), not stored
+        float v[4 * MT];
 #pragma unroll
-        for (int xt = 0; xt < XT; ++xt) {
-            const int x = xt * 16 + n;
-            const bool valid = !(xt == XT - 1 && x >= RWO);       // ragged last group: computed (the follower MFMA needs the whole wave), not stored
-            float v[4 * MT];
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int r = 0; r < 4; ++r) v[m * 4 + r] = accx[m][r];
+        if (SECOND && !RES_MFMA) {       // + block input; the lane's 4*MT channels start at g*4*MT
+            const bf16_t* rp = s_res + ((yb + ROFF) * RWR + n + ROFF) * C + res_ch + (orow * RWR + xt * 16) * C;
+            const u32x4 rv = *(const u32x4*)rp;
+            const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[xt][m][r];
-            if (SECOND && !RES_MFMA) {       // + block input; the lane's 4*MT channels start at g*4*MT
-                const bf16_t* rp = s_res + ((wave + ROFF) * RWR + n + ROFF) * C + res_ch + (yj * 8 * RWR + xt * 16) * C;
-                const u32x4 rv = *(const u32x4*)rp;
-                const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+        }
+        unsigned pk[2 * MT];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+        for (int i = 0; i < 2 * MT; ++i) pk[i] = relu_pk(pack2(v[2 * i], v[2 * i + 1]));
+        const int gx = gx0 + x;
+        bool inside = true;
+        if (!interior) {
+            inside = row_in && gx >= 0 && gx < W;
+#pragma unroll
+            for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
+        }
+        if (GLOBAL_OUT) {
+            if (MODE != 7 && inside && valid && gout) {
+                bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
+                if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
+                else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
-            unsigned pk[2 * MT];
+            if constexpr (CAN_SUM && MODE == 4) {
+                // plain chain: nothing rides in the epilogue
+            } else if constexpr (CAN_SUM && MODE > 0) {
+                constexpr int NS = MODE == 7 ? 3 : MODE;
+                constexpr bool HEAD = MODE == 7;
+                float ys[4];
+                if (HEAD) {          // neither the branch tensor nor the sum is stored: no rounding in front of the head
 #pragma unroll
-            for (int i = 0; i < 2 * MT; ++i) pk[i] = relu_pk(pack2(v[2 * i], v[2 * i + 1]));
-            const int gx = gx0 + x;
-            bool inside = true;
-            if (!interior) {
-                inside = row_in && gx >= 0 && gx < W;
-#pragma unroll
-                for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
-            }
-            if (GLOBAL_OUT) {
-                if (MODE != 7 && inside && valid && gout) {
-                    bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
-                    if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
-                    else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    for (int r = 0; r < 4; ++r) ys[r] = relu_f32(v[r]);
+                } else {
+                    ys[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); ys[1] = bf16_to_f32((bf16_t)(pk[0] >> 16));
+                    ys[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); ys[3] = bf16_to_f32((bf16_t)(pk[1] >> 16));
                 }
-                if constexpr (CAN_SUM && MODE == 4) {
-                    // plain chain: nothing rides in the epilogue
-                } else if constexpr (CAN_SUM && MODE > 0) {
-                    constexpr int NS = MODE == 7 ? 3 : MODE;
-                    constexpr bool HEAD = MODE == 7;
-                    float ys[4];
-                    if (HEAD) {          // neither the branch tensor nor the sum is stored: no rounding in front of the head
+                const bool live = inside && valid;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ys[r] = relu_f32(v[r]);
-                    } else {
-                        ys[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); ys[1] = bf16_to_f32((bf16_t)(pk[0] >> 16));
-                        ys[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); ys[3] = bf16_to_f32((bf16_t)(pk[1] >> 16));
+                for (int k = 0; k < NS; ++k) {
+                    // the tile origin is a multiple of 8 >= 2^sh: the term pixel of (y, x) is (y >> sh, x >> sh) of the slice --
+                    // a per-lane column part (tx, set up once) plus a wave-uniform row / group part
+                    const int sh = k + 1;
+                    const u32x2 tv = *(const u32x2*)(tl->s_terms + tx[k] + ((y >> sh) * (RWO >> sh) + ((xt * 16) >> sh)) * 16);
+                    ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
+                    ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
+                }
+                if (!HEAD) {
+                    const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
+                    if (live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
+                } else {
+                    float part = relu_f32(ys[0]) * hw4[0];
+                    part = fmaf(relu_f32(ys[1]), hw4[1], part);
+                    part = fmaf(relu_f32(ys[2]), hw4[2], part);
+                    part = fmaf(relu_f32(ys[3]), hw4[3], part);
+                    // sum over the pixel's 4 lane groups on the matrix pipe (exact fp32): D[0][n] = sum_g 1 * part(n, g)
+                    const f32x4 hd = __builtin_amdgcn_mfma_f32_16x16x4f32(head_one, part, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const float hv = hd[0] + ex->hbias;
+                    if (live && g == 0) {
+                        const long long e = (long long)gy * W + gx;      // the band walk is column-group major: ties need the index test
+                        ex->heat[(size_t)b * H * W + e] = hv;
+                        if (hv > best->v || (hv == best->v && e < best->i) || (hv != hv && (best->v == best->v || e < best->i))) { best->v = hv; best->i = e; }
+                    }
+                }
+            } else if constexpr (CAN_SUM) {
+                if (ex && (ex->nsum > 0 || ex->heat)) {
+                    // fuse-layer sum on the rounded block output, exactly what the element-wise pass read back from memory
+                    float ys[4] = {bf16_to_f32((bf16_t)(pk[0] & 0xffff)), bf16_to_f32((bf16_t)(pk[0] >> 16)),
+                                   bf16_to_f32((bf16_t)(pk[1] & 0xffff)), bf16_to_f32((bf16_t)(pk[1] >> 16))};
+                    // stage-4 tail: neither the branch tensor nor the sum is stored, so neither is rounded to bf16 -- the head
+                    // sees the fp32 values (two roundings fewer right in front of the heatmap: a smaller bf16-path error)
+                    const bool exact_tail = ex->heat && !gout && !ex->ysum;
+                    if (exact_tail) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ys[r] = v[r] > 0.f ? v[r] : 0.f;
                     }
                     const bool live = inside && valid;
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        // the tile origin is a multiple of 8 >= 2^sh: the term pixel of (y, x) is (y >> sh, x >> sh) of the slice --
-                        // a per-lane column part (tx, set up once) plus a wave-uniform row / group part
-                        const int sh = k + 1;
-                        const u32x2 tv = *(const u32x2*)(tl->s_terms + tx[k] + ((y >> sh) * (RWO >> sh) + ((xt * 16) >> sh)) * 16);
+                    for (int k = 0; k < 3; ++k) {
+                        if (k >= ex->nsum) continue;
+                        // the tile's slice of term k sits in LDS (staged during the previous conv): no memory round trip here
+                        const int sh = ex->ssh[k];
+                        const u32x2 tv = *(const u32x2*)(tl->s_terms + tl->toff[k] + ((((gy0 + y) >> sh) - (gy0 >> sh)) * tl->tw[k] + ((gx >> sh) - (gx0 >> sh))) * 16 + g * 4);
                         ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
                         ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
                     }
-                    if (!HEAD) {
-                        const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
-                        if (live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
-                    } else {
-                        float part = relu_f32(ys[0]) * hw4[0];
-                        part = fmaf(relu_f32(ys[1]), hw4[1], part);
-                        part = fmaf(relu_f32(ys[2]), hw4[2], part);
-                        part = fmaf(relu_f32(ys[3]), hw4[3], part);
-                        // sum over the pixel's 4 lane groups on the matrix pipe (exact fp32): D[0][n] = sum_g 1 * part(n, g)
-                        const f32x4 hd = __builtin_amdgcn_mfma_f32_16x16x4f32(head_one, part, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        const float hv = hd[0] + ex->hbias;
-                        if (live && g == 0) {
-                            const int e = gy * W + gx;          // rises along the lane's walk: a later equal value never replaces an earlier one
-                            ex->heat[(size_t)b * H * W + e] = hv;
-                            if (hv > best->v || (hv != hv && best->v == best->v)) { best->v = hv; best->i = e; }
-                        }
-                    }
-                } else if constexpr (CAN_SUM) {
-                    if (ex && (ex->nsum > 0 || ex->heat)) {
-                        // fuse-layer sum on the rounded block output, exactly what the element-wise pass read back from memory
-                        float ys[4] = {bf16_to_f32((bf16_t)(pk[0] & 0xffff)), bf16_to_f32((bf16_t)(pk[0] >> 16)),
-                                       bf16_to_f32((bf16_t)(pk[1] & 0xffff)), bf16_to_f32((bf16_t)(pk[1] >> 16))};
-                        // stage-4 tail: neither the branch tensor nor the sum is stored, so neither is rounded to bf16 -- the head
-                        // sees the fp32 values (two roundings fewer right in front of the heatmap: a smaller bf16-path error)
-                        const bool exact_tail = ex->heat && !gout && !ex->ysum;
+                    const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
+                    if (ex->ysum && live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
+                    if (ex->heat) {
+                        // head on the bf16-rounded sum: this lane's 4 channels, then across the 4 lane groups of the pixel
+                        float hy[4] = {bf16_to_f32((bf16_t)(q0 & 0xffff)), bf16_to_f32((bf16_t)(q0 >> 16)),
+                                       bf16_to_f32((bf16_t)(q1 & 0xffff)), bf16_to_f32((bf16_t)(q1 >> 16))};
                         if (exact_tail) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) ys[r] = v[r] > 0.f ? v[r] : 0.f;
+                            for (int r = 0; r < 4; ++r) hy[r] = ys[r] > 0.f ? ys[r] : 0.f;
                         }
-                        const bool live = inside && valid;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            if (k >= ex->nsum) continue;
-                            // the tile's slice of term k sits in LDS (staged during the previous conv): no memory round trip here
-                            const int sh = ex->ssh[k];
-                            const u32x2 tv = *(const u32x2*)(tl->s_terms + tl->toff[k] + ((((gy0 + y) >> sh) - (gy0 >> sh)) * tl->tw[k] + ((gx >> sh) - (gx0 >> sh))) * 16 + g * 4);
-                            ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
-                            ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
-                        }
-                        const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
-                        if (ex->ysum && live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
-                        if (ex->heat) {
-                            // head on the bf16-rounded sum: this lane's 4 channels, then across the 4 lane groups of the pixel
-                            float hy[4] = {bf16_to_f32((bf16_t)(q0 & 0xffff)), bf16_to_f32((bf16_t)(q0 >> 16)),
-                                           bf16_to_f32((bf16_t)(q1 & 0xffff)), bf16_to_f32((bf16_t)(q1 >> 16))};
-                            if (exact_tail) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) hy[r] = ys[r] > 0.f ? ys[r] : 0.f;
-                            }
-                            float part = hy[0] * hw4[0];
-                            part = fmaf(hy[1], hw4[1], part);
-                            part = fmaf(hy[2], hw4[2], part);
-                            part = fmaf(hy[3], hw4[3], part);
-                            part += __shfl_xor(part, 16, 64);
-                            part += __shfl_xor(part, 32, 64);
-                            const float hv = part + ex->hbias;
-                            if (live && g == 0) {
-                                const long long e = (long long)gy * W + gx;
-                                ex->heat[(size_t)b * H * W + e] = hv;
-                                if (bb_better(hv, e, best->v, best->i)) { best->v = hv; best->i = e; }
-                            }
+                        float part = hy[0] * hw4[0];
+                        part = fmaf(hy[1], hw4[1], part);
+                        part = fmaf(hy[2], hw4[2], part);
+                        part = fmaf(hy[3], hw4[3], part);
+                        part += __shfl_xor(part, 16, 64);
+                        part += __shfl_xor(part, 32, 64);
+                        const float hv = part + ex->hbias;
+                        if (live && g == 0) {
+                            const long long e = (long long)gy * W + gx;
+                            ex->heat[(size_t)b * H * W + e] = hv;
+                            if (bb_better(hv, e, best->v, best->i)) { best->v = hv; best->i = e; }
                         }
                     }
                 }
-                if constexpr (CAN_FOLLOW) {
-                    if (yf) {          // lane (n, g) holds channels 8g..8g+7 of its pixel = k-group g of the follower's only k-step
-                        const u32x4 bq = u32x4{pk[0], pk[1], pk[2], pk[3]};
-                        const f32x4 cf = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_f, __builtin_bit_cast(bf16x8, bq), bias_f, 0, 0, 0);
-                        if (inside && valid) *(u32x2*)(yf + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{pack2(cf[0], cf[1]), pack2(cf[2], cf[3])};
-                    }
+            }
+            if constexpr (CAN_FOLLOW) {
+                if (yf) {          // lane (n, g) holds channels 8g..8g+7 of its pixel = k-group g of the follower's only k-step
+                    const u32x4 bq = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    const f32x4 cf = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_f, __builtin_bit_cast(bf16x8, bq), bias_f, 0, 0, 0);
+                    if (inside && valid) *(u32x2*)(yf + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{pack2(cf[0], cf[1]), pack2(cf[2], cf[3])};
                 }
-            } else if (valid) {
-                bf16_t* o = so0 + (yj * 8 * ORW + xt * 16) * C;
-                if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
-                else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            }
+        } else if (valid) {
+            bf16_t* o = so0 + (orow * ORW + xt * 16) * C;
+            if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
+            else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        }
+    };
+    if constexpr (!BAND) {
+        // (the run-time epilogue form, MODE 0 with the fuse sum, is a cross-check path and stays rolled: unrolled it spills)
+        constexpr int ROW_UNROLL = (RHO + 7) / 8;
+#pragma unroll ROW_UNROLL
+        for (int yj = 0; yj < (RHO + 7) / 8; ++yj) {
+            const int y = wave + 8 * yj;
+            if (y >= RHO) break;
+            f32x4 acc[XT][MT];
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[xt][m] = bias[m];
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                bf16x8 bfr[XT];
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt)
+                    bfr[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + yj * ROWSTEP + xt * 16 * C) : *(const bf16x8*)(pkl[s] + yj * ROWSTEP);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[xt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][m], bfr[xt], acc[xt][m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) epi(xt, 8 * yj, y, acc[xt]);
+        }
+    } else {
+        const int h = g >> 1, c8 = g & 1;
+        constexpr int RS = RWI * C;                                   // one input row (elements)
+        constexpr bool RAGGED = RWO % 16 != 0;
+        // element offset of the lane's 8-channel chunk of the pixel dx columns right of output pixel nn (swizzle as in bb_off)
+        auto lane_off = [&](int nn, int dx) { return (nn + dx) * C + ((c8 ^ (((nn + dx + IOFF) >> 2) & 1)) << 3); };
+        const bf16_t* rowb = s_in + ((yb + IOFF) * RWI + IOFF) * C;
+        const bf16_t* pA = rowb + lane_off(n, h);                      // steps 0-2: row r + dy, column x | x+1
+        const bf16_t* pAl = rowb + XLAST * C + lane_off(nl, h);
+        const bf16_t* pC = rowb + h * RS + lane_off(n, 2);             // step 3: column x+2 of rows r | r+1
+        const bf16_t* pCl = rowb + XLAST * C + h * RS + lane_off(nl, 2);
+        // step 4: pixel (r+2, x+2) on the first half; second half: the block input at the output pixel (second conv of a block,
+        // identity weights) or the same pixel again (zero weights)
+        const bf16_t* pD = rowb + 2 * RS + lane_off(n, 2);
+        const bf16_t* pDl = rowb + XLAST * C + 2 * RS + lane_off(nl, 2);
+        int dstep = RS;
+        if (RES_MFMA && h) {
+            const bf16_t* rr = s_res + ((yb + ROFF) * RWR + ROFF) * C;
+            pD = rr + n * C + ((c8 ^ (((n + ROFF) >> 2) & 1)) << 3);
+            pDl = rr + (XLAST + nl) * C + ((c8 ^ (((nl + ROFF) >> 2) & 1)) << 3);
+            dstep = RWR * C;
+        }
+        // Rows of the band one after the other, the row's XT column groups as independent accumulator chains (as in the 32-channel
+        // form).  Per row and group: ONE new fragment for steps 0-2 (row r+2; rows r and r+1 are still in registers from the rows
+        // before) plus the fragments of steps 3 and 4 -- three LDS reads for five MFMAs instead of five.
+        if (yb < RHO) {
+            bf16x8 fa[XT][RB + 2];
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) {
+                const bf16_t* bA = (RAGGED && xt == XT - 1) ? pAl : pA + xt * 16 * C;
+                fa[xt][0] = *(const bf16x8*)bA; fa[xt][1] = *(const bf16x8*)(bA + RS);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int y = yb + r;
+                if (y >= RHO) break;
+                bf16x8 f3[XT], f4[XT];
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+                    const bool lastg = RAGGED && xt == XT - 1;
+                    fa[xt][r + 2] = *(const bf16x8*)((lastg ? pAl : pA + xt * 16 * C) + (r + 2) * RS);
+                    f3[xt] = *(const bf16x8*)((lastg ? pCl : pC + xt * 16 * C) + r * RS);
+                    f4[xt] = *(const bf16x8*)((lastg ? pDl : pD + xt * 16 * C) + r * dstep);
+                }
+                f32x4 acc[XT][1];
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], fa[xt][r], bias[0], 0, 0, 0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], fa[xt][r + 1], acc[xt][0], 0, 0, 0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][0], fa[xt][r + 2], acc[xt][0], 0, 0, 0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3][0], f3[xt], acc[xt][0], 0, 0, 0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4][0], f4[xt], acc[xt][0], 0, 0, 0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) epi(xt, r, y, acc[xt]);
             }
         }
     }
@@ -1432,7 +1511,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
         for (int k = 0; k < IN_PT; ++k)
             if (rl < RL && rl + k * RL < R0H) *(u32x4*)(dst + k * RL * R0W * C) = v[k];
     }
-    fr.idm = bb_identity_frag(lane);
+    const bf16x8 idm = bb_identity_frag(lane);
     if (C == 16) bb_load_frag16(fr, a.w[0], a.bias[0], lane);          // first conv's fragments: in flight across the barrier
     __syncthreads();
     TTUP_STAMP(1);
@@ -1444,7 +1523,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     __syncthreads();
     TTUP_STAMP(3);
     bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane,
-                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, pre);
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr, pre, nullptr, idm);
     if (C == 16) bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
     TTUP_STAMP(4);
@@ -1507,12 +1586,10 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
     bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0, MODE>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
-                                                                   nullptr, nullptr, nullptr, &a, &best, pre, &tlds);
+                                                                   nullptr, nullptr, nullptr, &a, &best, pre, &tlds, idm);
 #ifdef TTUP_TIMING_SPLIT
     TTUP_STAMP(6);
 #endif
-    if (MODE == 7 && lane < 16 && best.i == 0x7fffffffffffffffLL && oy0 + wave < a.H && ox0 + lane < a.W)
-        best.i = (long long)(oy0 + wave) * a.W + ox0 + lane;      // nothing above -inf seen: the lane's first pixel is its first maximum
     if (C == 16 && MODE == 7) {
         // argmax partial of this tile.  (value, index) pairs become one 64-bit key -- order-preserving bits of the value (NaN on
         // top, -0 = +0 as torch.argmax has it) above the complemented index -- so that "greater value, then lower index" is an
