@@ -320,6 +320,35 @@ def test_conv64_fuse_followers_are_bit_identical():
     assert torch.equal(i1, i2)
 
 
+def test_chain_runtime_epilogue_form_matches_compiled_forms(tmp_path):
+    """The 16-channel chain's epilogue variants are compiled out for the network (sum of 1-3 terms, stage-4 tail); the run-time
+    form stays as the fallback for other term layouts.  TTUP_BB2_GENERIC=1 (read once per process, hence the child process)
+    routes the same network through it: same rounding points, the head's cross-lane sum in a different fp32 order."""
+    import subprocess, sys
+    h, w, b = 104, 168, 2
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from upliftingtabletennis_amd import wasb, weights\n"
+        "sd = weights.random_wasb_state_dict(37)\n"
+        "x = torch.from_numpy(np.random.default_rng(37).standard_normal((%d, 9, %d, %d)).astype(np.float32))\n"
+        "net = wasb.WASBNet(sd, resolution=(%d, %d), max_batch=%d, dtype='bf16')\n"
+        "heat, idx, _ = net.forward(x, want_peaks=True)\n"
+        "np.savez(sys.argv[1], heat=heat.cpu().numpy(), idx=idx.cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), b, h, w, w, h, b)
+    outs = {}
+    for tag, env in (('compiled', {}), ('runtime', {'TTUP_BB2_GENERIC': '1'})):
+        out = str(tmp_path / (tag + '.npz'))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, '-c', script, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    a, g = outs['compiled']['heat'], outs['runtime']['heat']
+    scale = float(g.max() - g.min())
+    assert np.abs(a - g).max() <= 1e-5 * scale, (np.abs(a - g).max(), scale)
+    assert np.array_equal(outs['compiled']['idx'], outs['runtime']['idx'])
+
+
 @pytest.mark.parametrize('bias', [float('-inf'), float('nan'), float('inf'), -0.0])
 def test_fused_head_argmax_special_values(bias):
     """The stage-4 tail keeps its per-tile argmax partial as a 64-bit key (order-preserving value bits, NaN on top, -0 == +0,
