@@ -320,6 +320,28 @@ def test_conv64_fuse_followers_are_bit_identical():
     assert torch.equal(i1, i2)
 
 
+@pytest.mark.parametrize('knob', ['TTUP_NO_FUSE_SUM', 'TTUP_NO_STEM', 'TTUP_NO_FRAMES_MODE'])
+def test_partially_fused_graphs_agree(knob):
+    """The cross-check builds of the graph (README, environment knobs) stay alive: the plain 16-channel chain with element-wise
+    fuse sums and the separate head, the stem as separate convs, X0 records instead of per-frame records.  Each differs from the
+    default graph only in where an fp32 sum is rounded to bf16: heatmaps within 2 % of the range, peaks of planted weights equal."""
+    h, w, b = 104, 168, 3
+    sd = weights.random_wasb_state_dict(41, planted=True)
+    frames, track = synth.synth_frames(b + 2, h, w, seed=41)
+    fr = torch.from_numpy(frames).cuda()
+    ref = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    os.environ[knob] = '1'
+    try:
+        alt = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    finally:
+        del os.environ[knob]
+    h1, i1, _ = ref.forward_frames(fr, want_heatmap=True)
+    h2, i2, _ = alt.forward_frames(fr, want_heatmap=True)
+    scale = (h1.max() - h1.min()).item()
+    assert (h1 - h2).abs().max().item() <= 2e-2 * scale, (knob, (h1 - h2).abs().max().item(), scale)
+    assert torch.equal(i1, i2), knob
+
+
 def test_chain_runtime_epilogue_form_matches_compiled_forms(tmp_path):
     """The 16-channel chain's epilogue variants are compiled out for the network (sum of 1-3 terms, stage-4 tail); the run-time
     form stays as the fallback for other term layouts.  TTUP_BB2_GENERIC=1 (read once per process, hence the child process)
