@@ -1082,14 +1082,12 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
         for (int m = 0; m < MT; ++m) bias[m] = *(const f32x4*)(biasp + g * 4 * MT + m * 4);
     }
-    int koff[KSTEPS];                     // per-lane tap/channel offset of every k-step (elements)
+    int koff[KSTEPS];                     // C=32: per-lane tap/channel offset of every k-step (elements); k-step s = tap (s/3, s%3)
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-        int dy, dx, c8;
-        if (C == 16) { int tap = 2 * s + (g >> 1); tap = tap > 8 ? 8 : tap; dy = tap / 3; dx = tap % 3; c8 = g & 1; }
-        else { dy = s / 3; dx = s % 3; c8 = g; }
+        const int dy = s / 3, dx = s % 3;
         // the column swizzle depends only on (n + dx + IOFF) mod 8: 16-pixel groups start at multiples of 16
-        koff[s] = (dy * RWI + dx) * C + (C == 32 ? ((c8 ^ (((n + dx + IOFF) >> 1) & 3)) << 3) : ((c8 ^ (((n + dx + IOFF) >> 2) & 1)) << 3));
+        koff[s] = (dy * RWI + dx) * C + ((g ^ (((n + dx + IOFF) >> 1) & 3)) << 3);
     }
     // lane's pixel in the last (possibly ragged) group is clamped so that reads stay inside the buffer
     constexpr int XLAST = (XT - 1) * 16;
@@ -1113,24 +1111,17 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     constexpr bool BAND = (C == 16);
     constexpr int RB = (RHO + 7) / 8;
     const int yb = BAND ? wave * RB : wave;      // the wave's first row
-    // fixed trip count, fully unrolled: the row offsets become immediates of the LDS instructions instead of a dozen per-lane
-    // address registers that each need an add per row
-    // per-lane fragment addresses of the wave's FIRST row, one per k-step (full groups / clamped last group); the rows that
-    // follow are compile-time offsets from them
+    // C=32: per-lane fragment addresses of the wave's FIRST row, one per k-step (full groups / clamped last group); the row loop is
+    // fully unrolled, so the rows that follow are compile-time offsets (LDS instruction immediates) from them instead of a
+    // dozen address registers that each need an add per row.  (C=16 sets up its band addresses below.)
     const bf16_t* pk0[KSTEPS];
     const bf16_t* pkl[KSTEPS];
     {
         const bf16_t* row0 = s_in + ((wave + IOFF) * RWI + IOFF) * C;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { pk0[s] = row0 + n * C + koff[s]; pkl[s] = row0 + (XLAST + nl) * C + koff[s]; }
-        // last k-step of RES_MFMA: lanes g >= 2 read the block input at the output pixel instead of the (zero-weight) tap
-        if (RES_MFMA && g >= 2) {
-            const bf16_t* rr = s_res + ((wave + ROFF) * RWR + ROFF) * C + (((g & 1) ^ (((n + ROFF) >> 2) & 1)) << 3);
-            pk0[KSTEPS - 1] = rr + n * C; pkl[KSTEPS - 1] = rr + (XLAST + nl) * C;
-        }
     }
-    // the residual buffer's row stride may differ from the input's: its row step is applied to lanes g >= 2 only
-    constexpr int ROWSTEP = 8 * RWI * C, RES_ROWSTEP = 8 * RWR * C;
+    constexpr int ROWSTEP = 8 * RWI * C;
     int tx[3] = {0, 0, 0};
     if constexpr (CAN_SUM && MODE > 0 && MODE != 4) {
 #pragma unroll
