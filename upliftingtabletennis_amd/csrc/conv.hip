@@ -1542,8 +1542,11 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
         constexpr int BN = NS == 1 ? B1 : NS == 2 ? B2 : B3;
         const int k = tid < B1 ? 0 : tid < B2 ? 1 : 2, sh = k + 1;
         const int u = tid - (k == 0 ? 0 : k == 1 ? B1 : B2);
-        const int px = u >> 1, lw = __builtin_ctz(TW) - sh;
-        const int ty = (oy0 >> sh) + (px >> lw), tx = (ox0 >> sh) + (px & ((TW >> sh) - 1));
+        const int px = u >> 1;
+        // row / column of the slice pixel: division by the (compile-time) slice width of the thread's term
+        const int pr = k == 0 ? px / (TW >> 1) : k == 1 ? px / (TW >> 2) : px / (TW >> 3);
+        const int pc = px - pr * (TW >> sh);
+        const int ty = (oy0 >> sh) + pr, tx = (ox0 >> sh) + pc;
         const int hs = a.H >> sh, ws = a.W >> sh;
         const bf16_t* tp = k == 0 ? a.st[0] : k == 1 ? a.st[1] : a.st[2];
         const bool ok = tid < BN && ty < hs && tx < ws;
@@ -1559,9 +1562,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
                 tlds.toff[k] = base * 8; tlds.tw[k] = wk;
                 const int u = tid - base;
                 if (u >= 0 && u < hk * wk * 2) {
-                    static_assert(C != 16 || (TW & (TW - 1)) == 0, "slice width is a power of two: row / column of a slice pixel are a shift and a mask");
-                    const int lw = __builtin_ctz(TW) - sh;            // log2(wk)
-                    const int px = u >> 1, ty = (oy0 >> sh) + (px >> lw), tx = (ox0 >> sh) + (px & (wk - 1));
+                    const int px = u >> 1, ty = (oy0 >> sh) + px / wk, tx = (ox0 >> sh) + px % wk;
                     if (ty < (a.H >> sh) && tx < (a.W >> sh)) treg = *(const u32x4*)(a.st[k] + ((size_t)(b * (a.H >> sh) + ty) * (a.W >> sh) + tx) * 16 + (u & 1) * 8);
                     tunit = tid;
                 }
@@ -1571,7 +1572,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     }
     bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr, pre);
-    if (C == 16 && tunit >= 0) { static_assert(C != 16 || T_FREE * 2 >= 504 * 16, "bufB tail holds the term slices"); ((u32x4*)s_terms)[tunit] = treg; }
+    if (C == 16 && tunit >= 0) { static_assert(C != 16 || T_FREE * 2 >= ((TH >> 1) * (TW >> 1) + (TH >> 2) * (TW >> 2) + (TH >> 3) * (TW >> 3)) * 32, "bufB tail holds the term slices"); ((u32x4*)s_terms)[tunit] = treg; }
     if (C == 16) bb_load_frag16(fr, a.w[3], a.bias[3], lane);
     __syncthreads();
     TTUP_STAMP(5);
@@ -1660,7 +1661,13 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     return TTUP_OK;
 }
 
-int bb_chain_tiles_per_img(int h, int w) { return cdiv(w, 32) * cdiv(h, 24); }      // tile grid of the C=16 two-block chain (24x32)
+// tile of the C=16 two-block chain (multiples of 8: the fuse-term slices are aligned to the tile)
+#ifndef TTUP_BB2_TH
+#define TTUP_BB2_TH 24
+#define TTUP_BB2_TW 32
+#endif
+constexpr int BB2_TH = TTUP_BB2_TH, BB2_TW = TTUP_BB2_TW;
+int bb_chain_tiles_per_img(int h, int w) { return cdiv(w, BB2_TW) * cdiv(h, BB2_TH); }
 
 int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, void* y, int batch, int h, int w,
                     const PackedConv* follow, void* y_follow, hipStream_t st, const BBSum* sum) {
@@ -1697,12 +1704,12 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
         const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.ysum && !a.heat;      // a.y (the pre-fuse tensor) optional
         const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
-        if (!generic && a.nsum == 0 && !a.heat && !a.ysum && a.y) return launch_bb2_t<16, 24, 32, 4>(a, batch, h, w, st);
-        if (tail) return launch_bb2_t<16, 24, 32, 7>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 1) return launch_bb2_t<16, 24, 32, 1>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 2) return launch_bb2_t<16, 24, 32, 2>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 3) return launch_bb2_t<16, 24, 32, 3>(a, batch, h, w, st);
-        return launch_bb2_t<16, 24, 32, 0>(a, batch, h, w, st);
+        if (!generic && a.nsum == 0 && !a.heat && !a.ysum && a.y) return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
+        if (tail) return launch_bb2_t<16, BB2_TH, BB2_TW, 7>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 1) return launch_bb2_t<16, BB2_TH, BB2_TW, 1>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 2) return launch_bb2_t<16, BB2_TH, BB2_TW, 2>(a, batch, h, w, st);
+        if (sum_stored && a.nsum == 3) return launch_bb2_t<16, BB2_TH, BB2_TW, 3>(a, batch, h, w, st);
+        return launch_bb2_t<16, BB2_TH, BB2_TW, 0>(a, batch, h, w, st);
     }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
