@@ -320,10 +320,10 @@ def test_conv64_fuse_followers_are_bit_identical():
     assert torch.equal(i1, i2)
 
 
-@pytest.mark.parametrize('knob', ['TTUP_NO_FUSE_SUM', 'TTUP_NO_STEM', 'TTUP_NO_FRAMES_MODE'])
+@pytest.mark.parametrize('knob', ['TTUP_NO_FUSE_SUM', 'TTUP_NO_STEM', 'TTUP_NO_FRAMES_MODE', 'TTUP_NO_PAIR'])
 def test_partially_fused_graphs_agree(knob):
     """The cross-check builds of the graph (README, environment knobs) stay alive: the plain 16-channel chain with element-wise
-    fuse sums and the separate head, the stem as separate convs, X0 records instead of per-frame records.  Each differs from the
+    fuse sums and the separate head, the stem as separate convs, X0 records instead of per-frame records, the two stride-2 convs of stage 3's fuse layer as two launches.  Each differs from the
     default graph only in where an fp32 sum is rounded to bf16: heatmaps within 2 % of the range, peaks of planted weights equal."""
     h, w, b = 104, 168, 3
     sd = weights.random_wasb_state_dict(41, planted=True)
@@ -340,6 +340,9 @@ def test_partially_fused_graphs_agree(knob):
     scale = (h1.max() - h1.min()).item()
     assert (h1 - h2).abs().max().item() <= 2e-2 * scale, (knob, (h1 - h2).abs().max().item(), scale)
     assert torch.equal(i1, i2), knob
+    if knob == 'TTUP_NO_PAIR':          # the paired stride-2 kernel does the two convs' arithmetic unchanged, in one pass over their input
+        assert torch.equal(h1, h2)
+        assert len(wasb.time_ops(alt, reps=1)) - len(wasb.time_ops(ref, reps=1)) == 1
 
 
 def test_chain_runtime_epilogue_form_matches_compiled_forms(tmp_path):

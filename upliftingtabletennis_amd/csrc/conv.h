@@ -38,6 +38,8 @@ struct ConvLaunch {
     // bf16 64 -> 64 3x3 only: linear 1x1 followers (fuse-layer convs 64 -> 16 / 64 -> 32, no ReLU) applied to dst
     const PackedConv* lin16 = nullptr; void* lin16_dst = nullptr;
     const PackedConv* lin32 = nullptr; void* lin32_dst = nullptr;
+    // bf16 3x3 stride-2 16 -> 32 only: a second stride-2 conv 16 -> 16 on the same input, run in the same pass (one read of src0)
+    const PackedConv* pair = nullptr; void* pair_dst = nullptr; int pair_relu = 0;
 };
 
 // host-side packing (called from ttup_wasb_create)

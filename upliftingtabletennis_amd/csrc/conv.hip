@@ -54,6 +54,8 @@ struct ConvKArgs {
     // higher-resolution branches, wasb.py:189-205: conv + BN, no ReLU)
     const bf16_t* wl16; const float* bl16; bf16_t* dl16;
     const bf16_t* wl32; const float* bl32; bf16_t* dl32;
+    // conv_s2_pair_kernel: the second conv on the same input (16 -> 16), its own ReLU flag
+    const bf16_t* wpack_b; const float* bias_b; bf16_t* dst_b; int relu_b;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -319,6 +321,111 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                 for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(c11[i >> 1][2 * (i & 1)], c11[i >> 1][2 * (i & 1) + 1]));
                 *(u32x4*)(a.dst11 + ((size_t)(b * a.OH + oy) * a.OW + ox) * 32 + g * 8) = pk;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ two stride-2 convs on one input
+// Stage 3's fuse layer takes the full-resolution 16-channel branch down twice: 3x3 s2 16 -> 32 (the term of the half-resolution
+// output, wasb.py:207-222 with i=1: conv + BN, the running fuse sum and ReLU in the epilogue) and 3x3 s2 16 -> 16 + ReLU (first
+// conv of the chain towards the quarter resolution, i=2).  Both are HBM-bound on that 230-MB tensor (8 frames); here ONE
+// workgroup pass stages the halo tile once and runs both: one read of the branch instead of two.  Same arithmetic per output
+// as conv_mfma_kernel<16, COUT, 3, 2, 4, 32, 8> (same k-steps, same epilogue order).
+__global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
+    constexpr int CK = 16, KS = 3, S = 2, TH = 4, TW = 32, NW = 8, MTA = 2, MTB = 1;
+    constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+    constexpr int KSTEPS = 5, PAD = 1;
+    constexpr int IN_ELEMS = IH * IW * CK;
+    constexpr int IN_UNITS = IH * IW * (CK / 8), IN_PT = (IN_UNITS + 511) / 512;
+    constexpr int WA_UNITS = KSTEPS * MTA * 64, WB_UNITS = KSTEPS * MTB * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_in = (bf16_t*)smem;
+    bf16_t* s_wa = s_in + ((IN_ELEMS + 7) & ~7);
+    bf16_t* s_wb = s_wa + WA_UNITS * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    StageRegs<WA_UNITS> wa; StageRegs<WB_UNITS> wb;
+    stage_load_512<WA_UNITS>(wa, a.wpack, tid);
+    stage_load_512<WB_UNITS>(wb, a.wpack_b, tid);
+    u32x4 pin[IN_PT];
+    auto issue = [&](int it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * TH * S - PAD, gx0 = (t % a.tiles_x) * TW * S - PAD;
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u % (CK / 8), pix = u / (CK / 8);
+            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            const bool ok = u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const u32x4 v = *(const u32x4*)(ok ? a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * CK + c8 * 8 : a.src0);      // branch-free: the loads go out together
+            pin[k] = u32x4{ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u};
+        }
+    };
+    if (my_tiles > 0) issue(0);
+    stage_store_512<WA_UNITS>(s_wa, wa, tid);
+    stage_store_512<WB_UNITS>(s_wb, wb, tid);
+    f32x4 bias_a[MTA], bias_b;
+#pragma unroll
+    for (int m = 0; m < MTA; ++m) bias_a[m] = *(const f32x4*)(a.bias + g * 4 * MTA + m * 4);
+    bias_b = *(const f32x4*)(a.bias_b + g * 4);
+    // per-lane fragment bases, one per k-step (taps 2s | 2s+1 on lane groups 0-1 | 2-3; the tenth tap is a zero pad)
+    const bf16_t* bB[KSTEPS];
+#pragma unroll
+    for (int k = 0; k < KSTEPS; ++k) {
+        int tap = 2 * k + (g >> 1);
+        if (tap > 8) tap = 8;
+        bB[k] = s_in + lds_off<CK, IW>(tap / KS, n * S + tap % KS, g & 1);
+    }
+    // the wave's 16-pixel group of the 4x32 tile: row wave / 2, column half wave % 2
+    const int r = wave >> 1, cg = wave & 1;
+    for (int it = 0; it < my_tiles; ++it) {
+        if (it > 0) __syncthreads();            // every wave finished reading the previous tile
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            if (u < IN_UNITS) { const int c8 = u % (CK / 8), pix = u / (CK / 8); *(u32x4*)(s_in + lds_off<CK, IW>(pix / IW, pix % IW, c8)) = pin[k]; }
+        }
+        __syncthreads();
+        if (it + 1 < my_tiles) issue(it + 1);
+        f32x4 acc_a[MTA] = {bias_a[0], bias_a[1]}, acc_b = bias_b;
+#pragma unroll
+        for (int s5 = 0; s5 < KSTEPS; ++s5) {
+            const bf16x8 bfr = *(const bf16x8*)(bB[s5] + ((r * S) * IW + cg * 16 * S) * CK);
+#pragma unroll
+            for (int m = 0; m < MTA; ++m) acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(s_wa + ((s5 * MTA + m) * 64 + lane) * 8), bfr, acc_a[m], 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(s_wb + (s5 * 64 + lane) * 8), bfr, acc_b, 0, 0, 0);
+        }
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy = (tt / a.tiles_x) * TH + r, ox = (tt % a.tiles_x) * TW + cg * 16 + n;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t opix = (size_t)(b * a.OH + oy) * a.OW + ox;
+        {   // first conv: 32 outputs, lane holds couts g*8 .. g*8+7; fuse-layer terms in conv_mfma_kernel's order
+            const size_t o = opix * 32 + g * 8;
+            float v[8];
+#pragma unroll
+            for (int m = 0; m < MTA; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[m * 4 + q] = acc_a[m][q];
+            auto add_term = [&](const bf16_t* base) {
+                const u32x4 rv = *(const u32x4*)base;
+                const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+            };
+            if (a.residual) add_term(a.residual + o);
+            if (a.res2) add_term(a.res2 + o);
+            if (a.res3) add_term(a.res3 + ((size_t)(b * (a.OH >> a.sh3) + (oy >> a.sh3)) * (a.OW >> a.sh3) + (ox >> a.sh3)) * 32 + g * 8);
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[2 * i], v[2 * i + 1]); pk[i] = a.relu ? relu_pk(w) : w; }
+            *(u32x4*)(a.dst + o) = pk;
+        }
+        {   // second conv: 16 outputs, lane holds couts g*4 .. g*4+3
+            const unsigned w0 = pack2(acc_b[0], acc_b[1]), w1 = pack2(acc_b[2], acc_b[3]);
+            *(u32x2*)(a.dst_b + opix * 16 + g * 4) = u32x2{a.relu_b ? relu_pk(w0) : w0, a.relu_b ? relu_pk(w1) : w1};
         }
     }
 }
@@ -1895,6 +2002,25 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         return launch_mfma<32, 64, 3, 1, 8, 32, 8, true>(p, l, st);
     }
     if (p.k == 3 && p.stride == 1 && p.ck == 32 && p.cout == 64 && p.cin_total == 64 && p.c0 == 64 && !l.src1) return launch_conv64(p, l, st);
+    if (l.pair) {
+        const PackedConv& q = *l.pair;
+        TTUP_REQUIRE(p.k == 3 && p.stride == 2 && p.ck == 16 && p.cin_total == 16 && p.cout == 32 && q.k == 3 && q.stride == 2 && q.ck == 16 &&
+                     q.cin_total == 16 && q.cout == 16 && l.pair_dst && !l.src1, TTUP_EINVAL, "conv: the paired form is 3x3 s2 16 -> 32 with 3x3 s2 16 -> 16");
+        ConvKArgs a;
+        memset(&a, 0, sizeof a);
+        a.src0 = (const bf16_t*)l.src0; a.wpack = (const bf16_t*)p.w_dev; a.bias = p.bias_dev; a.residual = (const bf16_t*)l.residual; a.dst = (bf16_t*)l.dst;
+        a.res2 = (const bf16_t*)l.res2; a.res3 = (const bf16_t*)l.res3; a.sh3 = l.sh3; a.relu = l.relu;
+        a.wpack_b = (const bf16_t*)q.w_dev; a.bias_b = q.bias_dev; a.dst_b = (bf16_t*)l.pair_dst; a.relu_b = l.pair_relu;
+        a.H = l.h; a.W = l.w; a.OH = (l.h + 1) / 2; a.OW = (l.w + 1) / 2;
+        a.tiles_x = cdiv(a.OW, 32); a.tiles_per_img = a.tiles_x * cdiv(a.OH, 4); a.total_tiles = a.tiles_per_img * l.batch;
+        constexpr size_t SMEM = (size_t)(((9 * 65 * 16 + 7) & ~7) + 5 * 3 * 64 * 8) * 2;
+        if (int rc = ensure_max_lds((const void*)conv_s2_pair_kernel, SMEM)) return rc;
+        const int grid = a.total_tiles < 256 * 4 ? a.total_tiles : 256 * 4;
+        if (grid == 0) return TTUP_OK;
+        hipLaunchKernelGGL(conv_s2_pair_kernel, dim3(grid), dim3(512), SMEM, st, a);
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
     TTUP_REQUIRE(!l.lin16 && !l.lin32, TTUP_EINVAL, "conv: linear 1x1 followers ride on the 64 -> 64 3x3 kernel only");
     if (p.k == 3 && p.stride == 1) return p.ck == 32 ? dispatch_cout<32, 3, 1, 8, 32>(p, l, st) : dispatch_cout<16, 3, 1, 8, 32>(p, l, st);
     if (p.k == 3 && p.stride == 2) return p.ck == 32 ? dispatch_cout<32, 3, 2, 4, 32>(p, l, st) : dispatch_cout<16, 3, 2, 4, 32>(p, l, st);

@@ -31,6 +31,8 @@ struct Op {
     int conv1f = -1;                            // STEM: conv1 packed for the frames mode (channel slot f*4 + c)
     // CONV (64 -> 64 3x3, bf16): fuse-layer 1x1 convs on its output riding in its epilogue (packed conv index, output tensor)
     int lin16 = -1, lin16_dst = -1, lin32 = -1, lin32_dst = -1;
+    // CONV (3x3 s2 16 -> 32, bf16): a second 3x3 s2 16 -> 16 conv on the same input in the same pass (packed conv, output, ReLU)
+    int pair = -1, pair_dst = -1, pair_relu = 0;
 };
 
 // Certified argmax (csrc/certify.hip): state owned by a bf16 ball-detector handle

@@ -234,7 +234,20 @@ struct Builder {
                         const int dst = new_tensor(f.cout, (sc.h + 1) / 2, (sc.w + 1) / 2);
                         Op op; op.kind = Op::CONV; op.conv = pc; op.src0 = cur; op.dst = dst; op.relu = last ? 0 : 1;
                         if (last && acc >= 0) op.residual = acc;
-                        net->ops.push_back(op);
+                        // 16 -> 16 on the full-resolution branch while an earlier fuse chain took the same tensor down 16 -> 32: both
+                        // convs in one pass over it (conv_s2_pair_kernel)
+                        bool paired = false;
+                        if (fuse && !last && f.cout == 16 && sc.c == 16 && !getenv("TTUP_NO_PAIR")) {
+                            for (int q = (int)net->ops.size() - 1; q >= 0 && !paired; --q) {
+                                Op& po = net->ops[q];
+                                if (po.kind != Op::CONV || po.src0 != cur || po.conv < 0) continue;
+                                const PackedConv& pp = net->convs[po.conv];
+                                if (pp.k == 3 && pp.stride == 2 && pp.cout == 32 && pp.cin_total == 16 && po.pair < 0 && po.conv2 < 0 && po.src1 < 0) {
+                                    po.pair = pc; po.pair_dst = dst; po.pair_relu = op.relu; paired = true;
+                                }
+                            }
+                        }
+                        if (!paired) net->ops.push_back(op);
                         if (last) last_chain_op = (int)net->ops.size() - 1;
                         cur = dst;
                     }
@@ -398,6 +411,7 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
             if (op.lin16 >= 0) { l.lin16 = &net->convs[op.lin16]; l.lin16_dst = net->tensors[op.lin16_dst].ptr; }
             if (op.lin32 >= 0) { l.lin32 = &net->convs[op.lin32]; l.lin32_dst = net->tensors[op.lin32_dst].ptr; }
+            if (op.pair >= 0) { l.pair = &net->convs[op.pair]; l.pair_dst = net->tensors[op.pair_dst].ptr; l.pair_relu = op.pair_relu; }
             if (op.res2 >= 0) l.res2 = net->tensors[op.res2].ptr;
             if (op.res3 >= 0) { l.res3 = net->tensors[op.res3].ptr; l.sh3 = op.sh3; }
             const int rc = launch_conv(net->convs[op.conv], l, net->dtype, st);
@@ -689,6 +703,7 @@ void op_info(const ttup_wasb* net, int i, int* o, char* name) {
         o[0] = 0; o[1] = (i == 0) ? net->in_ch : pc.cin_total; o[2] = pc.cout; o[3] = pc.k; o[4] = pc.stride; o[5] = d.h; o[6] = d.w; o[7] = pc.cin_total;
         if (!bf) snprintf(nm, sizeof nm, "conv_direct_f32_kernel");
         else if (pc.k == 3 && pc.stride == 1 && pc.cout == 64 && pc.cin_total == 64 && op.conv2 < 0) snprintf(nm, sizeof nm, "conv64_kernel%s", (op.lin16 >= 0 || op.lin32 >= 0) ? "+1x1" : "");
+        else if (op.pair >= 0) { snprintf(nm, sizeof nm, "conv_s2_pair_kernel"); o[2] = pc.cout + net->convs[op.pair].cout; }      // both convs' outputs count
         else snprintf(nm, sizeof nm, "conv_mfma_kernel<%d,%d,%d,%d>", pc.ck, pc.cout, pc.k, pc.stride);
     } else {
         o[0] = op.kind == Op::UPSUM_HEAD ? 5 : 1; o[1] = op.n_terms; o[2] = d.c; o[3] = 0; o[4] = 0; o[5] = d.h; o[6] = d.w; o[7] = d.c;
