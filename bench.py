@@ -315,6 +315,11 @@ def main():
         raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    # host threads per rank: the host glue (filter / pad of a few hundred detections, pinned copies) is small; N ranks with the
+    # default thread pool each would oversubscribe the box's cores.  torch.distributed.run exports OMP_NUM_THREADS=1 when it is
+    # unset; the direct path and the self-spawned path end up with the same explicit setting here.
+    host_threads = int(os.environ.get('TTUP_THREADS_PER_RANK', max(1, min(8, (os.cpu_count() or 8) // max(1, world)))))
+    torch.set_num_threads(host_threads)
     dist = None
     collective = None
     if world > 1:
@@ -345,15 +350,21 @@ def main():
     # detections of step k and enqueues their uplift, so the GPU does not idle during the host glue.  Every step's
     # detect + refine + uplift + gather completes inside the timed region (the last collect is before the barrier).
     ticket = None
+    spec = pipe.worker.record_spec()
+    keys = pipe.worker.RECORD_KEYS
     for _ in range(a.steps):
         nxt = pipe.submit()
         if ticket is not None:
             rec = pipe.collect(ticket)
-            # final gather of the small per-frame / per-trajectory records (the only collective on the path)
-            gathered = pipeline.gather_records(rec, dist)
+            # final gather of the small per-frame / per-trajectory records: the only collective on the path, ONE all_gather per step
+            gathered = pipeline.gather_records({k: rec[k] for k in keys}, dist, spec=spec)
         ticket = nxt
     rec = pipe.collect(ticket)
-    gathered = pipeline.gather_records(rec, dist)
+    gathered = pipeline.gather_records({k: rec[k] for k in keys}, dist, spec=spec)
+    if dist is not None and rank == 0:
+        n_rows = sum(int(t.shape[0]) for t in gathered['xyv'])
+        if n_rows != TRIPLES * world:
+            raise SystemExit('bench.py: the gather returned %d detections, expected %d' % (n_rows, TRIPLES * world))
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -370,11 +381,19 @@ def main():
                        'frames_per_step_per_gpu': TRIPLES, 'parallelism': 'stream-per-gpu x%d, final gather' % world}}
     if pipe.worker.certify:
         cs = pipe.net.certify_stats()
+        au = pipe.worker.audit
         line['certified_argmax'] = {'eps_abs': round(pipe.worker.certify_eps, 6), 'heatmaps': cs['heatmaps'], 'single_candidate': cs['single'],
                                     'resolved_on_fp32_crops': cs['resolved'], 'not_certified': cs['not_certified'], 'crops': cs['crops'],
                                     'fp32_full_frame_reruns': pipe.worker.fp32_reruns,
-                                    'note': 'every argmax index of the timed steps is the fp32 argmax (csrc/certify.hip); counts cover warm-up + timed steps'}
+                                    'audited_frames': au['audited_frames'], 'audit_every_frames': pipe.worker.audit_every,
+                                    'max_err_seen': round(au['max_err_seen'], 6), 'max_candidate_err': round(cs['max_candidate_err'], 6),
+                                    'max_err_over_eps': round(au['max_err_over_eps'], 4), 'eps_widened': au['widened'], 'recertified_clips': au['recertified_clips'],
+                                    'note': 'an index is the fp32 argmax whenever |bf16 - fp32| <= eps on its frame (csrc/certify.hip); eps is audited inside the timed '
+                                            'steps: one random frame per audit_every frames on the fp32 twin (side stream) + the error at every candidate of every crop; '
+                                            'it is widened and the clip re-run when max_err * 1.5 > eps.  Counts cover warm-up + timed steps'}
+    line['host_threads_per_rank'] = host_threads
     if collective is not None:
+        line['collectives_per_step'] = 1
         line['rccl_ranks'] = collective['ranks'] if collective['backend'] == 'nccl' else 0
         line['collective'] = collective
     if rank == 0:

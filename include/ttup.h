@@ -116,8 +116,17 @@ int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float
  * fp32 winner and its fp32 3x3 window.  eps_abs < 0 switches it off.  csrc/certify.hip.
  * status (after a forward, per heatmap): 0 = one candidate (the bf16 index is certain), 1 = resolved on fp32 crops,
  * 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned).
- * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved, 0, 0}. */
+ * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved,
+ * bits of max |bf16 - fp32| seen at a candidate (a float in the low 32 bits: the free part of the eps audit), single-candidate
+ * heatmaps cropped in exact-window mode}. */
 int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map);
+/* exact-window mode (on != 0): heatmaps with ONE candidate get an fp32 crop too, so that every returned 3x3 window -- not only
+ * the near-ties' -- holds the fp32 path's values and the sub-pixel fit sees what the reference's fit sees (one 168x168 fp32
+ * pass per heatmap: a parity / audit mode, off by default) */
+int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on);
+/* info_dev[0] = crops the LAST forward asked for (may exceed the budget it had); info_dev[1] = the bits of a float: the largest
+ * |bf16 - fp32| seen so far at any candidate of any call (stats[6]); both copied in stream order, no synchronisation */
+int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream);
 int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
 /* crops the following forward calls may use (default: max_batch, i.e. one per heatmap): the call enqueues ceil(budget / 64) fp32
  * passes sized on the device, so a caller that knows its typical crop count (stats / status of earlier calls) saves the empty

@@ -105,3 +105,36 @@ def uplifting_transform(ball, table, times, seq_len=50):
         m[:, :tp] = 1.0
         return b, table, t, m
     return ball[:, :seq_len], table, np.asarray(times[:seq_len], dtype=np.float32)[None], np.ones((1, seq_len), np.float32)
+
+
+def _largest_cluster_centroid(detections, eps=10, min_samples=5):
+    """inference/utils.py:184-232: centroid of the largest DBSCAN cluster (scikit-learn, as in the reference)."""
+    from collections import Counter
+    from sklearn.cluster import DBSCAN
+    detections = np.asarray(detections)
+    if detections.shape[0] < min_samples:
+        return np.mean(detections, axis=0) if detections.shape[0] > 0 else None
+    labels = DBSCAN(eps=eps, min_samples=min_samples).fit(detections).labels_
+    valid = [lb for lb in labels if lb != -1]
+    if len(valid) == 0:
+        return np.mean(detections, axis=0)
+    largest = Counter(valid).most_common(1)[0][0]
+    return np.mean(detections[labels == largest], axis=0)
+
+
+def filter_trajectory_table(p1, p2):
+    """inference/utils.py:137-180: per keypoint, frames where both detectors see it within 10 px -> DBSCAN centroid;
+    fewer than 3 such frames -> (-1, -1, invisible)."""
+    p1, p2 = np.asarray(p1), np.asarray(p2)
+    out = []
+    for n in range(p1.shape[1]):
+        xs, ys = [], []
+        for t in range(p1.shape[0]):
+            if p1[t, n, 2] == 1 and p2[t, n, 2] == 1 and np.linalg.norm([p1[t, n, 0] - p2[t, n, 0], p1[t, n, 1] - p2[t, n, 1]]) < 10:
+                xs.append(p1[t, n, 0]); ys.append(p1[t, n, 1])
+        if len(xs) < 3:
+            out.append([-1, -1, 0])
+            continue
+        c = _largest_cluster_centroid(np.stack([xs, ys], axis=1), eps=10, min_samples=3)
+        out.append([c[0], c[1], 1] if c is not None else [-1, -1, 0])
+    return np.array(out)

@@ -1,0 +1,127 @@
+"""The certified argmax's supporting machinery on the MI355X box (-m gpu): the continuous eps audit (side-stream fp32 re-runs,
+candidate-level errors from the crops, widening + re-certification), the repair path of pipelined clips, and the per-handle
+serialisation of consecutive calls issued on different streams."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import has_gpu
+from upliftingtabletennis_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+if has_gpu():
+    from upliftingtabletennis_amd import pipeline, refine, wasb, _lib
+
+H, W = 96, 160            # small network: the full-frame fp32 twin is cheap
+
+
+def _fp32_peaks(sd, frames_dev, res):
+    """(idx, win, xyv) of every triple on the full-frame fp32 path."""
+    twin = wasb.WASBNet(sd, resolution=res, max_batch=1, dtype='f32')
+    x = wasb.preprocess_triples(frames_dev, res)
+    idx, win = [], []
+    for k in range(x.shape[0]):
+        _, i1, w1 = twin.forward(x[k:k + 1], want_heatmap=False, want_peaks=True)
+        idx.append(i1); win.append(w1)
+    idx, win = torch.cat(idx), torch.cat(win)
+    return idx, win, refine.refine_windows_device(idx, win, res[1], res[0], 1920, 1080, _lib.REFINE_TABLE)
+
+
+def test_audit_twin_recomputes_the_production_heatmap_bit_for_bit():
+    """The audit compares the fp32 twin with a ONE-sample bf16 handle instead of touching the production handle: both bf16 handles
+    must give the same heatmap for the same triple (per-tile deterministic kernels, any micro-batch / lane count)."""
+    sd = weights.random_wasb_state_dict(5)
+    frames, _ = synth.synth_frames(20, 720, 1280, seed=5)
+    fr = torch.from_numpy(frames).cuda()
+    net = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=18, dtype='bf16')
+    heat, _, _ = net.forward_frames(fr, want_heatmap=True)
+    for t in (0, 7, 8, 17):
+        h1, _, _ = net._audit_twin().forward_frames(fr[t:t + 3], want_heatmap=True)
+        assert torch.equal(h1[0], heat[t]), t
+    e = float(net.heatmap_error(fr, 3).item())
+    assert 0 < e < 0.1 * float(heat.abs().max())
+
+
+def test_eps_audit_widens_on_brighter_frames_and_recertifies():
+    """eps is calibrated on a dark clip; a later, much brighter clip has a larger bf16 error.  The side-stream audit (here one in
+    two triples) must notice, widen eps and re-run the clip, after which every index is the fp32 argmax and the observed error sits
+    inside the safety margin again."""
+    sd = weights.random_wasb_state_dict(9)                      # noise weights: near-ties everywhere
+    base, _ = synth.synth_frames(14, H, W, seed=9)
+    # "dark" = a flat mid-grey clip (normalised inputs near 0: small activations, small bf16 error); "bright" = the same scene at
+    # four times the contrast, saturating both ends
+    dark = np.clip(115.0 + (base.astype(np.float32) - 70.0) * 0.1, 0, 255).astype(np.uint8)
+    bright = np.clip(128.0 + (base.astype(np.float32) - 70.0) * 4.0, 0, 255).astype(np.uint8)
+    usd = weights.random_uplift_state_dict(9, 'large')
+    worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=2, audit_seed=1)
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    fd, fb = torch.from_numpy(dark).cuda(), torch.from_numpy(bright).cuda()
+    worker.process_clip(fd, table_px, 60.0)
+    eps_dark = worker.certify_eps
+    err_bright = max(float(worker.net.heatmap_error(fb, t).item()) for t in range(12))
+    assert err_bright * 1.5 > eps_dark, 'premise: the bright clip must break the dark clip\'s bound (%.3g vs eps %.3g)' % (err_bright, eps_dark)
+    # pipelined: the bright clip is submitted under the stale eps and must come back re-certified
+    t1 = worker.submit(fb)
+    t2 = worker.submit(fb)
+    o1 = worker.collect(t1, table_px, 60.0)
+    o2 = worker.collect(t2, table_px, 60.0)
+    a = worker.audit
+    print('\neps %.4g (dark clip) -> %.4g; bright clip error %.4g; audited %d frames, widened %d times, %d clips re-certified, max err / eps %.3f'
+          % (eps_dark, worker.certify_eps, err_bright, a['audited_frames'], a['widened'], a['recertified_clips'], a['max_err_over_eps']))
+    assert worker.certify_eps > eps_dark and a['widened'] >= 1 and a['recertified_clips'] >= 1
+    assert a['max_err_over_eps'] <= 1 / 1.5 + 1e-6
+    ref_idx, _, _ = _fp32_peaks(sd, fb, (W, H))
+    for o in (o1, o2):
+        _, idx, win = worker.net.forward_frames(fb)
+        worker.net.fix_uncertified(idx, win, frames_u8=fb)
+        assert torch.equal(idx, ref_idx)
+    assert torch.equal(o1['xyv'], o2['xyv'])
+
+
+def test_pipelined_repair_uses_the_tickets_own_status():
+    """collect() of clip k runs after submit() of clip k+1 has flipped the handle's per-call slot: the heatmaps of clip k that the
+    crop budget could not settle (status 2) must be repaired from clip k's OWN status.  A tiny budget and a wide eps on noise
+    weights force status 2 on many heatmaps of three different clips; every returned detection must equal the fp32 path's."""
+    sd = weights.random_wasb_state_dict(3)
+    usd = weights.random_uplift_state_dict(3, 'large')
+    clips = [torch.from_numpy(synth.synth_frames(14, H, W, seed=40 + k)[0]).cuda() for k in range(3)]
+    worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=0)
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    worker.process_clip(clips[0], table_px, 60.0)
+    worker.certify_eps = worker.net.widen_eps(worker.certify_eps * 4)        # more candidates than the 32 kept per heatmap on some maps
+    tickets = [worker.submit(c) for c in clips[:2]]
+    outs = [worker.collect(tickets[0], table_px, 60.0)]
+    tickets.append(worker.submit(clips[2]))
+    outs += [worker.collect(tickets[1], table_px, 60.0), worker.collect(tickets[2], table_px, 60.0)]
+    assert worker.fp32_reruns > 0, 'the repair path did not run: no heatmap was flagged'
+    n_flagged = 0
+    for c, o, t in zip(clips, outs, tickets):
+        ref_idx, ref_win, ref_xyv = _fp32_peaks(sd, c, (W, H))
+        st = t['status'].numpy()
+        n_flagged += int((st == 2).sum())
+        assert torch.equal(t['idx'], ref_idx)
+        fp32_win = torch.from_numpy(st != 0).cuda()
+        assert torch.equal(t['win'][fp32_win], ref_win[fp32_win])
+        assert torch.equal(o['xyv'][fp32_win], ref_xyv[fp32_win])
+    print('\n%d heatmaps flagged over 3 pipelined clips, %d full-frame fp32 re-runs' % (n_flagged, worker.fp32_reruns))
+    assert n_flagged == worker.fp32_reruns
+
+
+@pytest.mark.parametrize('lanes', ['1', '2'])
+def test_pipelined_small_clips_on_alternating_streams_do_not_share_buffers(monkeypatch, lanes):
+    """Clips of <= one micro-batch run on ONE lane; consecutive submits alternate between two caller streams.  Different clips
+    back to back must give what they give one at a time (TTUP_LANES=1: the micro-batches run on the caller's streams and the
+    handle orders them itself; 2: on the lane's stream)."""
+    monkeypatch.setenv('TTUP_LANES', lanes)
+    sd = weights.random_wasb_state_dict(0, planted=True)
+    usd = weights.random_uplift_state_dict(0, 'large')
+    worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(1280, 704), max_triples=16 if lanes == '2' else 8, traj_len=32, seq_len=50, audit_every=0)
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    clips = [torch.from_numpy(synth.synth_frames(8, 720, 1280, seed=70 + k)[0]).cuda() for k in range(4)]
+    alone = [worker.process_clip(c, table_px, 60.0) for c in clips]
+    assert not torch.equal(alone[0]['xyv'], alone[1]['xyv'])
+    for rep in range(3):
+        tickets = [worker.submit(c) for c in clips]
+        outs = [worker.collect(t, table_px, 60.0) for t in tickets]
+        for a, o in zip(alone, outs):
+            assert torch.equal(a['xyv'], o['xyv']) and torch.equal(a['spin'], o['spin'])

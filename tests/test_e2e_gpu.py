@@ -1,0 +1,125 @@
+"""End-to-end parity of the whole chain -- frames in, (spin, 3-D positions) out -- against the reference's own modules
+chained as interface.py chains them (tests/golden/e2e.npz, made by tools/make_goldens.py gen_e2e in the build container).
+Runs on the MI355X box only (-m gpu); /root/reference is never read here.
+
+Two regimes are measured and asserted:
+  * production: bf16 CNN with the certified argmax; 94 % of the heatmaps have one candidate and keep their bf16 3x3 window, so
+    the refined xy differs from the reference's by a few hundredths of a network pixel and that propagates into the uplift;
+  * exact windows (TTUP_EXACT_WINDOWS=1 / exact_windows=True): every heatmap gets an fp32 crop, all windows are fp32 values and
+    the chain agrees with the reference to the accuracy of the device fit and the fp32 uplift (north_star's 1e-4 rel).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import has_gpu
+from e2e_common import e2e_case, check_spin_pos
+from upliftingtabletennis_amd import weights
+
+pytestmark = pytest.mark.gpu
+
+# bars (measured values are printed by the tests; DESIGN.md 3 quotes them)
+XY_NET_PX = {False: 0.05, True: 2e-4}          # refined xy, in network pixels (output px / (1920 / W))
+REL_3D = {False: 5e-3, True: 1e-4}             # pos3d, |spin|, spin_z relative to the largest entry
+
+
+def _write_checkpoints(root, sd_ball, sd_table, sd_up, res):
+    """Reference-format checkpoint folder (inference_<task>/<model>/model.pt, helper_balldetection.py:510-529)."""
+    layout = {('inference_balldetection', 'wasb'): (sd_ball, {'model_name': 'wasb', 'image_resolution': tuple(res), 'in_frames': 3, 'lr': 1e-3}),
+              ('inference_tabledetection', 'hrnet'): (sd_table, {'model_name': 'hrnet', 'image_resolution': tuple(res)}),
+              ('inference_uplifting', 'ours'): (sd_up, {'name': 'connectstage', 'size': 'large', 'tabletoken_mode': 'dynamic', 'time_rotation': 'new',
+                                                         'transform_mode': 'global'})}
+    for (task, name), (sd, info) in layout.items():
+        d = os.path.join(str(root), task, name)
+        os.makedirs(d)
+        torch.save({'model_state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, 'identifier': 'e2e-test', 'additional_info': info},
+                   os.path.join(d, 'model.pt'))
+
+
+def _hub(tmp_path, monkeypatch, g, name, exact):
+    import hubconf
+    frames, fps, sd_ball, sd_table, sd_up, res = e2e_case(g, name)
+    _write_checkpoints(tmp_path, sd_ball, sd_table, sd_up, res)
+    monkeypatch.setenv('TTUP_WEIGHTS', str(tmp_path))
+    monkeypatch.delenv('TTUP_SYNTHETIC_WEIGHTS', raising=False)
+    if exact:
+        monkeypatch.setenv('TTUP_EXACT_WINDOWS', '1')
+    else:
+        monkeypatch.delenv('TTUP_EXACT_WINDOWS', raising=False)
+    pipe = hubconf.full_pipeline()
+    assert pipe.ball_detector.model_resolution == res and pipe.table_detector.model_resolution == res
+    return pipe, [f for f in frames], fps, res
+
+
+@pytest.mark.parametrize('exact', [False, True], ids=['production', 'exact-windows'])
+def test_e2e_small_hub_predict_matches_reference_chain(golden, tmp_path, monkeypatch, exact):
+    """hubconf.full_pipeline().predict(images, fps) on the 51-frame 96x160 fixture: checkpoints in the reference's format, both
+    detectors on every frame, DBSCAN keypoint filter, uplift -- against the reference chain's (spin, pos3d) and its intermediates."""
+    g = golden('e2e.npz')
+    pipe, images, fps, (w, h) = _hub(tmp_path, monkeypatch, g, 'small', exact)
+    spin, pos3d = pipe.predict(images, fps)
+    scale = 1920.0 / w
+    # intermediates through the same detectors
+    bp = pipe.ball_detector.predict_clip(images)
+    kp = pipe.table_detector.predict_keypoints(images)
+    fr = torch.from_numpy(np.stack(images)).cuda()
+    _, bidx, _ = pipe.ball_detector.model.forward_frames(fr[:34])
+    assert np.array_equal(bidx.cpu().numpy(), g['small/ball_argmax'][:32]), 'certified ball argmax differs from the reference argmax'
+    _, tidx, _ = pipe.table_detector.model.forward_frames(fr[:16])
+    t_agree = float((tidx.cpu().numpy().reshape(16, 13) == g['small/table_argmax'][:16]).mean())
+    d_ball = np.abs(bp[:, :2] - g['small/ball_positions'][:, :2]).max() / scale
+    d_table = np.abs(kp[..., :2] - g['small/table_keypoints'][..., :2]).max() / scale
+    assert np.array_equal(bp[:, 2], g['small/ball_positions'][:, 2]) and np.array_equal(kp[..., 2], g['small/table_keypoints'][..., 2])
+    dev = check_spin_pos(spin.cpu().numpy(), pos3d, g, 'small', REL_3D[exact])
+    print('\n[e2e small, %s] ball xy %.2e / table xy %.2e network px off the reference; table argmax agreement %.3f (bf16, not certified); '
+          'pos3d %.2e, |spin| %.2e, spin_z %.2e, spin_xy %.2e rel' % ('exact windows' if exact else 'production', d_ball, d_table, t_agree, *dev))
+    assert d_ball <= XY_NET_PX[exact], d_ball
+    assert t_agree == 1.0 and d_table <= XY_NET_PX[False], (t_agree, d_table)        # the table detector's windows are always bf16
+    assert pos3d.shape == g['small/pos3d'].shape
+
+
+@pytest.mark.parametrize('exact', [False, True], ids=['production', 'exact-windows'])
+def test_e2e_full_size_worker_and_hub_match_reference_chain(golden, tmp_path, monkeypatch, exact):
+    """The 12-frame 704x1280 fixture (10 triples) through StreamWorker.process_clip, its pipelined submit / collect form, and
+    TableTennisPipeline.predict_with_table, with the reference chain's filtered table keypoints handed in: argmax indices equal,
+    xy and (spin, pos3d) inside the stated bars; then `predict` (table detector on every frame) on the same clip."""
+    from upliftingtabletennis_amd import pipeline
+    g = golden('e2e.npz')
+    frames, fps, sd_ball, sd_table, sd_up, res = e2e_case(g, 'full')
+    n = len(frames)
+    scale = 1920.0 / res[0]
+    table_px = g['full/filtered_table']
+    worker = pipeline.StreamWorker('cuda:0', sd_ball, sd_up, net_wh=res, max_triples=16, traj_len=32, seq_len=50, exact_windows=exact, audit_every=8)
+    fr = torch.from_numpy(frames).cuda()
+    out = worker.process_clip(fr, table_px, fps)
+    _, idx, _ = worker.net.forward_frames(fr)
+    assert np.array_equal(idx.cpu().numpy(), g['full/ball_argmax'])
+    xyv = out['xyv'].cpu().numpy()
+    d_ball = np.abs(xyv[:, :2] - g['full/ball_positions'][:, :2]).max() / scale
+    assert d_ball <= XY_NET_PX[exact], d_ball
+    assert int(out['n_valid'][0]) == g['full/pos3d'].shape[0]
+    dev = check_spin_pos(out['spin'][0].cpu().numpy(), out['pos3d'][0, :int(out['n_valid'][0])].cpu().numpy(), g, 'full', REL_3D[exact])
+    a = worker.audit
+    print('\n[e2e full, %s] worker: ball xy %.2e network px; pos3d %.2e, |spin| %.2e, spin_z %.2e, spin_xy %.2e rel; eps audit: %d frames, max err / eps %.3f'
+          % ('exact windows' if exact else 'production', d_ball, *dev, a['audited_frames'], a['max_err_over_eps']))
+    assert a['audited_frames'] >= 4 and a['max_err_over_eps'] <= 1 / 1.5 + 1e-6
+    # pipelined form: same numbers
+    t1 = worker.submit(fr); t2 = worker.submit(fr)
+    o1 = worker.collect(t1, table_px, fps); o2 = worker.collect(t2, table_px, fps)
+    for o in (o1, o2):
+        assert torch.equal(o['xyv'], out['xyv']) and torch.equal(o['spin'], out['spin']) and torch.equal(o['pos3d'], out['pos3d'])
+    del worker
+    torch.cuda.empty_cache()
+    # hub surface with known table keypoints, then with its own table detector
+    pipe, images, fps, _ = _hub(tmp_path, monkeypatch, g, 'full', exact)
+    spin, pos3d = pipe.predict_with_table(images, fps, table_px)
+    dev = check_spin_pos(spin.cpu().numpy(), pos3d, g, 'full', REL_3D[exact])
+    print('[e2e full, %s] hub predict_with_table: pos3d %.2e, |spin| %.2e, spin_z %.2e, spin_xy %.2e rel' % ('exact windows' if exact else 'production', *dev))
+    spin, pos3d = pipe.predict(images, fps)
+    kp = pipe.table_detector.predict_keypoints(images)
+    d_table = np.abs(kp[..., :2] - g['full/table_keypoints'][..., :2]).max() / scale
+    dev = check_spin_pos(spin.cpu().numpy(), pos3d, g, 'full', REL_3D[False])
+    print('[e2e full, %s] hub predict: table xy %.2e network px; pos3d %.2e, |spin| %.2e, spin_z %.2e, spin_xy %.2e rel' % ('exact windows' if exact else 'production', d_table, *dev))
+    assert d_table <= XY_NET_PX[False] and n == len(images)

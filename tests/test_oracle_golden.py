@@ -125,3 +125,34 @@ def test_table_hrnet_oracle_matches_reference(golden, name):
     assert heat.shape == (b, 13, h, w)
     assert np.abs(heat - g[name + '/heat']).max() <= 1e-5 * np.abs(g[name + '/heat']).max()
     assert [(k, tuple(s)) for k, s in arch.wasb_schema(in_ch=3, head_out=13)][0] == ('model.conv1.weight', (64, 3, 3, 3))
+
+
+from e2e_common import e2e_case, check_spin_pos
+
+
+def test_e2e_oracle_matches_reference_chain(golden):
+    """The chained oracle (oracle/e2e_ref.py) against the reference's own modules chained as interface.py chains them
+    (tests/golden/e2e.npz, tools/make_goldens.py gen_e2e): 51 frames of 96x160 through both detectors, both filters, the uplift
+    transformer and the spin frame change.  Indices and filter decisions exact, coordinates to 1e-5 px (the oracle's heatmaps differ from the reference's in the last fp32 bits and the L-BFGS-B fit amplifies that), 3-D outputs to 1e-5 rel."""
+    from oracle import e2e_ref
+    g = golden('e2e.npz')
+    frames, fps, sd_ball, sd_table, sd_up, res = e2e_case(g, 'small')
+    spin, pos3d, it = e2e_ref.full_pipeline(frames, fps, sd_ball, sd_table, sd_up, res)
+    assert np.array_equal(it['ball_argmax'], g['small/ball_argmax'])
+    assert np.array_equal(it['table_argmax'], g['small/table_argmax'])
+    np.testing.assert_allclose(it['ball_positions'], g['small/ball_positions'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(it['table_keypoints'], g['small/table_keypoints'], rtol=0, atol=1e-5)
+    assert np.array_equal(it['valid_idx'], g['small/valid_idx'])
+    np.testing.assert_allclose(it['filtered_table'], g['small/filtered_table'], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(it['u_mask'], g['small/u_mask'])
+    np.testing.assert_allclose(it['u_ball'], g['small/u_ball'], rtol=0, atol=1e-7)
+    # 3-D outputs: positions / global rotation to 1e-5 rel; the local spin's x / y only to the conditioning of the frame change
+    # (check_spin_pos: a 3e-6 px difference in the detections moves spin_x by 2.5e-4 here -- with the reference's own modules)
+    dev = check_spin_pos(spin, pos3d, g, 'small', 1e-5)
+    np.testing.assert_allclose(it['rot'], g['small/rot'], rtol=1e-5, atol=1e-6)
+    print('e2e oracle vs reference chain: pos %.2e |spin| %.2e spin_z %.2e spin_xy %.2e rel' % dev)
+    # second half of the chain alone on the full-size fixture's detections (its CNN half runs on the GPU box: tests/test_e2e_gpu.py)
+    spin, pos3d, it = e2e_ref.uplift_from_detections(g['full/ball_positions'], g['full/filtered_table'], float(g['full/fps']),
+                                                     weights.random_uplift_state_dict(int(g['full/meta'][5]), 'large'))
+    np.testing.assert_allclose(spin, g['full/spin'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pos3d, g['full/pos3d'], rtol=1e-5, atol=1e-6)

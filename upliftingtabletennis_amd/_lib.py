@@ -28,6 +28,8 @@ SIGNATURES = {
     'ttup_wasb_time_graph': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _c.POINTER(_i), _vp]),
     'ttup_wasb_set_certify': (_i, [_vp, _c.c_float, _i, _i]),
     'ttup_wasb_certify_budget': (_i, [_vp, _i]),
+    'ttup_wasb_certify_exact_windows': (_i, [_vp, _i]),
+    'ttup_wasb_certify_info': (_i, [_vp, _vp, _vp]),
     'ttup_wasb_certify_status': (_i, [_vp, _i, _vp, _vp]),
     'ttup_wasb_certify_stats': (_i, [_vp, _vp, _i]),
     'ttup_wasb_set_priority': (_i, [_vp, _i]),

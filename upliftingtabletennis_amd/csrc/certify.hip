@@ -32,7 +32,8 @@ __device__ __forceinline__ bool better(float v, long long i, float bv, long long
 
 // ---- 1. candidates of each heatmap of a micro-batch: heat (n_maps, hw) fp32, argmax (n_maps)
 __global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict__ heat, const long long* __restrict__ argmax, long long hw,
-                                                        float two_eps, int K, int* __restrict__ cand_idx, int* __restrict__ cand_cnt) {
+                                                        float two_eps, int K, int* __restrict__ cand_idx, int* __restrict__ cand_cnt,
+                                                        float* __restrict__ cand_bf) {
     const int map = blockIdx.y;
     const float* h = heat + (size_t)map * hw;
     const float hmax = h[argmax[map]];
@@ -47,14 +48,14 @@ __global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict_
         for (int k = 0; k < 4; ++k)
             if (e[k] >= thr) {
                 const int slot = atomicAdd(&cand_cnt[map], 1);
-                if (slot < K) cand_idx[(size_t)map * K + slot] = (int)(q * 4 + k);
+                if (slot < K) { cand_idx[(size_t)map * K + slot] = (int)(q * 4 + k); cand_bf[(size_t)map * K + slot] = e[k]; }
             }
     }
 }
 
 struct PlanArgs {
-    int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats;
-    int K, maxc, max_crops, H, W, Hc, Wc, R, map0;
+    int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats; float* cand_bf;
+    int K, maxc, max_crops, H, W, Hc, Wc, R, map0, exact;
 };
 
 // valid core of a crop along one axis: positions whose value AND 3x3 neighbourhood are exact
@@ -69,14 +70,18 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     const int map = a.map0 + blockIdx.x;
     const int cnt = a.cand_cnt[map];
     atomicAdd(&a.stats[0], 1ull);
-    if (cnt <= 1) { a.status[map] = 0; atomicAdd(&a.stats[1], 1ull); return; }
+    // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
+    if (cnt <= 0 || (cnt == 1 && !a.exact)) { a.status[map] = 0; atomicAdd(&a.stats[1], 1ull); return; }
     if (cnt > a.K) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+    if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
     int* ci = a.cand_idx + (size_t)map * a.K;
+    float* cb = a.cand_bf + (size_t)map * a.K;
     for (int i = 1; i < cnt; ++i) {             // insertion sort (the scan appends in arbitrary order)
         const int v = ci[i];
+        const float vb = cb[i];
         int j = i - 1;
-        while (j >= 0 && ci[j] > v) { ci[j + 1] = ci[j]; --j; }
-        ci[j + 1] = v;
+        while (j >= 0 && ci[j] > v) { ci[j + 1] = ci[j]; cb[j + 1] = cb[j]; --j; }
+        ci[j + 1] = v; cb[j + 1] = vb;
     }
     int my_crop[8], my_y0[8], my_x0[8], n_my = 0;
     for (int k = 0; k < cnt; ++k) {
@@ -136,7 +141,8 @@ __global__ void cert_gather_kernel(const float* __restrict__ x, int in_ch, int H
 // ---- 4a. fp32 value and 3x3 window of every candidate whose crop is in this chunk
 __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ cand_crop,
                                    const int* __restrict__ status, const int* __restrict__ crop_rec, const float* __restrict__ crop_heat,
-                                   int K, int H, int W, int Hc, int Wc, int crop0, int CH, int n_maps, float* __restrict__ cand_val, float* __restrict__ cand_win) {
+                                   int K, int H, int W, int Hc, int Wc, int crop0, int CH, int n_maps, float* __restrict__ cand_val, float* __restrict__ cand_win,
+                                   const float* __restrict__ cand_bf, unsigned long long* __restrict__ stats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_maps * K) return;
     const int map = i / K, k = i % K;
@@ -146,7 +152,12 @@ __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* 
     const int* rec = crop_rec + 4 * id;
     const int gy = cand_idx[i] / W, gx = cand_idx[i] % W;
     const float* h = crop_heat + (size_t)(id - crop0) * Hc * Wc;
-    cand_val[i] = h[(size_t)(gy - rec[1]) * Wc + (gx - rec[2])];
+    const float vf = h[(size_t)(gy - rec[1]) * Wc + (gx - rec[2])];
+    cand_val[i] = vf;
+    // audit of the error bound: |bf16 - fp32| at every candidate comes for free here; the running maximum sits in stats[6] (the
+    // bits of a non-negative float order like the unsigned integer they spell)
+    const float err = fabsf(cand_bf[i] - vf);
+    if (err == err) atomicMax(&stats[6], (unsigned long long)__float_as_uint(err));
     for (int t = 0; t < 9; ++t) {
         const int y = gy + t / 3 - 1, x = gx + t % 3 - 1;
         float v = 0.f;                        // zero padding outside the IMAGE (helper_balldetection.py:55-64)
@@ -180,7 +191,7 @@ void cert_free(ttup_wasb* net) {
     CertState& c = net->cert;
     if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
     for (auto& sl : c.slot) {
-        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.crop_rec, sl.n_crops, sl.n_active, sl.status};
+        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (sl.done) (void)hipEventDestroy(sl.done);
         sl = CertState::Slot();
@@ -211,12 +222,12 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     int nblk = (int)(hw / 4 / 256 / 8);           // 8 float4 per thread
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
-                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0);
+                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0, sl.cand_bf + (size_t)b0 * c.K);
     TTUP_LAUNCH_CHECK();
     PlanArgs a;
     a.cand_idx = sl.cand_idx; a.cand_cnt = sl.cand_cnt; a.cand_crop = sl.cand_crop; a.crop_rec = sl.crop_rec; a.n_crops = sl.n_crops;
-    a.status = sl.status; a.stats = c.stats; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
-    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0;
+    a.status = sl.status; a.stats = c.stats; a.cand_bf = sl.cand_bf; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
+    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0; a.exact = c.exact_windows ? 1 : 0;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -259,7 +270,7 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
         const int nthr = batch * c.K;
         hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.cand_crop,
                            (const int*)sl.status, (const int*)sl.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch,
-                           sl.cand_val, sl.cand_win);
+                           sl.cand_val, sl.cand_win, (const float*)sl.cand_bf, c.stats);
         TTUP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.status,
@@ -292,18 +303,22 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 24, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 24);
     c.Hc = side < net->H ? side : net->H;
     c.Wc = side < net->W ? side : net->W;
+    // the scan reads float4 quads of whole heatmaps; a crop is exact only when its (clamped) origin is a multiple of 8
+    TTUP_REQUIRE(((long long)net->H * net->W) % 4 == 0 && (net->H - c.Hc) % 8 == 0 && (net->W - c.Wc) % 8 == 0, TTUP_EINVAL,
+                 "ttup_wasb_set_certify: %dx%d heatmaps with %dx%d crops cannot be certified (H*W %% 4, (H-Hc) %% 8, (W-Wc) %% 8 must be 0)", net->H, net->W, c.Hc, c.Wc);
     c.CH = net->max_batch < 64 ? net->max_batch : 64;
-    c.max_crops = net->max_batch > c.CH ? net->max_batch : c.CH;           // one crop per heatmap on average; the overflow is flagged
+    c.max_crops = 2 * net->max_batch > c.CH ? 2 * net->max_batch : c.CH;   // two crops per heatmap on average (exact-window mode: one each + the near-ties); the overflow is flagged
     c.nchunks = cdiv(c.max_crops, c.CH);
     TTUP_REQUIRE(c.nchunks <= 64, TTUP_EINVAL, "ttup_wasb_set_certify: max_batch %d too large", net->max_batch);
     c.max_crops = c.nchunks * c.CH;
-    c.budget = c.max_crops;
+    c.budget = net->max_batch < c.max_crops ? (net->max_batch > c.CH ? net->max_batch : c.CH) : c.max_crops;      // default: one crop per heatmap
     const size_t nb = (size_t)net->max_batch;
     for (auto& sl : c.slot) {
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_idx, nb * c.K * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_cnt, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_crop, nb * c.K * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_val, nb * c.K * sizeof(float)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_bf, nb * c.K * sizeof(float)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_win, nb * c.K * 9 * sizeof(float)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_crops, sizeof(int)));
@@ -327,6 +342,20 @@ extern "C" int ttup_wasb_certify_budget(ttup_wasb* net, int max_crops) {
     TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_budget: the certified argmax is not enabled on this handle");
     TTUP_REQUIRE(max_crops >= 1, TTUP_EINVAL, "ttup_wasb_certify_budget: budget must be positive");
     net->cert.budget = max_crops < net->cert.max_crops ? max_crops : net->cert.max_crops;
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on) {
+    TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_exact_windows: the certified argmax is not enabled on this handle");
+    net->cert.exact_windows = on != 0;
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream) {
+    TTUP_REQUIRE(net && info_dev, TTUP_EINVAL, "ttup_wasb_certify_info: null pointer");
+    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_info: the certified argmax is not enabled on this handle");
+    TTUP_HIP_CHECK(hipMemcpyAsync(info_dev, net->cert.slot[net->cert.cur].n_crops, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    TTUP_HIP_CHECK(hipMemcpyAsync(info_dev + 1, net->cert.stats + 6, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));      // low word (little endian)
     return TTUP_OK;
 }
 

@@ -44,11 +44,13 @@ struct CertState {
     int maxc = 4;                        // crops per heatmap
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
+    bool exact_windows = false;          // every heatmap gets an fp32 crop (also single-candidate ones): all 3x3 windows are fp32 values
     struct ::ttup_wasb* cropnet = nullptr;  // fp32 handle at crop size, batch CH
     // Per-call state, two slots used alternately: the fp32 passes of call k run on the handle's own stream (`stream`) while the
     // bf16 micro-batches of call k+1 -- issued on another caller stream -- already fill slot (k+1)&1
     struct Slot {
         int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
+        float* cand_bf = nullptr;           // the bf16 path's value of every candidate (audit: |bf16 - fp32| at the candidates is free)
         int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
         hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
     } slot[2];
@@ -89,6 +91,10 @@ struct ttup_wasb {
     };
     std::vector<Lane> lanes;
     hipEvent_t fork = nullptr;
+    // bf16 / fp32 micro-batches of consecutive forward calls share the lanes' activation and scratch buffers: a call waits for the
+    // previous call's last micro-batch (whatever stream that call was issued on) before it touches them
+    hipEvent_t pass_done = nullptr;
+    bool pass_recorded = false;
 
     void use_lane(int l) {
         const Lane& L = lanes[l];

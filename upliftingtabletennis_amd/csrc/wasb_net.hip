@@ -42,6 +42,7 @@ ttup_wasb::~ttup_wasb() {
         if (L.done) (void)hipEventDestroy(L.done);
     }
     if (fork) (void)hipEventDestroy(fork);
+    if (pass_done) (void)hipEventDestroy(pass_done);
     if (head_w_dev) (void)hipFree(head_w_dev);
     if (head_b_dev) (void)hipFree(head_b_dev);
 }
@@ -536,23 +537,30 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
     const int n_lanes = n_micro < (int)net->lanes.size() ? (n_micro > 0 ? n_micro : 1) : (int)net->lanes.size();
     const hipStream_t caller = st;
     const bool certify = net->cert.enabled && net->fused_head && argmax_dev && win_dev && batch > 0;
+    // Consecutive calls may come in on different caller streams (StreamWorker.submit alternates two) while the activations, the
+    // heatmap scratch and the argmax workspace of a lane belong to ONE micro-batch at a time.  Handles with lane streams run every
+    // micro-batch on its lane's stream -- also when the call has a single micro-batch -- so stream order serialises the lane's
+    // buffers.  Single-lane handles (max_batch <= micro-batch, TTUP_LANES=1) run on the caller's stream: a call then waits for the
+    // previous call's last micro-batch, whatever stream that call was issued on.
+    const bool lane_streams = net->lanes[0].stream != nullptr;
+    if (!lane_streams && net->pass_recorded) TTUP_HIP_CHECK(hipStreamWaitEvent(caller, net->pass_done, 0));
     if (certify) { const int rc = cert_begin(net, batch, caller); if (rc) return rc; }
-    if (n_lanes > 1) {
+    if (lane_streams) {
         TTUP_HIP_CHECK(hipEventRecord(net->fork, caller));
         for (int l = 0; l < n_lanes; ++l) TTUP_HIP_CHECK(hipStreamWaitEvent(net->lanes[l].stream, net->fork, 0));
     }
     int rc_all = TTUP_OK, last_lane = 0;
     for (int b0 = 0, i = 0; b0 < batch && rc_all == TTUP_OK; b0 += net->micro, ++i) {
         rc_all = forward_micro(net, x_dev, frames_dev, n_frames, src_h, src_w, batch, b0, heat_dev, argmax_dev, win_dev,
-                               n_lanes > 1 ? i % n_lanes : 0, n_lanes > 1 ? net->lanes[i % n_lanes].stream : caller);
-        last_lane = n_lanes > 1 ? i % n_lanes : 0;
+                               i % n_lanes, lane_streams ? net->lanes[i % n_lanes].stream : caller);
+        last_lane = i % n_lanes;
     }
-    if (n_lanes > 1) {       // join even after an error so the caller's stream never runs ahead of enqueued work
+    if (lane_streams) {       // join even after an error so the caller's stream never runs ahead of enqueued work
         for (int l = 0; l < n_lanes; ++l) {
             (void)hipEventRecord(net->lanes[l].done, net->lanes[l].stream);
             (void)hipStreamWaitEvent(caller, net->lanes[l].done, 0);
         }
-    }
+    } else if (hipEventRecord(net->pass_done, caller) == hipSuccess) net->pass_recorded = true;
     net->use_lane(last_lane);
     if (rc_all) return rc_all;
     net->last_batch = batch < net->micro ? batch : net->micro;
@@ -633,6 +641,7 @@ int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, i
             }
         }
         if (n_lanes > 1) TTUP_HIP_CHECK(hipEventCreateWithFlags(&net->fork, hipEventDisableTiming));
+        TTUP_HIP_CHECK(hipEventCreateWithFlags(&net->pass_done, hipEventDisableTiming));
         net->use_lane(0);
     }
     TTUP_HIP_CHECK(hipDeviceSynchronize());

@@ -85,11 +85,14 @@ class BallDetector:
         self.model_resolution = res
         self.max_batch = max_batch
 
+    AUDIT_EVERY = 256          # triples per audited triple (see _audit_picks)
+
     def predict(self, images):
         """images: list (length B) of [prev, curr, next] BGR uint8 HWC arrays.
         Returns (pred_pos (B,3) float64 [x, y, confidence] in 1920x1080 px, preds (B,1,H,W) float32)."""
         pred_pos, preds = [], []
         w, h = self.model_resolution
+        m = self.model
         for b0 in range(0, len(images), self.max_batch):
             chunk = images[b0:b0 + self.max_batch]
             xs = []
@@ -98,10 +101,22 @@ class BallDetector:
                 xs.append(wasb.preprocess_triples(fr, (w, h)))
             x = torch.cat(xs)
             self._calibrate(x=x)
-            # peaks from the certified argmax (the fp32 index the reference's torch.argmax returns), table-variant fit (interface.py:116)
-            heat, idx, win = self.model.forward(x, want_heatmap=True, want_peaks=True)
-            if self.model.certified:
-                self.model.fix_uncertified(idx, win, x=x)
+            picks = self._audit_picks(x.shape[0])
+            while True:
+                # peaks from the certified argmax (the fp32 index the reference's torch.argmax returns), table-variant fit (interface.py:116)
+                heat, idx, win = m.forward(x, want_heatmap=True, want_peaks=True)
+                if not m.certified:
+                    break
+                status, info = m.certify_status(x.shape[0]), m.certify_info()
+                err = m.note_error(m.decode_info(info.cpu().numpy())[1])
+                for t in picks:        # eps audit: the bf16 heatmap of a random triple against the fp32 twin
+                    err = max(err, m.note_error(float((heat[t] - m._twin().forward(x[t:t + 1])[0][0]).abs().max().item()), 1))
+                picks = []
+                if m.eps_violated(err):
+                    m.widen_eps(err)
+                    continue
+                m.fix_uncertified(idx, win, x=x, status=status)
+                break
             pos = refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
             pred_pos.append(pos.cpu().numpy())
             preds.append(heat.cpu().numpy())
@@ -110,17 +125,55 @@ class BallDetector:
         return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
     def _calibrate(self, frames=None, x=None):
-        """Certified argmax (csrc/certify.hip): the bf16 path's error bound is measured once, on the first input this detector
-        sees, against the fp32 path; from then on every returned index is the fp32 argmax."""
-        if self.model.certified or self.model.dtype != 'bf16' or os.environ.get('TTUP_NO_CERTIFY') == '1':
+        """Certified argmax (csrc/certify.hip): a first estimate of the bf16 path's error bound eps is measured on the first input
+        this detector sees, against the fp32 path; the audits (`_audit_picks`, the crops' candidate errors) keep checking it on later
+        inputs and widen it when one comes within the safety factor.  Every returned index is the fp32 argmax as long as eps bounds
+        the frame's error."""
+        m = self.model
+        if m.certified or m.dtype != 'bf16' or os.environ.get('TTUP_NO_CERTIFY') == '1':
             return
+        exact = os.environ.get('TTUP_EXACT_WINDOWS') == '1'
         if frames is None:
-            hb, _ = self.model.forward(x[:2])
-            twin = self.model._twin()
-            err = max(float((hb[k] - twin.forward(x[k:k + 1])[0][0]).abs().max().item()) for k in range(hb.shape[0]))
-            self.model.set_certify(1.5 * err)
+            n = min(2, x.shape[0])
+            hb, _ = m.forward(x[:n])
+            twin = m._twin()
+            err = max(float((hb[k] - twin.forward(x[k:k + 1])[0][0]).abs().max().item()) for k in range(n))
+            m.set_certify(m.SAFETY * err, exact_windows=exact)
+            m.audit_state = dict(audited_frames=n, max_err_seen=err, widened=0)
         else:
-            self.model.calibrate(frames, n=2)
+            m.calibrate(frames, n=2, exact_windows=exact)
+
+    def _audit_picks(self, n_triples):
+        """One random triple per AUDIT_EVERY triples this detector has processed is re-run on the fp32 twin (eps audit)."""
+        if not self.model.certified or n_triples <= 0 or os.environ.get('TTUP_NO_AUDIT') == '1':
+            return []
+        rng = self.__dict__.setdefault('_audit_rng', np.random.default_rng(0))
+        self._since_audit = self.__dict__.get('_since_audit', 0) + n_triples
+        picks = []
+        while self._since_audit >= self.AUDIT_EVERY:
+            self._since_audit -= self.AUDIT_EVERY
+            picks.append(int(rng.integers(n_triples)))
+        return picks
+
+    def _certified_peaks(self, fr):
+        """(idx, win) of the triples of the uint8 device clip `fr` (one forward call), certified under an audited eps."""
+        m = self.model
+        picks = self._audit_picks(fr.shape[0] - 2)
+        while True:
+            audit = m.audit_async(fr, picks) if picks else None
+            _, idx, win = m.forward_frames(fr, want_heatmap=False)
+            if not m.certified:
+                return idx, win
+            status, info = m.certify_status(idx.shape[0]), m.certify_info()
+            err = m.note_error(m.decode_info(info.cpu().numpy())[1])
+            if audit is not None:
+                err = max(err, m.audit_result(audit))
+            picks = []
+            if m.eps_violated(err):
+                m.widen_eps(err)
+                continue
+            m.fix_uncertified(idx, win, frames_u8=fr, status=status)
+            return idx, win
 
     def predict_clip(self, images):
         """Fast path for consecutive frames (what TableTennisPipeline.predict feeds the detector, interface.py:276-279):
@@ -136,9 +189,7 @@ class BallDetector:
         for t0 in range(0, n - 2, step):
             fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[t0:t0 + step + 2]])).to(self.device)
             self._calibrate(frames=fr)
-            _, idx, win = self.model.forward_frames(fr, want_heatmap=False)
-            if self.model.certified:
-                self.model.fix_uncertified(idx, win, frames_u8=fr)
+            idx, win = self._certified_peaks(fr)
             out.append(refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE).cpu().numpy())
         return np.concatenate(out, axis=0)
 
@@ -306,8 +357,10 @@ class TableTennisPipeline:
                     st['ball'].wait_event(uploaded[(t_next + nt + 1) // C])
                     fr = frames[t_next:t_next + nt + 2]
                     _, idx, win = bd.model.forward_frames(fr, want_heatmap=False)
+                    # status / info of THIS call, copied right behind it (the handle's per-call slot flips with the next call)
                     status = bd.model.certify_status(nt) if bd.model.certified else None
-                    ball_calls.append((t_next, nt, idx, win, status))
+                    info = bd.model.certify_info() if bd.model.certified else None
+                    ball_calls.append((t_next, nt, idx, win, status, info, bd.model.eps if bd.model.certified else None))
                 t_next += nt
 
         for ci, c0 in enumerate(range(0, n, C)):
@@ -332,6 +385,12 @@ class TableTennisPipeline:
                     table_out.append(refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE))
             submit_ball(c1, final=(c1 == n))
         frames.record_stream(st['ball']); frames.record_stream(st['table'])
+        # eps audit of the certified argmax: a random triple of the clip on the fp32 twin, on its own stream next to the detectors
+        audit = None
+        picks = bd._audit_picks(n - 2)
+        if picks:
+            cur.wait_event(uploaded[-1])
+            audit = bd.model.audit_async(frames, picks)
         kp = None
         if want_table:
             # the table detector (high-priority streams) finishes first: its keypoints come back and the host-side DBSCAN filter
@@ -345,12 +404,20 @@ class TableTennisPipeline:
             kp = table_consumer(kp_host.numpy()) if table_consumer is not None else kp_host.numpy().copy()
         for s in st.values():
             cur.wait_stream(s)
-        for (t0, nt, idx, win, status) in ball_calls:
-            if status is not None and (status.cpu().numpy() == 2).any():
-                # rare: crop budget exceeded -> those frames on the full-frame fp32 path (the status belongs to the handle's LAST call,
-                # so re-run this call first)
-                _, idx, win = bd.model.forward_frames(frames[t0:t0 + nt + 2], want_heatmap=False)
-                bd.model.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2])
+        m = bd.model
+        if m.certified and ball_calls:
+            err = m.note_error(max(m.decode_info(c[5].cpu().numpy())[1] for c in ball_calls))
+            if audit is not None:
+                err = max(err, m.audit_result(audit))
+            if m.eps_violated(err):
+                m.widen_eps(err)
+        for (t0, nt, idx, win, status, info, eps_used) in ball_calls:
+            if status is not None and eps_used < m.eps:
+                # rare: an audit found eps too small -> this call again under the widened eps (audited, blocking)
+                idx, win = bd._certified_peaks(frames[t0:t0 + nt + 2])
+            elif status is not None and (status.cpu().numpy() == 2).any():
+                # rare: crop budget exceeded -> those frames on the full-frame fp32 path (with the call's own status)
+                m.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2], status=status)
             ball_out.append(refine.refine_windows_device(idx, win, bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
         pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
         return pos, kp

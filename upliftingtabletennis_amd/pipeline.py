@@ -30,77 +30,179 @@ def frame_range_with_halo(n_frames, world, rank):
     return t0, t1 + 2, t0, t1 - t0
 
 
-def gather_records(records, dist=None, dst=0):
-    """Gather a dict of same-dtype-per-key tensors (first dim may differ per rank) on rank `dst`.
-    Returns {key: [tensor_of_rank0, tensor_of_rank1, ...]} on dst, None elsewhere.  With dist=None (single
-    process) it just wraps the local records.  Works with the nccl (=RCCL) and gloo backends."""
+def _pack_records(records, spec, device):
+    """One byte buffer per rank: int64 row counts of every key (sorted), then each key's rows in a region of fixed capacity."""
+    keys = sorted(spec)
+    cap = {k: int(spec[k][0]) * int(np.prod(spec[k][1], dtype=np.int64)) * torch.empty((), dtype=spec[k][2]).element_size() for k in keys}
+    total = 8 * len(keys) + sum(cap.values())
+    buf = torch.zeros((total,), dtype=torch.uint8, device=device)
+    rows = []
+    off = 8 * len(keys)
+    for k in keys:
+        v = records[k].contiguous()
+        if v.dtype != spec[k][2] or tuple(v.shape[1:]) != tuple(spec[k][1]) or v.shape[0] > spec[k][0]:
+            raise ValueError('record %r %s/%s does not fit its spec %s' % (k, tuple(v.shape), v.dtype, spec[k]))
+        rows.append(v.shape[0])
+        nb = v.numel() * v.element_size()
+        if nb:
+            buf[off:off + nb] = v.to(device).reshape(-1).view(torch.uint8)
+        off += cap[k]
+    buf[:8 * len(keys)] = torch.tensor(rows, dtype=torch.int64).view(torch.uint8).to(device)
+    return buf, keys, cap
+
+
+def _unpack_records(flat, world, keys, cap, spec):
+    total = flat.numel() // world
+    out = {k: [] for k in keys}
+    for r in range(world):
+        b = flat[r * total:(r + 1) * total]
+        rows = b[:8 * len(keys)].clone().view(torch.int64).tolist()
+        off = 8 * len(keys)
+        for k, n in zip(keys, rows):
+            shape, dt = tuple(spec[k][1]), spec[k][2]
+            nb = n * int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+            out[k].append(b[off:off + nb].clone().view(dt).reshape((n,) + shape))
+            off += cap[k]
+    return out
+
+
+def gather_records(records, dist=None, dst=0, spec=None):
+    """The one exchange of the path: gather a dict of per-rank records -- tensors whose first dimension may differ per
+    rank -- on rank `dst`.  Returns {key: [tensor_of_rank0, tensor_of_rank1, ...]} on dst, None elsewhere; with dist=None (single
+    process) it just wraps the local records.
+
+    `spec` = {key: (max_rows, row_shape, dtype)} (StreamWorker.record_spec()) fixes every key's capacity, so a step is exactly ONE
+    collective: all ranks contribute one equally sized byte buffer (row counts + rows) to an all_gather.  Without a spec the
+    capacities are agreed first (one extra all_reduce of the row counts): two collectives.  nccl (= RCCL) gathers device buffers,
+    gloo (CPU tests, single-GPU dry runs) host buffers."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return {k: [v] for k, v in records.items()}
     world, rank = dist.get_world_size(), dist.get_rank()
-    out = {} if rank == dst else None
-    on_host = dist.get_backend() == 'gloo'        # gloo (CPU tests, single-GPU dry runs) gathers on the host; nccl = RCCL on device
-    for k in sorted(records):
-        v = records[k].contiguous()
-        if on_host:
-            v = v.cpu()
-        n = torch.tensor([v.shape[0]], dtype=torch.int64, device=v.device)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes + [1])
-        pad = torch.zeros((mx,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        pad[:v.shape[0]] = v
-        # all_gather (every backend implements it on device tensors; the records are a few KB) and keep the result on `dst` only
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-        if rank == dst:
-            out[k] = [b[:s] for b, s in zip(bufs, sizes)]
-    return out
+    on_host = dist.get_backend() == 'gloo'
+    any_v = next(iter(records.values()))
+    device = torch.device('cpu') if on_host else any_v.device
+    if spec is None:
+        keys = sorted(records)
+        rows = torch.tensor([records[k].shape[0] for k in keys], dtype=torch.int64, device=device)
+        dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+        spec = {k: (max(int(n), 1), tuple(records[k].shape[1:]), records[k].dtype) for k, n in zip(keys, rows.tolist())}
+    buf, keys, cap = _pack_records(records, spec, device)
+    flat = torch.empty((world * buf.numel(),), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(flat, buf)
+    if rank != dst:
+        return None
+    return _unpack_records(flat.cpu(), world, keys, cap, spec)
 
 
 class StreamWorker:
     """Per-GPU worker: owns one CNN handle, one uplift handle, and runs whole clips through the path.
-    Raises RuntimeError without a HIP device (no CPU fallback)."""
+    Raises RuntimeError without a HIP device (no CPU fallback).
+
+    Certified argmax (`certify=True`, bf16): eps -- the bound on |bf16 heatmap - fp32 heatmap| the certification rests on -- is
+    estimated on the first clip and then AUDITED while the worker runs: one random triple per `audit_every` triples is re-run on
+    the fp32 twin on a side stream, and every fp32 crop the certification computes anyway reports the error at its candidates.
+    When an observed error comes within the safety factor (1.5) of eps, eps is widened and the clips certified under the old value
+    are re-run.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
-                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True):
+                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False):
         from . import glue, refine, uplift, wasb, _lib
         _lib.require_gpu()
         self._glue, self._refine, self._uplift, self._lib = glue, refine, uplift, _lib
         self.device = torch.device(device)
         self.net_w, self.net_h = net_wh
         self.traj_len, self.seq_len = traj_len, seq_len
+        self.max_triples = max_triples
         self.net = wasb.WASBNet(wasb_state_dict, resolution=net_wh, max_batch=max_triples, dtype=dtype, device=self.device)
+        self.max_segments = max(64, (max_triples + traj_len - 1) // traj_len)
         self.up = uplift.get_model('connectstage', uplift_size, 'dynamic', 'new', state_dict=uplift_state_dict,
-                                   max_batch=max(64, (max_triples + traj_len - 1) // traj_len), max_len=seq_len, device=self.device)
-        # certified argmax (bit-exact fp32 indices from the bf16 path, csrc/certify.hip): calibrated on the first clip seen
+                                   max_batch=self.max_segments, max_len=seq_len, device=self.device)
+        # certified argmax (the fp32 path's indices from the bf16 path, csrc/certify.hip): calibrated on the first clip seen
         self.certify = bool(certify) and dtype == 'bf16'
+        self.exact_windows = bool(exact_windows)
         self.certify_eps = None
         self.fp32_reruns = 0
+        self.recertified_clips = 0
+        self.audit_every = int(audit_every)
+        self._since_audit = 0
+        self._rng = np.random.default_rng(audit_seed)
+
+    def record_spec(self):
+        """Capacities of the per-clip records (`gather_records(..., spec=...)`: one collective per step)."""
+        return {'xyv': (self.max_triples, (3,), torch.float64), 'spin': (self.max_segments, (3,), torch.float32),
+                'pos3d': (self.max_segments, (self.seq_len, 3), torch.float32), 'n_valid': (self.max_segments, (), torch.int64)}
+
+    @property
+    def audit(self):
+        """{'audited_frames', 'max_err_seen', 'widened', 'eps', 'max_err_over_eps', 'recertified_clips'} of the certified argmax."""
+        a = dict(getattr(self.net, 'audit_state', None) or dict(audited_frames=0, max_err_seen=0.0, widened=0))
+        a['eps'] = self.certify_eps
+        a['max_err_over_eps'] = (a['max_err_seen'] / self.certify_eps) if self.certify_eps else None
+        a['recertified_clips'] = self.recertified_clips
+        return a
 
     def detect(self, frames_u8):
         """(N,h,w,3) uint8 on the device -> (N-2,3) float64 [x, y, visibility] in 1920x1080 px (table-variant refine,
         like interface.py:116)."""
         return self._detect(frames_u8)[0]
 
-    def _detect(self, frames_u8):
+    def _calibrated(self, frames_u8):
         if self.certify and self.certify_eps is None:
-            self.certify_eps = self.net.calibrate(frames_u8, n=4)
+            self.certify_eps = self.net.calibrate(frames_u8, n=4, exact_windows=self.exact_windows)
+        return self.certify_eps
+
+    def _start_audit(self, frames_u8):
+        """Enqueue the side-stream audit of this clip (if one is due) next to its detector pass; None otherwise."""
+        picks = self._pick_audits(frames_u8.shape[0] - 2)
+        return self.net.audit_async(frames_u8, picks) if picks else None
+
+    def _detect(self, frames_u8):
+        self._calibrated(frames_u8)
         _, idx, win = self.net.forward_frames(frames_u8, want_heatmap=False)
         xyv = self._refine.refine_windows_device(idx, win, self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
+        # status and info belong to THIS call: both are copied right behind it in stream order, before another call can flip the
+        # handle's per-call slot
         status = self.net.certify_status(idx.shape[0]) if self.certify else None
-        return xyv, idx, win, status
+        info = self.net.certify_info() if self.certify else None
+        return xyv, idx, win, status, info
+
+    def _pick_audits(self, n_triples):
+        """Indices of the triples of a clip that the side-stream audit re-runs on the fp32 twin: one per `audit_every` triples."""
+        if not self.certify or self.audit_every <= 0 or n_triples <= 0:
+            return []
+        self._since_audit += n_triples
+        picks = []
+        while self._since_audit >= self.audit_every:
+            self._since_audit -= self.audit_every
+            picks.append(int(self._rng.integers(n_triples)))
+        return picks
 
     def _repair(self, frames_u8, xyv, idx, win, status_host):
         """Rare slow path: heatmaps the certified argmax could not settle inside its crop budget are re-run on the full-frame
-        fp32 handle, so that every detection comes from the fp32 argmax."""
+        fp32 handle, so that every detection comes from the fp32 argmax.  `status_host` is the status of the call that produced
+        idx / win (not of whatever the handle ran last)."""
         bad = np.nonzero(status_host == 2)[0]
         if bad.size == 0:
             return xyv
-        self.fp32_reruns += self.net.fix_uncertified(idx, win, frames_u8=frames_u8)
+        self.fp32_reruns += self.net.fix_uncertified(idx, win, frames_u8=frames_u8, status=status_host)
         sel = torch.as_tensor(bad, device=self.device)
         xyv[sel] = self._refine.refine_windows_device(idx[sel], win[sel], self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
         return xyv
+
+    def _after_clip(self, n_crops, cand_err, audit_ticket):
+        """Fold a finished clip's evidence into the eps audit and size the crop budget of the clips to come.  Returns True when eps
+        had to be widened (clips certified under a smaller eps must be re-run)."""
+        net = self.net
+        err = net.note_error(cand_err)
+        if audit_ticket is not None:
+            err = max(err, net.audit_result(audit_ticket))
+        widened = False
+        if net.eps_violated(err):
+            self.certify_eps = net.widen_eps(err)
+            widened = True
+        # crop budget of the next clips: twice the crops this clip asked for (+ slack); clips that outgrow it are flagged and repaired
+        net.certify_budget(2 * n_crops + 16)
+        return widened
 
     def uplift_segments(self, positions, table_px, fps):
         """Cut the detections into rallies of `traj_len` frames, filter / normalise / pad each like the reference
@@ -117,10 +219,23 @@ class StreamWorker:
         spin = self._uplift.transform_rotationaxes(rot, p3)
         return spin, p3, mask.sum(1).to(torch.int64).to(self.device)
 
+    def _detect_blocking(self, frames_u8):
+        """One clip, start to finish, with the audit folded in: (xyv device tensor) whose every index is certified under the
+        current eps.  Loops only when an audit widens eps (then at most a couple of times: eps only grows)."""
+        while True:
+            eps_used = self._calibrated(frames_u8)
+            ticket = self._start_audit(frames_u8)
+            xyv, idx, win, status, info = self._detect(frames_u8)
+            if status is None:
+                return xyv
+            n_crops, cand_err = self.net.decode_info(info.cpu().numpy())
+            if self._after_clip(n_crops, cand_err, ticket) or eps_used < self.certify_eps:
+                self.recertified_clips += 1
+                continue
+            return self._repair(frames_u8, xyv, idx, win, status.cpu().numpy())
+
     def process_clip(self, frames_u8, table_px, fps):
-        xyv, idx, win, status = self._detect(frames_u8)
-        if status is not None:
-            xyv = self._repair(frames_u8, xyv, idx, win, status.cpu().numpy())
+        xyv = self._detect_blocking(frames_u8)
         spin, p3, nvalid = self.uplift_segments(xyv.cpu().numpy(), table_px, fps)
         return {'xyv': xyv, 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
 
@@ -140,38 +255,48 @@ class StreamWorker:
         with torch.cuda.stream(sub):
             return self._submit(frames_u8, sub)
 
+    def _pinned(self, key, like, i):
+        ring = self.__dict__.setdefault('_pinned_ring', {})          # two pinned buffers per (name, shape), used alternately
+        slot = ring.setdefault((key, tuple(like.shape)), [None, None])
+        if slot[i] is None:
+            slot[i] = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+        return slot[i]
+
     def _submit(self, frames_u8, sub):
-        xyv, idx, win, status = self._detect(frames_u8)
-        ring = self.__dict__.setdefault('_pinned', {})          # two pinned buffers per shape, used alternately
-        slot = ring.setdefault(tuple(xyv.shape), {'bufs': [None, None], 'next': 0})
-        i = slot['next']; slot['next'] = 1 - i
-        if slot['bufs'][i] is None:
-            slot['bufs'][i] = torch.empty(xyv.shape, dtype=xyv.dtype, pin_memory=True)
-        host = slot['bufs'][i]
+        eps_used = self._calibrated(frames_u8)
+        audit = self._start_audit(frames_u8)          # side stream: shares the GPU with this clip's detector pass
+        xyv, idx, win, status, info = self._detect(frames_u8)
+        i = self.__dict__.get('_pin_next', 0)
+        self._pin_next = 1 - i
+        host = self._pinned('xyv', xyv, i)
         host.copy_(xyv, non_blocking=True)
-        st_host = None
+        st_host = info_host = None
         if status is not None:
-            st_host = slot.setdefault('status', [None, None])
-            if st_host[i] is None:
-                st_host[i] = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
-            st_host = st_host[i]
+            st_host = self._pinned('status', status, i)
             st_host.copy_(status, non_blocking=True)
+            info_host = self._pinned('info', info, i)
+            info_host.copy_(info, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        for t in (xyv, idx, win, frames_u8) + ((status,) if status is not None else ()):
+        for t in (xyv, idx, win, frames_u8) + ((status, info) if status is not None else ()):
             t.record_stream(sub)
-        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host, 'stream': sub}
+        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host, 'info': info_host,
+                'stream': sub, 'audit': audit, 'eps': eps_used}
 
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
         torch.cuda.current_stream(self.device).wait_stream(ticket['stream'])
         if ticket.get('status') is not None:
-            # crop budget of the next clips: twice what this clip needed (+ slack); clips that outgrow it are flagged and repaired below
-            need = int((ticket['status'].numpy() == 1).sum())
-            self.net.certify_budget(2 * need + 16)
-        if ticket.get('status') is not None and (ticket['status'].numpy() == 2).any():
-            ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], ticket['status'].numpy())
-            ticket['host'].copy_(ticket['xyv'])
+            n_crops, cand_err = self.net.decode_info(ticket['info'].numpy())
+            widened = self._after_clip(n_crops, cand_err, ticket.get('audit'))
+            if widened or ticket['eps'] < self.certify_eps:
+                # this clip was certified under an eps that an audit has since found too small: run it again (blocking; rare)
+                self.recertified_clips += 1
+                ticket['xyv'] = self._detect_blocking(ticket['frames'])
+                ticket['host'].copy_(ticket['xyv'])
+            elif (ticket['status'].numpy() == 2).any():
+                ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], ticket['status'].numpy())
+                ticket['host'].copy_(ticket['xyv'])
         # the uplift (about a hundred small launches for a handful of trajectories) runs on a side stream, so it shares
         # the GPU with the detector of the clip submitted in the meantime instead of queueing behind it
         side = self.__dict__.get('_side')
@@ -187,3 +312,5 @@ class StreamWorker:
         for t in (spin, p3, nvalid):
             t.record_stream(cur)
         return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
+
+    RECORD_KEYS = ('xyv', 'spin', 'pos3d', 'n_valid')          # what a step hands to gather_records

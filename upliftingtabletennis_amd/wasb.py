@@ -30,7 +30,9 @@ class WASBNet:
         self._lib = _lib.load()
         self._state_dict = state_dict            # kept for the fp32 twin of the certified argmax (calibrate / fix_uncertified)
         self._f32_twin = None
+        self._bf16_twin = None
         self.certified = False
+        self.exact_windows = False
         blob = weights.pack_wasb_blob(state_dict, in_ch=self.IN_CH, head_out=self.HEAD_OUT)
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -99,13 +101,25 @@ class WASBNet:
         _lib.check(rc)
         return heat, idx, win
 
-    # ---- certified argmax (csrc/certify.hip): bit-exact fp32 argmax indices from the bf16 path
-    def set_certify(self, eps_abs, crop=0, max_crops_per_map=0):
-        """eps_abs bounds |bf16 heatmap - fp32 heatmap|; < 0 switches the certification off."""
+    # ---- certified argmax (csrc/certify.hip): the fp32 path's argmax indices from the bf16 path, GIVEN an error bound eps
+    # The guarantee is conditional: an index is the fp32 argmax whenever |bf16 heatmap - fp32 heatmap| <= eps on that frame.  eps is
+    # an empirical bound -- measured (`calibrate`), then audited for as long as the handle runs (`audit_async` / the candidate-level
+    # error the crops give for free, `certify_info`) and widened when an audit comes within the safety factor of it.
+    SAFETY = 1.5
+
+    def set_certify(self, eps_abs, crop=0, max_crops_per_map=0, exact_windows=None):
+        """eps_abs bounds |bf16 heatmap - fp32 heatmap|; < 0 switches the certification off.  exact_windows=True: every heatmap
+        (not only the near-ties) gets an fp32 crop, so every 3x3 window holds fp32 values (parity mode, one fp32 crop per frame)."""
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ttup_wasb_set_certify(self._handle, float(eps_abs), int(crop), int(max_crops_per_map)))
         self.certified = eps_abs >= 0
         self.eps = float(eps_abs)
+        if exact_windows is not None:
+            self.exact_windows = bool(exact_windows)
+        if self.certified:
+            _lib.check(self._lib.ttup_wasb_certify_exact_windows(self._handle, 1 if getattr(self, 'exact_windows', False) else 0))
+            if getattr(self, 'exact_windows', False):
+                self.certify_budget(2 * self.max_batch)
 
     def _twin(self):
         if self._f32_twin is None:
@@ -113,24 +127,76 @@ class WASBNet:
                 if type(self) is not WASBNet else WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='f32', device=self.device)
         return self._f32_twin
 
-    def calibrate(self, frames_u8, n=4, safety=1.5, crop=0, max_crops_per_map=0):
-        """Measure the bf16 path's heatmap error against the fp32 path on the first `n` triples of `frames_u8` (uint8 (N,h,w,3)
-        device tensor) and enable the certified argmax with eps = safety * max |error|.  Returns eps."""
+    def _audit_twin(self):
+        """A one-sample bf16 handle with the same weights: the audit re-computes the production path's heatmap of a frame on its own
+        buffers (the kernels are per-tile deterministic: same values as the batched handle, asserted in the tests), so it never
+        touches the production handle's lanes or its per-call certification state."""
+        if getattr(self, '_bf16_twin', None) is None:
+            self._bf16_twin = WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='bf16', device=self.device)
+        return self._bf16_twin
+
+    def heatmap_error(self, frames_u8, t):
+        """max |bf16 heatmap - fp32 heatmap| of triple t of the uint8 clip, on the current stream -> 0-dim device tensor."""
+        fr = frames_u8[t:t + 3]
+        hb, _, _ = self._audit_twin().forward_frames(fr, want_heatmap=True)
+        hf, _ = self._twin().forward(preprocess_triples(fr, (self.W, self.H)))
+        return (hb[0] - hf[0]).abs().max()
+
+    def calibrate(self, frames_u8, n=4, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
+        """First estimate of eps: safety * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
+        (N,h,w,3) device tensor).  Enables the certified argmax and returns eps.  The estimate is then kept honest by the audits."""
+        safety = self.SAFETY if safety is None else safety
         frames_u8 = frames_u8.to(self.device)
-        n = max(1, min(n, frames_u8.shape[0] - 2, self.max_batch))
-        was = self.certified
-        if was:
-            self.set_certify(-1.0)
-        hb, _, _ = self.forward_frames(frames_u8[:n + 2], want_heatmap=True)
-        x = preprocess_triples(frames_u8[:n + 2], (self.W, self.H))
-        twin = self._twin()
-        err = 0.0
-        for k in range(n):
-            hf, _ = twin.forward(x[k:k + 1])
-            err = max(err, float((hb[k] - hf[0]).abs().max().item()))
-        eps = safety * err
-        self.set_certify(eps, crop, max_crops_per_map)
-        return eps
+        nt = frames_u8.shape[0] - 2
+        n = max(1, min(n, nt))
+        picks = sorted(set(int(round(k * (nt - 1) / max(1, n - 1))) for k in range(n))) if n > 1 else [0]
+        err = max(float(self.heatmap_error(frames_u8, t).item()) for t in picks)
+        self.set_certify(safety * err, crop, max_crops_per_map, exact_windows)
+        self.audit_state = dict(audited_frames=len(picks), max_err_seen=err, widened=0)
+        return self.eps
+
+    def audit_async(self, frames_u8, picks):
+        """Re-run the triples `picks` of the clip on the bf16 audit twin and the fp32 twin on a side stream (behind everything the
+        current stream has enqueued) and leave max |bf16 - fp32| in pinned host memory.  Returns a ticket for `audit_result`."""
+        st = getattr(self, '_audit_stream', None)
+        if st is None:
+            st = self._audit_stream = torch.cuda.Stream(self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            err = None
+            for t in picks:
+                e = self.heatmap_error(frames_u8, int(t))
+                err = e if err is None else torch.maximum(err, e)
+            host = torch.empty((1,), dtype=torch.float32, pin_memory=True)
+            host.copy_(err.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        frames_u8.record_stream(st)
+        return {'host': host, 'event': ev, 'n': len(picks)}
+
+    def audit_result(self, ticket):
+        """Wait for an audit and fold it into `audit_state`.  Returns the error it measured."""
+        ticket['event'].synchronize()
+        err = float(ticket['host'][0])
+        return self.note_error(err, ticket['n'])
+
+    def note_error(self, err, n_frames=0):
+        a = self.__dict__.setdefault('audit_state', dict(audited_frames=0, max_err_seen=0.0, widened=0))
+        a['audited_frames'] += n_frames
+        a['max_err_seen'] = max(a['max_err_seen'], err)
+        return err
+
+    def eps_violated(self, err):
+        """True when an observed error is within the safety factor of eps: eps must be widened and the work re-certified."""
+        return self.certified and err * self.SAFETY > self.eps * (1 + 1e-6)
+
+    def widen_eps(self, err):
+        """eps <- safety * err (never smaller); affects the forward calls issued from now on."""
+        new = max(self.eps, self.SAFETY * err)
+        if new > self.eps:
+            self.set_certify(new)
+            self.audit_state['widened'] += 1
+        return self.eps
 
     def certify_budget(self, max_crops):
         """Crops the following forward calls may use (saves empty fp32 passes when the typical count is known)."""
@@ -143,19 +209,36 @@ class WASBNet:
             _lib.check(self._lib.ttup_wasb_certify_status(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
         return st
 
+    def certify_info(self):
+        """(2,) int32 device tensor of the last forward, in stream order: [crops it asked for, bits of the largest |bf16 - fp32|
+        seen at any candidate so far].  `decode_info` turns a host copy into (n_crops, max_candidate_err)."""
+        info = torch.empty((2,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_certify_info(self._handle, _lib.ptr(info), _lib.stream_ptr()))
+        return info
+
+    @staticmethod
+    def decode_info(info_host):
+        a = np.asarray(info_host, dtype=np.int32)
+        return int(a[0]), float(a[1:2].view(np.float32)[0])
+
     def certify_stats(self, reset=False):
         out = np.zeros(8, np.int64)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ttup_wasb_certify_stats(self._handle, out.ctypes.data_as(ctypes.c_void_p), 1 if reset else 0))
-        return dict(heatmaps=int(out[0]), single=int(out[1]), resolved=int(out[2]), not_certified=int(out[3]), crops=int(out[4]), candidates=int(out[5]))
+        return dict(heatmaps=int(out[0]), single=int(out[1]), resolved=int(out[2]), not_certified=int(out[3]), crops=int(out[4]), candidates=int(out[5]),
+                    max_candidate_err=float(out[6:7].astype(np.uint32).view(np.float32)[0]), exact_singles=int(out[7]))
 
-    def fix_uncertified(self, idx, win, frames_u8=None, x=None):
+    def fix_uncertified(self, idx, win, frames_u8=None, x=None, status=None):
         """Heatmaps the certified argmax flagged 2 (candidate / crop budget exceeded) are re-run on the full-frame fp32 path, so that
-        every returned index is the fp32 argmax.  Give the call's input: the uint8 clip (`forward_frames`) or the float tensor
-        (`forward`).  Synchronises; returns the number of frames re-run."""
+        every returned index is the fp32 argmax.  Give the call's input -- the uint8 clip (`forward_frames`) or the float tensor
+        (`forward`) -- and the call's OWN status (`certify_status` taken right after it, host or device); without it the handle's
+        last call is assumed.  Synchronises; returns the number of frames re-run."""
         if idx.shape[0] > self.max_batch:
             raise ValueError('fix_uncertified covers one forward call of at most max_batch=%d heatmaps' % self.max_batch)
-        st = self.certify_status(idx.shape[0]).cpu().numpy()
+        if status is None:
+            status = self.certify_status(idx.shape[0])
+        st = status.cpu().numpy() if torch.is_tensor(status) else np.asarray(status)
         bad = np.nonzero(st == 2)[0]
         if bad.size:
             twin = self._twin()

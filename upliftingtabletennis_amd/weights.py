@@ -8,6 +8,7 @@ with ``load_state_dict(strict=True)``) and the GPU tests reproduce identical ten
 Checkpoint ingestion (reference format): ``load_checkpoint_state_dict`` accepts the
 dict saved by balldetection/helper_balldetection.py:510-529 / uplifting/helper.py:371-391.
 """
+import os
 import struct
 import numpy as np
 
@@ -24,7 +25,7 @@ def _np(v):
 
 
 # --------------------------------------------------------------------------- generators
-def random_wasb_state_dict(seed=0, planted=False, in_ch=9, head_out=3, eps=0.2):
+def random_wasb_state_dict(seed=0, planted=False, in_ch=9, head_out=3, eps=0.2, plant_all_heads=False):
     """Seeded WASB/HRNet weights.
 
     planted=False: Kaiming-scaled noise everywhere, BN running stats randomised so that BN
@@ -32,7 +33,8 @@ def random_wasb_state_dict(seed=0, planted=False, in_ch=9, head_out=3, eps=0.2):
     planted=True: the same noise scaled by ``eps`` plus an identity path that carries the mean of
     the centre frame's three channels through channel 0 of the full-resolution trunk to head channel 1, so a
     bright blob in the frames produces a dominant heatmap peak (margin >> bf16 rounding) while
-    every conv still contributes.
+    every conv still contributes.  plant_all_heads=True routes the planted trunk channel to EVERY head channel (the 13-keypoint
+    table detector of the end-to-end fixtures: all keypoints then follow the blob with the same margin).
     """
     rng = np.random.default_rng(seed)
     sd = {}
@@ -59,7 +61,9 @@ def random_wasb_state_dict(seed=0, planted=False, in_ch=9, head_out=3, eps=0.2):
         w = sd[p + '.conv2.weight']; w[0] = 0; w[0, 0, 1, 1] = 1.0; ident_bn(p + '.bn2')
         w = sd[p + '.layer1.0.downsample.0.weight']; w[0] = 0; w[0, 0, 0, 0] = 1.0; ident_bn(p + '.layer1.0.downsample.1')
         w = sd[p + '.transition1.0.0.weight']; w[0] = 0; w[0, 0, 1, 1] = 1.0; ident_bn(p + '.transition1.0.1')
-        w = sd[p + '.final_layers.0.weight']; w[1] *= 0.25; w[1, 0, 0, 0] = 1.0
+        w = sd[p + '.final_layers.0.weight']
+        for k in (range(head_out) if plant_all_heads else [1]):
+            w[k] *= 0.25; w[k, 0, 0, 0] = 1.0
     return sd
 
 
@@ -128,8 +132,32 @@ def pack_uplift_blob(state_dict, size='large'):
 
 def load_checkpoint_state_dict(path):
     """Read a reference checkpoint file (torch.save of {'model_state_dict', 'identifier',
-    'additional_info'}) -> (state_dict, additional_info)."""
+    'additional_info'}) -> (state_dict, additional_info).
+
+    A checkpoint folder is user input, so the file is read with ``weights_only=True`` (tensors + plain containers: the default of
+    the torch 2.6 the reference pins, and what the reference's detector loaders use, inference_balldetection.py:49).  The
+    reference reads the UPLIFTING checkpoint with ``weights_only=False`` (inference_uplifting.py:43) because its
+    ``additional_info`` carries the training hyper-parameters, which may hold numpy scalars / dtypes: those are allow-listed on a
+    second attempt.  Anything beyond that needs the explicit opt-in ``TTUP_UNSAFE_LOAD=1`` (full unpickling, trusted files only)."""
+    import pickle
     import torch
-    # tensors + plain containers only (the default of the torch 2.6 the reference pins): a checkpoint folder is user input
-    d = torch.load(path, map_location='cpu', weights_only=True)
+    if os.environ.get('TTUP_UNSAFE_LOAD') == '1':
+        d = torch.load(path, map_location='cpu', weights_only=False)
+        return d['model_state_dict'], d.get('additional_info', {})
+    try:
+        d = torch.load(path, map_location='cpu', weights_only=True)
+    except pickle.UnpicklingError as first:
+        import numpy as np
+        allow = [np.dtype, np.ndarray, type(np.dtype('float32')), type(np.dtype('float64')), type(np.dtype('int64')), type(np.dtype('int32')), type(np.dtype('bool'))]
+        try:
+            from numpy._core.multiarray import scalar, _reconstruct
+        except ImportError:                                   # numpy < 2
+            from numpy.core.multiarray import scalar, _reconstruct
+        allow += [scalar, _reconstruct]
+        try:
+            with torch.serialization.safe_globals(allow):
+                d = torch.load(path, map_location='cpu', weights_only=True)
+        except pickle.UnpicklingError:
+            raise RuntimeError('checkpoint %s holds pickled objects beyond tensors, containers and numpy scalars (%s); if the file is '
+                               'trusted, set TTUP_UNSAFE_LOAD=1 to read it like the reference does (weights_only=False)' % (path, first)) from first
     return d['model_state_dict'], d.get('additional_info', {})
