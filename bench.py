@@ -63,7 +63,8 @@ class Pipeline:
     def __init__(self, device, seed, certify=True):
         from upliftingtabletennis_amd import pipeline, synth, weights
         self.worker = pipeline.StreamWorker(device, weights.random_wasb_state_dict(0, planted=True), weights.random_uplift_state_dict(0, 'large'),
-                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=SEQ_LEN, certify=certify)
+                                            net_wh=(W_NET, H_NET), max_triples=TRIPLES, traj_len=TRAJ_LEN, seq_len=SEQ_LEN, certify=certify,
+                                            audit_every=int(os.environ.get('TTUP_AUDIT_EVERY', '256')))
         self.net = self.worker.net
         # synthetic clip: 34 distinct frames tiled to TRIPLES+2 (keeps generation time low; content still varies per frame)
         base, track = synth.synth_frames(34, H_SRC, W_SRC, seed=seed)

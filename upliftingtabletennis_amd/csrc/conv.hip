@@ -1439,10 +1439,15 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         // Rows of the band one after the other, the row's XT column groups as independent accumulator chains (as in the 32-channel
         // form).  Per row and group: ONE new fragment for steps 0-2 (row r+2; rows r and r+1 are still in registers from the rows
         // before) plus the fragments of steps 3 and 4 -- three LDS reads for five MFMAs instead of five.
+#ifdef TTUP_ABLATE_RAGGED
+        constexpr int XTR = RAGGED ? XT - 1 : XT;       // ablation (wrong results): the ragged last column group is not computed at all
+#else
+        constexpr int XTR = XT;
+#endif
         if (yb < RHO) {
             bf16x8 fa[XT][RB + 2];
 #pragma unroll
-            for (int xt = 0; xt < XT; ++xt) {
+            for (int xt = 0; xt < XTR; ++xt) {
                 const bf16_t* bA = (RAGGED && xt == XT - 1) ? pAl : pA + xt * 16 * C;
                 fa[xt][0] = *(const bf16x8*)bA; fa[xt][1] = *(const bf16x8*)(bA + RS);
             }
@@ -1452,7 +1457,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 if (y >= RHO) break;
                 bf16x8 f3[XT], f4[XT];
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) {
+                for (int xt = 0; xt < XTR; ++xt) {
                     const bool lastg = RAGGED && xt == XT - 1;
                     fa[xt][r + 2] = *(const bf16x8*)((lastg ? pAl : pA + xt * 16 * C) + (r + 2) * RS);
                     f3[xt] = *(const bf16x8*)((lastg ? pCl : pC + xt * 16 * C) + r * RS);
@@ -1460,17 +1465,17 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 }
                 f32x4 acc[XT][1];
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], fa[xt][r], bias[0], 0, 0, 0);
+                for (int xt = 0; xt < XTR; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], fa[xt][r], bias[0], 0, 0, 0);
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], fa[xt][r + 1], acc[xt][0], 0, 0, 0);
+                for (int xt = 0; xt < XTR; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], fa[xt][r + 1], acc[xt][0], 0, 0, 0);
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][0], fa[xt][r + 2], acc[xt][0], 0, 0, 0);
+                for (int xt = 0; xt < XTR; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][0], fa[xt][r + 2], acc[xt][0], 0, 0, 0);
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3][0], f3[xt], acc[xt][0], 0, 0, 0);
+                for (int xt = 0; xt < XTR; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3][0], f3[xt], acc[xt][0], 0, 0, 0);
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4][0], f4[xt], acc[xt][0], 0, 0, 0);
+                for (int xt = 0; xt < XTR; ++xt) acc[xt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4][0], f4[xt], acc[xt][0], 0, 0, 0);
 #pragma unroll
-                for (int xt = 0; xt < XT; ++xt) epi(xt, r, y, acc[xt]);
+                for (int xt = 0; xt < XTR; ++xt) epi(xt, r, y, acc[xt]);
             }
         }
     }

@@ -138,10 +138,10 @@ class BallDetector:
             hb, _ = m.forward(x[:n])
             twin = m._twin()
             err = max(float((hb[k] - twin.forward(x[k:k + 1])[0][0]).abs().max().item()) for k in range(n))
-            m.set_certify(m.SAFETY * err, exact_windows=exact)
+            m.set_certify(m.HEADROOM * err, exact_windows=exact)
             m.audit_state = dict(audited_frames=n, max_err_seen=err, widened=0)
         else:
-            m.calibrate(frames, n=2, exact_windows=exact)
+            m.calibrate(frames, n=4, exact_windows=exact)
 
     def _audit_picks(self, n_triples):
         """One random triple per AUDIT_EVERY triples this detector has processed is re-run on the fp32 twin (eps audit)."""

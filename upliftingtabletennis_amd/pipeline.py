@@ -101,8 +101,8 @@ class StreamWorker:
     Certified argmax (`certify=True`, bf16): eps -- the bound on |bf16 heatmap - fp32 heatmap| the certification rests on -- is
     estimated on the first clip and then AUDITED while the worker runs: one random triple per `audit_every` triples is re-run on
     the fp32 twin on a side stream, and every fp32 crop the certification computes anyway reports the error at its candidates.
-    When an observed error comes within the safety factor (1.5) of eps, eps is widened and the clips certified under the old value
-    are re-run.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
+    eps starts at 1.75 times the largest error of the calibration frames; when an observed error comes within the safety factor (1.5) of
+    eps, eps is widened (to 1.75 times that error) and the clips certified under the old value are re-run.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
                  traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False):
@@ -148,7 +148,7 @@ class StreamWorker:
 
     def _calibrated(self, frames_u8):
         if self.certify and self.certify_eps is None:
-            self.certify_eps = self.net.calibrate(frames_u8, n=4, exact_windows=self.exact_windows)
+            self.certify_eps = self.net.calibrate(frames_u8, n=8, exact_windows=self.exact_windows)
         return self.certify_eps
 
     def _start_audit(self, frames_u8):
@@ -255,26 +255,28 @@ class StreamWorker:
         with torch.cuda.stream(sub):
             return self._submit(frames_u8, sub)
 
-    def _pinned(self, key, like, i):
-        ring = self.__dict__.setdefault('_pinned_ring', {})          # two pinned buffers per (name, shape), used alternately
-        slot = ring.setdefault((key, tuple(like.shape)), [None, None])
-        if slot[i] is None:
-            slot[i] = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
-        return slot[i]
+    def _pinned(self, key, like):
+        """A pinned host buffer shaped like `like` from the worker's pool (returned to it by collect): any number of clips may be
+        in flight between submit and collect."""
+        pool = self.__dict__.setdefault('_pin_pool', {})
+        free = pool.setdefault((key, tuple(like.shape), like.dtype), [])
+        return free.pop() if free else torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+
+    def _unpin(self, key, buf):
+        if buf is not None:
+            self._pin_pool[(key, tuple(buf.shape), buf.dtype)].append(buf)
 
     def _submit(self, frames_u8, sub):
         eps_used = self._calibrated(frames_u8)
         audit = self._start_audit(frames_u8)          # side stream: shares the GPU with this clip's detector pass
         xyv, idx, win, status, info = self._detect(frames_u8)
-        i = self.__dict__.get('_pin_next', 0)
-        self._pin_next = 1 - i
-        host = self._pinned('xyv', xyv, i)
+        host = self._pinned('xyv', xyv)
         host.copy_(xyv, non_blocking=True)
         st_host = info_host = None
         if status is not None:
-            st_host = self._pinned('status', status, i)
+            st_host = self._pinned('status', status)
             st_host.copy_(status, non_blocking=True)
-            info_host = self._pinned('info', info, i)
+            info_host = self._pinned('info', info)
             info_host.copy_(info, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
@@ -311,6 +313,11 @@ class StreamWorker:
         cur = torch.cuda.current_stream(self.device)
         for t in (spin, p3, nvalid):
             t.record_stream(cur)
-        return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid}
+        status_host = None if ticket.get('status') is None else ticket['status'].numpy().copy()
+        for k in ('host', 'status', 'info'):
+            self._unpin('xyv' if k == 'host' else k, ticket.get(k))
+            ticket[k] = None
+        ticket['status_host'] = status_host
+        return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid, 'status': status_host}
 
     RECORD_KEYS = ('xyv', 'spin', 'pos3d', 'n_valid')          # what a step hands to gather_records

@@ -105,7 +105,8 @@ class WASBNet:
     # The guarantee is conditional: an index is the fp32 argmax whenever |bf16 heatmap - fp32 heatmap| <= eps on that frame.  eps is
     # an empirical bound -- measured (`calibrate`), then audited for as long as the handle runs (`audit_async` / the candidate-level
     # error the crops give for free, `certify_info`) and widened when an audit comes within the safety factor of it.
-    SAFETY = 1.5
+    SAFETY = 1.5           # an observed error within this factor of eps triggers a widening (and a re-run of the affected work)
+    HEADROOM = 1.75        # eps is set to this factor times the largest error seen: a new maximum up to a sixth above the old one fits
 
     def set_certify(self, eps_abs, crop=0, max_crops_per_map=0, exact_windows=None):
         """eps_abs bounds |bf16 heatmap - fp32 heatmap|; < 0 switches the certification off.  exact_windows=True: every heatmap
@@ -142,10 +143,10 @@ class WASBNet:
         hf, _ = self._twin().forward(preprocess_triples(fr, (self.W, self.H)))
         return (hb[0] - hf[0]).abs().max()
 
-    def calibrate(self, frames_u8, n=4, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
-        """First estimate of eps: safety * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
+    def calibrate(self, frames_u8, n=8, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
+        """First estimate of eps: HEADROOM * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
         (N,h,w,3) device tensor).  Enables the certified argmax and returns eps.  The estimate is then kept honest by the audits."""
-        safety = self.SAFETY if safety is None else safety
+        safety = self.HEADROOM if safety is None else safety
         frames_u8 = frames_u8.to(self.device)
         nt = frames_u8.shape[0] - 2
         n = max(1, min(n, nt))
@@ -191,8 +192,8 @@ class WASBNet:
         return self.certified and err * self.SAFETY > self.eps * (1 + 1e-6)
 
     def widen_eps(self, err):
-        """eps <- safety * err (never smaller); affects the forward calls issued from now on."""
-        new = max(self.eps, self.SAFETY * err)
+        """eps <- HEADROOM * err (never smaller); affects the forward calls issued from now on."""
+        new = max(self.eps, self.HEADROOM * err)
         if new > self.eps:
             self.set_certify(new)
             self.audit_state['widened'] += 1
