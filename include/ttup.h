@@ -108,6 +108,13 @@ int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_d
 int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
 int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, char* names_out,
                          int* n_ops_out, void* stream);
+/* measured peaks of the device (csrc/peaks.hip; SURVEY 8d "Peaks to divide by"), HIP events on `stream`, synchronises.
+ * mfma: out_host[0..1] = TFLOP/s of register-resident v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16 loops on random
+ * operands with `waves_per_simd` waves on every SIMD, [2..3] their durations (ms).
+ * hbm: out_host[0..2] = GB/s of a streaming read / copy / triad over arrays of `bytes` each (>= 1 GiB: past the Infinity Cache),
+ * [3..5] their durations (ms). */
+int ttup_peak_mfma_bf16(int iters, int waves_per_simd, double* out_host, void* stream);
+int ttup_peak_hbm(size_t bytes, double* out_host, void* stream);
 /* Certified argmax for the bf16 ball detector (north_star: bit-exact heatmap argmax indices; reference
  * balldetection/helper_balldetection.py:50 takes torch.argmax of the fp32 heatmap).  eps_abs bounds |bf16 heatmap - fp32 heatmap|
  * (calibrated by the caller on its own frames; upliftingtabletennis_amd.wasb.WASBNet.calibrate).  Once set, every forward that
@@ -120,6 +127,12 @@ int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float
  * bits of max |bf16 - fp32| seen at a candidate (a float in the low 32 bits: the free part of the eps audit), single-candidate
  * heatmaps cropped in exact-window mode}. */
 int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map);
+/* step 1 of the certification on its own (the kernel that streams the heatmap on the production path: measurement aid, test
+ * hook): for each of n_maps fp32 heatmaps (n_maps, H, W) the pixels whose value is >= heat[argmax[map]] - 2*eps_abs, appended in
+ * arbitrary order to cand_idx_dev[map*K ..] (flat pixel index) / cand_bf_dev (their values); cand_cnt_dev[map] (zeroed by the
+ * caller) counts ALL of them, also those past K. */
+int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_dev, int n_maps, int height, int width, float eps_abs, int K,
+                      int* cand_idx_dev, int* cand_cnt_dev, float* cand_bf_dev, void* stream);
 /* exact-window mode (on != 0): heatmaps with ONE candidate get an fp32 crop too, so that every returned 3x3 window -- not only
  * the near-ties' -- holds the fp32 path's values and the sub-pixel fit sees what the reference's fit sees (one 168x168 fp32
  * pass per heatmap: a parity / audit mode, off by default) */

@@ -53,7 +53,26 @@ def _worker(rank, world, port, out_dir):
                'spin': torch.from_numpy(rng.standard_normal((s1 - s0, 3)).astype(np.float32)),
                'pos3d': torch.from_numpy(rng.standard_normal((s1 - s0, 50, 3)).astype(np.float32)),
                'n_valid': torch.arange(s0, s1, dtype=torch.int64)}
-        got = pipeline.gather_records(rec, dist, dst=0)
+        # count the collectives a gather issues: with the worker's record spec exactly ONE, without it two
+        calls = {'n': 0}
+        orig = {k: getattr(dist, k) for k in ('all_gather_into_tensor', 'all_gather', 'all_reduce', 'gather', 'broadcast')}
+        for k, fn in orig.items():
+            setattr(dist, k, (lambda fn: lambda *a, **kw: (calls.__setitem__('n', calls['n'] + 1), fn(*a, **kw))[1])(fn))
+        spec = {'xyv': (64, (3,), torch.float64), 'spin': (8, (3,), torch.float32), 'pos3d': (8, (50, 3), torch.float32), 'n_valid': (8, (), torch.int64)}
+        got = pipeline.gather_records(rec, dist, dst=0, spec=spec)
+        assert calls['n'] == 1, calls
+        got2 = pipeline.gather_records(rec, dist, dst=0)
+        assert calls['n'] == 3, calls
+        for k, fn in orig.items():
+            setattr(dist, k, fn)
+        if rank == 0:
+            assert all(torch.equal(a, b) for k in got for a, b in zip(got[k], got2[k]))
+            try:
+                pipeline.gather_records({'xyv': rec['xyv'][:, :2]}, None)            # fine without dist
+                pipeline._pack_records({'xyv': rec['xyv'][:, :2]}, {'xyv': spec['xyv']}, torch.device('cpu'))
+                raise AssertionError('a record that does not fit its spec must be refused')
+            except ValueError:
+                pass
         if rank == 0:
             assert got is not None and set(got) == set(rec)
             assert [int(v.shape[0]) for v in got['spin']] == [pipeline.shard_range(n_streams, world, r)[1] - pipeline.shard_range(n_streams, world, r)[0] for r in range(world)]

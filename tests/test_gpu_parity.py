@@ -579,6 +579,28 @@ def test_bench_spawns_its_own_ranks():
     assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
 
 
+def test_bench_eight_rank_dry_run_on_one_gpu():
+    """BASELINE config 4's process layout without the hardware: EIGHT ranks (one full StreamWorker each: bf16 handle with two
+    lanes, fp32 crop net, audit twins -- about 10 GB per rank) come up side by side on this box's one GPU, rendezvous on eight
+    ports' worth of state, gather once per step through gloo and rank 0 reports 8 x 256 frames per step.  What it cannot show is
+    the RCCL transport between eight devices: unmeasured on hardware until the driver's 8-GPU run."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'OMP_NUM_THREADS')}
+    env.update(TTUP_BENCH_SHARE_GPU='1', TTUP_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['collective']['ranks'] == 8 and rec['collective']['world_size'] == 8 and rec['collectives_per_step'] == 1
+    assert rec['config']['frames_per_step_per_gpu'] == 256
+    assert abs(rec['value'] - 8 * 256 / (rec['ms_per_step'] / 1e3)) / rec['value'] < 1e-3
+    assert 1 <= rec['host_threads_per_rank'] <= max(1, (os.cpu_count() or 8) // 8)
+    print('\n8 ranks on one GPU: %.0f frames/s aggregate, %.0f ms per step, %d host threads per rank' % (rec['value'], rec['ms_per_step'], rec['host_threads_per_rank']))
+
+
 def test_rccl_gather_on_device_tensors():
     """The path's only collective over RCCL itself (backend 'nccl' on ROCm) with device tensors: a world of one rank on this
     box's single GPU -- init, all_reduce, all_gather of the record sizes and the gather of `gather_records`."""

@@ -345,6 +345,22 @@ extern "C" int ttup_wasb_certify_budget(ttup_wasb* net, int max_crops) {
     return TTUP_OK;
 }
 
+// The scan on its own (measurement aid and test hook): candidates of n_maps fp32 heatmaps within 2*eps_abs of each map's value at
+// argmax_dev[map].  cand_cnt_dev must be zeroed by the caller; cand_idx_dev / cand_bf_dev hold K entries per map.
+extern "C" int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_dev, int n_maps, int height, int width, float eps_abs, int K,
+                                 int* cand_idx_dev, int* cand_cnt_dev, float* cand_bf_dev, void* stream) {
+    TTUP_REQUIRE(heat_dev && argmax_dev && cand_idx_dev && cand_cnt_dev && cand_bf_dev, TTUP_EINVAL, "ttup_certify_scan: null pointer");
+    TTUP_REQUIRE(n_maps >= 0 && height > 0 && width > 0 && ((long long)height * width) % 4 == 0 && K > 0 && eps_abs >= 0.f, TTUP_EINVAL, "ttup_certify_scan: bad argument");
+    if (n_maps == 0) return TTUP_OK;
+    const long long hw = (long long)height * width;
+    int nblk = (int)(hw / 4 / 256 / 8);
+    nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+    hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, n_maps), dim3(256), 0, (hipStream_t)stream, heat_dev, (const long long*)argmax_dev, hw, 2.f * eps_abs, K,
+                       cand_idx_dev, cand_cnt_dev, cand_bf_dev);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 extern "C" int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on) {
     TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_exact_windows: the certified argmax is not enabled on this handle");
     net->cert.exact_windows = on != 0;
