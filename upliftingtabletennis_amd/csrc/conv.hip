@@ -1439,11 +1439,17 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         // Rows of the band one after the other, the row's XT column groups as independent accumulator chains (as in the 32-channel
         // form).  Per row and group: ONE new fragment for steps 0-2 (row r+2; rows r and r+1 are still in registers from the rows
         // before) plus the fragments of steps 3 and 4 -- three LDS reads for five MFMAs instead of five.
-#ifdef TTUP_ABLATE_RAGGED
-        constexpr int XTR = RAGGED ? XT - 1 : XT;       // ablation (wrong results): the ragged last column group is not computed at all
+        // Ragged region widths (38 / 36 / 34 px = two full 16-pixel groups + 6 / 4 / 2 px): the band walks the FULL groups only; the
+        // leftover strip (RHO rows x RX columns) is packed 16 pixels at a time into "strip groups" whose lanes sit in different rows
+        // -- 12 / 7 / 4 groups instead of 30 / 28 / 26 two-thirds-empty ones -- and handed to the waves with spare time: the last
+        // wave's band is short or empty (RHO is not a multiple of 8), so it takes the first K0 strip groups, the others one each.
+        // Same k-step order and operands per output pixel as a band group: bit-identical results.
+#ifdef TTUP_NO_STRIP
+        constexpr bool STRIP = false;
 #else
-        constexpr int XTR = XT;
+        constexpr bool STRIP = RAGGED && !GLOBAL_OUT;
 #endif
+        constexpr int XTR = STRIP ? XT - 1 : XT;
         if (yb < RHO) {
             bf16x8 fa[XT][RB + 2];
 #pragma unroll
@@ -1477,6 +1483,41 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                 for (int xt = 0; xt < XTR; ++xt) epi(xt, r, y, acc[xt]);
             }
+        }
+        if constexpr (STRIP) {
+            constexpr int RX = RWO - XLAST, NSP = RHO * RX, NSG = (NSP + 15) / 16;
+            constexpr int ROWS7 = RHO - 7 * RB < 0 ? 0 : (RHO - 7 * RB > RB ? RB : RHO - 7 * RB);      // band rows of the last wave
+            constexpr int K0 = NSG < 2 * (RB - ROWS7) ? NSG : 2 * (RB - ROWS7);                        // strip groups that fill its band's gap
+            static_assert(NSG - K0 <= 8, "one strip group per wave after the last wave's share");
+            auto strip = [&](int j) __attribute__((always_inline)) {
+                const int p = 16 * j + n;
+                const bool valid = p < NSP;
+                const int pc = valid ? p : NSP - 1;                   // lanes past the strip recompute its last pixel and store nothing
+                const int row = pc / RX, col = XLAST + (pc - row * RX);
+                const bf16_t* b0 = s_in + ((row + IOFF) * RWI + IOFF + col) * C;
+                const int sw2 = (c8 ^ (((col + 2 + IOFF) >> 2) & 1)) << 3;
+                const bf16_t* a0 = b0 + h * C + ((c8 ^ (((col + h + IOFF) >> 2) & 1)) << 3);        // steps 0-2: rows row + dy, column col | col+1
+                const bf16_t* a3 = b0 + h * RS + 2 * C + sw2;                                       // step 3: column col+2 of rows row | row+1
+                const bf16_t* a4 = b0 + 2 * RS + 2 * C + sw2;                                       // step 4: (row+2, col+2) | block input / pad
+                if (RES_MFMA && h) a4 = s_res + ((row + ROFF) * RWR + ROFF + col) * C + ((c8 ^ (((col + ROFF) >> 2) & 1)) << 3);
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], *(const bf16x8*)a0, bias[0], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], *(const bf16x8*)(a0 + RS), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][0], *(const bf16x8*)(a0 + 2 * RS), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3][0], *(const bf16x8*)a3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4][0], *(const bf16x8*)a4, acc, 0, 0, 0);
+                unsigned q0 = relu_pk(pack2(acc[0], acc[1])), q1 = relu_pk(pack2(acc[2], acc[3]));
+                if (!interior) {                                      // zero padding of the next conv outside the image
+                    const int gy = gy0 + row, gx = gx0 + col;
+                    const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    q0 = inside ? q0 : 0u; q1 = inside ? q1 : 0u;
+                }
+                if (valid) *(u32x2*)(s_out + ((row + OOFF) * ORW + col + OOFF) * C + ((((g >> 1) ^ (((col + OOFF) >> 2) & 1)) << 3) + (g & 1) * 4)) = u32x2{q0, q1};
+            };
+            if (wave == 7) {
+#pragma unroll
+                for (int j = 0; j < K0; ++j) strip(j);
+            }
+            if (K0 + wave < NSG) strip(K0 + wave);
         }
     }
 }
