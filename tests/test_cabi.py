@@ -248,3 +248,28 @@ def test_reference_format_checkpoints_are_ingested(tmp_path, monkeypatch):
     torch.save({'model_state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in up.items()}, 'identifier': 'unit-test', 'additional_info': info}, str(d))
     with pytest.raises(ValueError, match='time_rotation'):
         interface._load_uplift_checkpoint()
+
+
+def test_native_dbscan_labels_equal_sklearns():
+    """glue._dbscan_labels replaces the scikit-learn DBSCAN call of the reference's keypoint filter (inference/utils.py:213) on the
+    product side: same labels -- cluster numbering, border-point assignment, noise -- on random point sets with one to four
+    clusters, including integer coordinates that put distances exactly on the threshold; and the filter built on it equals the
+    oracle's (which keeps sklearn) on two disagreeing detectors."""
+    from sklearn.cluster import DBSCAN
+    from oracle import glue_ref
+    rng = np.random.default_rng(3)
+    for trial in range(400):
+        n, k = int(rng.integers(3, 70)), int(rng.integers(1, 5))
+        centers = rng.uniform(0, 120, (k, 2))
+        pts = centers[rng.integers(k, size=n)] + rng.normal(0, rng.uniform(1, 12), (n, 2))
+        if trial % 4 == 0:
+            pts = np.round(pts)
+        for eps, ms in ((10, 3), (10, 5), (6, 4)):
+            assert np.array_equal(glue._dbscan_labels(pts, eps, ms), DBSCAN(eps=eps, min_samples=ms).fit(pts).labels_), (trial, eps, ms)
+    for trial in range(20):
+        T = 40
+        p1 = np.zeros((T, 13, 3)); p1[:, :, :2] = rng.uniform(0, 1900, (13, 2)) + rng.normal(0, rng.uniform(0.5, 8), (T, 13, 2)); p1[:, :, 2] = rng.uniform(size=(T, 13)) < 0.9
+        p2 = p1.copy(); p2[:, :, :2] += rng.normal(0, 5, (T, 13, 2)); p2[:, :, 2] = rng.uniform(size=(T, 13)) < 0.9
+        if trial % 3 == 0:
+            p1, p2 = np.round(p1), np.round(p2)
+        assert np.array_equal(glue.filter_trajectory_table(p1, p2), glue_ref.filter_trajectory_table(p1, p2))

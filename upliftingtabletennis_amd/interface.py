@@ -298,9 +298,11 @@ class TableTennisPipeline:
     def __init__(self, max_batch=32):
         _lib.require_gpu()
         self.device = torch.device('cuda')
-        self.ball_detector = BallDetector(model_name='wasb', max_batch=max_batch)
+        self.CHUNK = int(os.environ.get('TTUP_HUB_CHUNK', self.CHUNK))
+        self.FIRST = int(os.environ.get('TTUP_HUB_FIRST', self.FIRST))
+        self.ball_detector = BallDetector(model_name='wasb', max_batch=max(max_batch, self.CHUNK))
         self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
-        self.table_detector = TableDetector(model_name='hrnet', max_batch=16)
+        self.table_detector = TableDetector(model_name='hrnet', max_batch=max(16, self.CHUNK))
         self.table_detector_aux = self.table_detector
         # the overlapped clip path runs both detectors side by side: the table detector goes first on the GPU, so that its
         # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
@@ -318,7 +320,8 @@ class TableTennisPipeline:
         for fixed-camera streams; the reference surface is `predict`."""
         return self._predict(images, fps, table_keypoints)
 
-    CHUNK = 16          # frames per upload / detector call of the overlapped clip path
+    CHUNK = 24          # frames per upload / detector call of the overlapped clip path (measured: 16 -> 68 ms, 24 -> 60 ms, 48 -> 63 ms per 48-frame clip)
+    FIRST = 24          # frames of the first chunk (a short first chunk -- 8 frames -- was measured 5 ms SLOWER per clip: its one-micro-batch calls run at half the batched rate)
 
     def _clip_detections(self, images, want_table, table_consumer=None):
         """Ball positions (N-2,3) and table keypoints ((N,13,3), or what `table_consumer` makes of them) of one clip with everything overlapped: the frames are staged in
@@ -342,19 +345,37 @@ class TableTennisPipeline:
         cur = torch.cuda.current_stream(dev)
         for s in st.values():
             s.wait_stream(cur)
-        uploaded = []                     # event per chunk
+        # chunk schedule: a short first chunk (FIRST frames) gets the GPU going while the host still stages the bulk of the clip;
+        # after it, chunks of C frames.  Each chunk = one upload, one table-detector call and one ball-detector call on the triples
+        # whose three frames are resident by then.
+        F0 = min(self.FIRST, C, n)
+        bounds = [0, F0] + list(range(F0 + C, n, C)) + ([n] if n > F0 else [])
+        bounds = sorted(set(bounds))
         ball_out, table_out, ball_calls = [], [], []
         t_next = 0                        # first triple not yet submitted
-
-        def submit_ball(limit_frames, final):
-            nonlocal t_next
-            # triples t .. need frames t..t+2 resident; submit full chunks (or the remainder at the end)
-            while t_next < n - 2 and (t_next + min(C, n - 2 - t_next) + 2 <= limit_frames):
-                nt = min(C, n - 2 - t_next)
-                if not final and nt < C and limit_frames < n:
-                    break
+        ev = None
+        for ci, (c0, c1) in enumerate(zip(bounds[:-1], bounds[1:])):
+            pin = self._pinned[ci % 2]
+            if self._pin_free[ci % 2] is not None:
+                self._pin_free[ci % 2].synchronize()          # the copy that last read this staging buffer is done
+            self._stage(images, c0, c1, pin)
+            with torch.cuda.stream(st['copy']):
+                frames[c0:c1].copy_(pin[:c1 - c0], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record()
+            self._pin_free[ci % 2] = ev
+            if ci == 0:
+                torch.cuda.current_stream(dev).wait_event(ev)
+                bd._calibrate(frames=frames[:c1]) if c1 >= 3 else None        # certified argmax: once per detector
+            if want_table:
+                with torch.cuda.stream(st['table']):
+                    st['table'].wait_event(ev)
+                    _, idx, win = td.model.forward_frames(frames[c0:c1], want_heatmap=False)
+                    table_out.append(refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE))
+            # triples t need frames t..t+2: everything up to c1-3 can go now
+            while t_next < c1 - 2:
+                nt = min(bd.max_batch, c1 - 2 - t_next)
                 with torch.cuda.stream(st['ball']):
-                    st['ball'].wait_event(uploaded[(t_next + nt + 1) // C])
+                    st['ball'].wait_event(ev)
                     fr = frames[t_next:t_next + nt + 2]
                     _, idx, win = bd.model.forward_frames(fr, want_heatmap=False)
                     # status / info of THIS call, copied right behind it (the handle's per-call slot flips with the next call)
@@ -362,28 +383,7 @@ class TableTennisPipeline:
                     info = bd.model.certify_info() if bd.model.certified else None
                     ball_calls.append((t_next, nt, idx, win, status, info, bd.model.eps if bd.model.certified else None))
                 t_next += nt
-
-        for ci, c0 in enumerate(range(0, n, C)):
-            c1 = min(c0 + C, n)
-            pin = self._pinned[ci % 2]
-            if self._pin_free[ci % 2] is not None:
-                self._pin_free[ci % 2].synchronize()          # the copy that last read this staging buffer is done
-            for k in range(c0, c1):
-                pin[k - c0].copy_(torch.from_numpy(np.ascontiguousarray(images[k])))
-            with torch.cuda.stream(st['copy']):
-                frames[c0:c1].copy_(pin[:c1 - c0], non_blocking=True)
-                ev = torch.cuda.Event(); ev.record()
-            uploaded.append(ev)
-            self._pin_free[ci % 2] = ev
-            if ci == 0:
-                torch.cuda.current_stream(dev).wait_event(ev)
-                bd._calibrate(frames=frames[:min(c1, 4)]) if c1 >= 3 else None        # certified argmax: once per detector
-            if want_table:
-                with torch.cuda.stream(st['table']):
-                    st['table'].wait_event(ev)
-                    _, idx, win = td.model.forward_frames(frames[c0:c1], want_heatmap=False)
-                    table_out.append(refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE))
-            submit_ball(c1, final=(c1 == n))
+        uploaded = [ev]
         frames.record_stream(st['ball']); frames.record_stream(st['table'])
         # eps audit of the certified argmax: a random triple of the clip on the fp32 twin, on its own stream next to the detectors
         audit = None
@@ -421,6 +421,24 @@ class TableTennisPipeline:
             ball_out.append(refine.refine_windows_device(idx, win, bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
         pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
         return pos, kp
+
+    STAGE_THREADS = 4
+
+    def _stage(self, images, c0, c1, pin):
+        """Copy frames c0..c1 of the caller's list into the pinned staging buffer.  The copies are plain memcpys of 2.8 MB each
+        (numpy releases the GIL for them), so a few threads bring a 16-frame chunk from 4.5 ms down to about 1.5 ms -- the first
+        chunk's staging is the one stretch of a clip during which the GPU has nothing to do."""
+        dst = pin.numpy()
+        nthr = 1 if os.environ.get('TTUP_HUB_STAGE_THREADS') == '1' else self.STAGE_THREADS
+        if nthr <= 1 or c1 - c0 < 4:
+            for k in range(c0, c1):
+                np.copyto(dst[k - c0], images[k])
+            return
+        pool = self.__dict__.get('_stage_pool')
+        if pool is None:
+            import concurrent.futures
+            pool = self._stage_pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.STAGE_THREADS)
+        list(pool.map(lambda k: np.copyto(dst[k - c0], images[k]), range(c0, c1)))
 
     def _predict(self, images, fps, table_keypoints):
         overlapped = (self.ball_detector_aux is self.ball_detector and self.table_detector_aux is self.table_detector and len(images) >= 3
