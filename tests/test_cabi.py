@@ -145,21 +145,62 @@ def host_fit(tmp_path_factory):
     return ctypes.CDLL(so)
 
 
-def _check_fit_bars(err, variant, device=False):
-    """Bars on |offset - SciPy offset| in heatmap pixels over the 51 golden windows (tests/golden/refine.npz).
-    Table variant (sigma in [0.5, 3], the hub surface): every window to 1e-5 px (measured 4e-7 on host and device).
-    Ball variant (sigma free up to 50): flat valleys amplify last-bit exp() differences through the 1e-8 finite-difference
-    step -- 44 of 51 windows agree to 1e-6, all but window 36 (the sigma=30 blob) to 1.5e-3.  Window 36 measures 0.030 px
-    with glibc's exp (host build) and 0.088 px with the device's exp; numpy's own SIMD exp differs from glibc the same way."""
-    n = err.shape[0]
+_FIT_RADIUS = {}
+
+
+def _fit_radius(win, variant):
+    """How far the REFERENCE's own answer moves when exp() differs in the last bit: SciPy's L-BFGS-B (the reference's optimiser,
+    2-point finite differences with a 1e-8 step) on the reference's loss, with every exp() result randomly left alone or moved
+    up by one ulp -- what separates numpy's SIMD exp (which produced the goldens), glibc's and the device's.  Largest shift of
+    the fitted offset over 5 seeded draws, per window (heatmap pixels).  Ball variant, window 36 (a sigma = 30 blob: a flat
+    valley up to the sigma bound of 50): 0.08 px; glibc's exp alone moves it by 0.018 px.  Table variant: < 1e-5 px everywhere."""
+    key = (variant, win.tobytes())
+    if key in _FIT_RADIUS:
+        return _FIT_RADIUS[key]
+    from scipy.optimize import minimize
+    from oracle import refine_ref as R
+    n = win.shape[0]
+    smax = 50 if variant == 0 else 3
+    bounds = [(0, 3), (0, 3), (0.5, smax), (0.5, smax)]
+
+    def fit(flat, expfn):
+        def loss(p):
+            x0, y0, sx, sy = p
+            if variant == 1:
+                sx, sy = max(0.5, sx), max(0.5, sy)
+            return np.mean((expfn(-((R._XY[0] - x0) ** 2 / (2 * sx ** 2) + (R._XY[1] - y0) ** 2 / (2 * sy ** 2))) - flat) ** 2)
+        return minimize(loss, np.array([1, 1, 1.0, 1.0], dtype=np.float32), method='L-BFGS-B', bounds=bounds).x[:2]
+    flats = [np.asarray(win[i], np.float32).flatten() for i in range(n)]
+    ref = np.array([fit(f, np.exp) for f in flats])
+    rad = np.zeros(n)
+    for draw in range(5):
+        rng = np.random.default_rng(100 + draw)
+
+        def exp_ulp(a):
+            e = np.exp(a)
+            return np.where(rng.uniform(size=e.shape) < 0.5, np.nextafter(e, np.inf), e)
+        rad = np.maximum(rad, np.abs(np.array([fit(f, exp_ulp) for f in flats]) - ref).max(1))
+    _FIT_RADIUS[key] = rad
+    return rad
+
+
+def _check_fit_bars(err, variant, win, device=False):
+    """Bars on |offset - SciPy offset| in heatmap pixels over the 51 golden windows (tests/golden/refine.npz), tied to the
+    conditioning of each fit instead of one number for all: a window must agree to 1e-6 px or to twice the distance the
+    reference's OWN answer moves under one-ulp differences of exp() (`_fit_radius`), whichever is larger.
+    Table variant (sigma in [0.5, 3], the hub surface): all radii are below 1e-5, so every window agrees to 2e-5 px at worst
+    (measured 4e-7 on host and device).  Ball variant (sigma free up to 50): 44 of 51 windows have radii below 1e-6; the flat
+    valleys of the wide blobs amplify last-bit exp() differences through the 1e-8 finite-difference step -- window 36 (sigma = 30)
+    has a radius of 0.08 px, and the host build (glibc exp) / the device land 0.030 / 0.088 px from numpy's answer."""
+    rad = _fit_radius(win, variant)
+    bar = np.maximum(1e-6, 2.0 * rad)
+    worst = int(np.argmax(err / bar))
+    assert (err <= bar).all(), 'window %d: off by %.3e px, bar %.3e (radius of the reference answer %.3e)' % (worst, err[worst], bar[worst], rad[worst])
     if variant == 1:
-        assert err.max() < 1e-5, (err.max(), int(err.argmax()))
-        return
-    assert (err < 1e-6).sum() >= n - 8, np.sort(err)[-10:]
-    assert (err < 1e-4).sum() >= n - (8 if device else 6), np.sort(err)[-10:]
-    rest = np.delete(err, 36)
-    assert rest.max() < 1.5e-3, (rest.max(), int(err.argmax()))
-    assert err[36] < (0.15 if device else 0.05), err[36]
+        assert err.max() < 2e-5, (err.max(), int(err.argmax()))
+    else:
+        assert (err < 1e-6).sum() >= err.shape[0] - 8, np.sort(err)[-10:]
+    return bar
 
 
 def test_fit_solver_host_build_tracks_scipy(host_fit, golden):
@@ -175,7 +216,7 @@ def test_fit_solver_host_build_tracks_scipy(host_fit, golden):
         host_fit.ttup_host_fit(w.ctypes.data_as(ctypes.c_void_p), n, variant, out.ctypes.data_as(ctypes.c_void_p))
         ref = np.array([refine_ref.fit_window(win[i], variant)[:2] for i in range(n)])
         err = np.abs(out[:, :2] - ref).max(1)
-        _check_fit_bars(err, variant)
+        _check_fit_bars(err, variant, win)
 
 
 def test_filter_trajectory_table_matches_reference(golden):

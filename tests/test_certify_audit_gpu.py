@@ -40,6 +40,10 @@ def test_audit_twin_recomputes_the_production_heatmap_bit_for_bit():
         assert torch.equal(h1[0], heat[t]), t
     e = float(net.heatmap_error(fr, 3).item())
     assert 0 < e < 0.1 * float(heat.abs().max())
+    # the running audit looks at a quarter-width strip of the frame: a smaller sample of the same error distribution
+    strips = [float(net.heatmap_error(fr, 3, x0).item()) for x0 in (0, 480, 960)]
+    print('\nfull-frame error %.4g, strip errors %s' % (e, ['%.4g' % v for v in strips]))
+    assert all(0.25 * e < v <= 1.25 * e for v in strips), (e, strips)
 
 
 def test_eps_audit_widens_on_brighter_frames_and_recertifies():

@@ -142,7 +142,7 @@ def test_eval_path_callers(golden):
     got = refine.refine_windows_device(idx, win, heat.shape[1], heat.shape[2], 1920, 1080, _lib.REFINE_BALL).cpu().numpy()
     err = (np.abs(got - rg['ball'])[:, :2] / np.array([1920 / heat.shape[2], 1080 / heat.shape[1]])).max(1)
     from test_cabi import _check_fit_bars
-    _check_fit_bars(err, 0, device=True)
+    _check_fit_bars(err, 0, win.cpu().numpy().reshape(-1, 3, 3), device=True)
     ug = golden('uplift.npz')
     name = 'large_T50'
     sd = weights.random_uplift_state_dict(int(ug[name + '/meta'][0]), 'large')
