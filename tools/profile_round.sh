@@ -5,7 +5,7 @@
 # passes (never combined with a trace domain other than --kernel-trace) on tools/prof_cnn.py / tools/prof_argmax.py.
 # Raw output: gpurun_out/<tag>/...; summaries: gpurun_out/<tag>/summary/ (copied into profiles/ by the caller).
 set -u
-TAG=${1:-r2}; COMMIT=${2:-unknown}
+TAG=${1:-r3}; COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; S=$O/summary
 rm -rf $O; mkdir -p $S

@@ -1442,7 +1442,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         // Ragged region widths (38 / 36 / 34 px = two full 16-pixel groups + 6 / 4 / 2 px): the band walks the FULL groups only; the
         // leftover strip (RHO rows x RX columns) is packed 16 pixels at a time into "strip groups" whose lanes sit in different rows
         // -- 12 / 7 / 4 groups instead of 30 / 28 / 26 two-thirds-empty ones -- and handed to the waves with spare time: the last
-        // wave's band is short or empty (RHO is not a multiple of 8), so it takes the first K0 strip groups, the others one each.
+        // wave's band is short or empty (RHO is not a multiple of 8), so it takes the first K0 strip groups, the others one or two each.
         // Same k-step order and operands per output pixel as a band group: bit-identical results.
 #ifdef TTUP_NO_STRIP
         constexpr bool STRIP = false;
@@ -1487,8 +1487,14 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         if constexpr (STRIP) {
             constexpr int RX = RWO - XLAST, NSP = RHO * RX, NSG = (NSP + 15) / 16;
             constexpr int ROWS7 = RHO - 7 * RB < 0 ? 0 : (RHO - 7 * RB > RB ? RB : RHO - 7 * RB);      // band rows of the last wave
-            constexpr int K0 = NSG < 2 * (RB - ROWS7) ? NSG : 2 * (RB - ROWS7);                        // strip groups that fill its band's gap
-            static_assert(NSG - K0 <= 8, "one strip group per wave after the last wave's share");
+            // a strip group costs about two band groups (five fragment reads instead of three, one dependent MFMA chain, per-lane
+            // addresses): the last wave takes as many as fit in HALF of its band's gap (in band-group units), the rest go round
+#ifdef TTUP_STRIP_K0_FULL
+            constexpr int K0 = NSG < 2 * (RB - ROWS7) ? NSG : 2 * (RB - ROWS7);
+#else
+            constexpr int K0 = NSG < RB - ROWS7 ? NSG : RB - ROWS7;
+#endif
+            static_assert(NSG - K0 <= 16, "at most two strip groups per wave after the last wave's share");
             auto strip = [&](int j) __attribute__((always_inline)) {
                 const int p = 16 * j + n;
                 const bool valid = p < NSP;
@@ -1518,6 +1524,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 for (int j = 0; j < K0; ++j) strip(j);
             }
             if (K0 + wave < NSG) strip(K0 + wave);
+            if (NSG - K0 > 8 && K0 + 8 + wave < NSG) strip(K0 + 8 + wave);
         }
     }
 }
