@@ -443,10 +443,10 @@ def main():
                                     'fp32_full_frame_reruns': pipe.worker.fp32_reruns,
                                     'audited_frames': au['audited_frames'], 'audit_every_frames': pipe.worker.audit_every,
                                     'max_err_seen': round(au['max_err_seen'], 6), 'max_candidate_err': round(cs['max_candidate_err'], 6),
-                                    'max_err_over_eps': round(au['max_err_over_eps'], 4), 'eps_widened': au['widened'], 'recertified_clips': au['recertified_clips'],
+                                    'max_err_over_eps': round(au['max_err_over_eps'], 4), 'eps_widened': au['widened'], 'recertified_clips': au['recertified_clips'], 'recertified_heatmaps': au['recertified_heatmaps'],
                                     'note': 'an index is the fp32 argmax whenever |bf16 - fp32| <= eps on its frame (csrc/certify.hip); eps is audited inside the timed '
                                             'steps: one random frame per audit_every frames on the fp32 twin (side stream) + the error at every candidate of every crop; '
-                                            'it is widened and the clip re-run when max_err * 1.5 > eps.  Counts cover warm-up + timed steps'}
+                                            'eps = 1.5 x the largest error seen; a new maximum widens it and the heatmaps whose guard band (2 eps .. 2.5 eps below the maximum) is not empty are run again, the whole clip when eps grows by more than a quarter at once.  Counts cover warm-up + timed steps'}
     line['host_threads_per_rank'] = host_threads
     if collective is not None:
         line['collectives_per_step'] = 1

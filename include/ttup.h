@@ -121,8 +121,10 @@ int ttup_peak_hbm(size_t bytes, double* out_host, void* stream);
  * returns peaks re-evaluates the pixels within 2*eps_abs of the bf16 maximum on fp32 receptive-field crops (crop x crop pixels,
  * 0 = 168, the smallest that holds the 72-pixel receptive-field radius on both sides; at most max_crops_per_map per heatmap, 0 = 4) inside the same call, without host synchronisation, and returns the
  * fp32 winner and its fp32 3x3 window.  eps_abs < 0 switches it off.  csrc/certify.hip.
- * status (after a forward, per heatmap): 0 = one candidate (the bf16 index is certain), 1 = resolved on fp32 crops,
- * 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned).
+ * status (after a forward, per heatmap), bits 0-1: 0 = one candidate (the bf16 index is certain), 1 = resolved on fp32 crops,
+ * 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned); bit 2 (value 4): the GUARD band -- the pixels
+ * between 2*eps_abs and 2*1.25*eps_abs below the maximum -- is not empty: a heatmap WITHOUT that bit has the same candidates, and
+ * so the same certified result, under any eps up to 1.25*eps_abs (a caller that widens eps re-runs only the heatmaps with it).
  * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved,
  * bits of max |bf16 - fp32| seen at a candidate (a float in the low 32 bits: the free part of the eps audit), single-candidate
  * heatmaps cropped in exact-window mode}. */
@@ -181,6 +183,11 @@ void ttup_uplift_destroy(ttup_uplift* net);
 int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* table_dev, const float* mask_dev,
                         const float* times_dev, int batch, int len, float* rot_dev, float* pos_dev,
                         int check_mask, void* stream);
+
+/* Co-residency guard (on != 0): every workgroup of this handle's kernels reserves 84 KB of LDS, so that none shares a CU with a
+ * workgroup of the CNN's 16-channel chain kernel (measured: sharing a CU with it corrupts single words of the attention kernel's
+ * staged keys; csrc/uplift.hip).  For handles that run next to a CNN handle on other streams; off by default. */
+int ttup_uplift_set_isolated(ttup_uplift* net, int on);
 
 /* ---------------------------------------------------------------- a7: spin frame change
  * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */

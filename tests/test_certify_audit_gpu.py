@@ -111,6 +111,73 @@ def test_pipelined_repair_uses_the_tickets_own_status():
     assert n_flagged == worker.fp32_reruns
 
 
+def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
+    """eps is widened by 15 % between submit and collect (what a new error maximum does).  Heatmaps whose guard band -- the pixels
+    between 2 eps and 2.5 eps below the maximum -- is empty have the same candidate set under the new eps and keep their result;
+    only the others are run again (on the one-sample certified handle).  Every index must equal the fp32 path's, the count of
+    re-run heatmaps must equal the count of guard bits, and the whole clip must NOT be re-run."""
+    sd = weights.random_wasb_state_dict(21, planted=True, eps=1.0)          # planted peak + unscaled noise: a mix of clear peaks and near-ties
+    usd = weights.random_uplift_state_dict(3, 'large')
+    fr = torch.from_numpy(synth.synth_frames(14, H, W, seed=21)[0]).cuda()
+    worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=0)
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    worker.process_clip(fr, table_px, 60.0)
+    e0 = worker.certify_eps
+    t = worker.submit(fr)
+    torch.cuda.synchronize()
+    raw = t['status'].numpy().copy()
+    worker.certify_eps = worker.net.widen_eps(1.15 * e0 / worker.net.HEADROOM)
+    assert abs(worker.certify_eps - 1.15 * e0) < 1e-6 * e0
+    before = worker.recertified_heatmaps
+    o = worker.collect(t, table_px, 60.0)
+    n_guard = int(((raw & 4) != 0).sum())
+    print('\n%d of 12 heatmaps had a non-empty guard band and were run again; status %s' % (n_guard, raw.tolist()))
+    assert worker.recertified_heatmaps - before == n_guard and worker.recertified_clips == 0
+    ref_idx, ref_win, ref_xyv = _fp32_peaks(sd, fr, (W, H))
+    assert torch.equal(t['idx'], ref_idx)
+    # the same clip run from scratch under the widened eps gives the same detections
+    again = worker.process_clip(fr, table_px, 60.0)
+    assert torch.equal(again['xyv'], o['xyv'])
+
+
+def test_uplift_beside_the_cnn_is_bit_stable_with_the_co_residency_guard():
+    """The uplift transformer of clip k runs on a side stream while the detector of clip k+1 is busy.  Measured: when workgroups of
+    its attention / linear kernels share a CU with the CNN's 16-channel chain kernel, single words of the attention kernel's staged
+    keys come out wrong and pos3d moves by up to 4e-3 (csrc/uplift.hip, ttup_uplift_set_isolated; cause not understood).  With the
+    guard on (every uplift workgroup reserves 84 KB of LDS: no room beside a chain workgroup) the results must be bit-identical to
+    the ones of an idle GPU; without it the test only reports what it sees."""
+    from upliftingtabletennis_amd import uplift
+    usd = weights.random_uplift_state_dict(0, 'large')
+    up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=usd, max_batch=64, max_len=50)
+    args = [torch.from_numpy(a).cuda() for a in synth.synth_trajectories(3, 40, seed=3, pad=10)]
+    r0, p0 = up(*args)
+    r0, p0 = r0.clone(), p0.clone()
+    net = wasb.WASBNet(weights.random_wasb_state_dict(0, planted=True), resolution=(1280, 704), max_batch=16, dtype='bf16')
+    fr = torch.from_numpy(synth.synth_frames(18, 720, 1280, seed=1)[0]).cuda()
+    net.forward_frames(fr)
+    s1, side = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    seen = {}
+    for guard in (False, True):
+        up.isolate(guard)
+        bad, worst = 0, 0.0
+        for k in range(20):
+            with torch.cuda.stream(s1):
+                for _ in range(2):
+                    net.forward_frames(fr)
+            with torch.cuda.stream(side):
+                r, p = up(*args)
+            side.synchronize()
+            if not (torch.equal(r, r0) and torch.equal(p, p0)):
+                bad += 1
+                worst = max(worst, float((p - p0).abs().max()))
+            torch.cuda.synchronize()
+        seen[guard] = (bad, worst)
+    print('\nuplift beside the CNN: without the guard %d of 20 calls differ from the idle result (worst |dpos| %.2e); with it %d of 20'
+          % (seen[False][0], seen[False][1], seen[True][0]))
+    assert seen[True][0] == 0
+
+
 @pytest.mark.parametrize('lanes', ['1', '2'])
 def test_pipelined_small_clips_on_alternating_streams_do_not_share_buffers(monkeypatch, lanes):
     """Clips of <= one micro-batch run on ONE lane; consecutive submits alternate between two caller streams.  Different clips

@@ -33,12 +33,15 @@ __device__ __forceinline__ bool better(float v, long long i, float bv, long long
 // ---- 1. candidates of each heatmap of a micro-batch: heat (n_maps, hw) fp32, argmax (n_maps)
 __global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict__ heat, const long long* __restrict__ argmax, long long hw,
                                                         float two_eps, int K, int* __restrict__ cand_idx, int* __restrict__ cand_cnt,
-                                                        float* __restrict__ cand_bf) {
+                                                        float* __restrict__ cand_bf, float guard_two_eps, int* __restrict__ guard_cnt) {
     const int map = blockIdx.y;
     const float* h = heat + (size_t)map * hw;
     const float hmax = h[argmax[map]];
     if (hmax != hmax) return;                 // NaN maximum: torch.argmax returns the first NaN, which the bf16 pass already did
     const float thr = hmax - two_eps;
+    // guard band: pixels just below the candidate band, down to 2 * (GUARD * eps).  A heatmap without any keeps its candidate set
+    // -- and with it its certified result -- when eps is widened by up to the factor GUARD (the shim then re-runs only the others)
+    const float gthr = guard_cnt ? hmax - guard_two_eps : thr;
     const long long quads = hw / 4;
     const float4* h4 = (const float4*)h;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
@@ -49,13 +52,14 @@ __global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict_
             if (e[k] >= thr) {
                 const int slot = atomicAdd(&cand_cnt[map], 1);
                 if (slot < K) { cand_idx[(size_t)map * K + slot] = (int)(q * 4 + k); cand_bf[(size_t)map * K + slot] = e[k]; }
-            }
+            } else if (e[k] >= gthr) atomicAdd(&guard_cnt[map], 1);
     }
 }
 
 struct PlanArgs {
     int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats; float* cand_bf;
     int K, maxc, max_crops, H, W, Hc, Wc, R, map0, exact;
+    const int* guard_cnt;
 };
 
 // valid core of a crop along one axis: positions whose value AND 3x3 neighbourhood are exact
@@ -70,9 +74,10 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     const int map = a.map0 + blockIdx.x;
     const int cnt = a.cand_cnt[map];
     atomicAdd(&a.stats[0], 1ull);
+    const int gbit = a.guard_cnt[map] > 0 ? 4 : 0;          // status bit 2: the guard band is not empty
     // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
-    if (cnt <= 0 || (cnt == 1 && !a.exact)) { a.status[map] = 0; atomicAdd(&a.stats[1], 1ull); return; }
-    if (cnt > a.K) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+    if (cnt <= 0 || (cnt == 1 && !a.exact)) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); return; }
+    if (cnt > a.K) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
     if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
     int* ci = a.cand_idx + (size_t)map * a.K;
     float* cb = a.cand_bf + (size_t)map * a.K;
@@ -94,9 +99,9 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
             if (cy >= ylo && cy < yhi && cx >= xlo && cx < xhi) found = c;
         }
         if (found < 0) {
-            if (n_my >= a.maxc) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+            if (n_my >= a.maxc) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
             const int id = atomicAdd(a.n_crops, 1);
-            if (id >= a.max_crops) { a.status[map] = 2; atomicAdd(&a.stats[3], 1ull); return; }
+            if (id >= a.max_crops) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
             int y0 = ((cy - a.Hc / 2) / 8) * 8, x0 = ((cx - a.Wc / 2) / 8) * 8;
             y0 = y0 < 0 ? 0 : (y0 > a.H - a.Hc ? a.H - a.Hc : y0);
             x0 = x0 < 0 ? 0 : (x0 > a.W - a.Wc ? a.W - a.Wc : x0);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         }
         a.cand_crop[(size_t)map * a.K + k] = my_crop[found];
     }
-    a.status[map] = 1;
+    a.status[map] = 1 | gbit;
     atomicAdd(&a.stats[2], 1ull);
     atomicAdd(&a.stats[5], (unsigned long long)cnt);
 }
@@ -146,7 +151,7 @@ __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_maps * K) return;
     const int map = i / K, k = i % K;
-    if (status[map] != 1 || k >= cand_cnt[map]) return;
+    if ((status[map] & 3) != 1 || k >= cand_cnt[map]) return;
     const int id = cand_crop[i];
     if (id < crop0 || id >= crop0 + CH) return;
     const int* rec = crop_rec + 4 * id;
@@ -171,7 +176,7 @@ __global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int*
                                     const float* __restrict__ cand_val, const float* __restrict__ cand_win, int K, int n_maps,
                                     long long* __restrict__ argmax, float* __restrict__ win) {
     const int map = blockIdx.x * blockDim.x + threadIdx.x;
-    if (map >= n_maps || status[map] != 1) return;
+    if (map >= n_maps || (status[map] & 3) != 1) return;
     const int cnt = cand_cnt[map];
     float bv = cand_val[(size_t)map * K];
     long long bi = cand_idx[(size_t)map * K];
@@ -191,7 +196,7 @@ void cert_free(ttup_wasb* net) {
     CertState& c = net->cert;
     if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
     for (auto& sl : c.slot) {
-        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status};
+        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (sl.done) (void)hipEventDestroy(sl.done);
         sl = CertState::Slot();
@@ -210,6 +215,7 @@ int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
     CertState::Slot& sl = c.slot[c.cur];
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // the call that last used this slot has finished its fp32 passes
     TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.guard_cnt, 0, (size_t)batch * sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.n_crops, 0, sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.status, 0, (size_t)batch * sizeof(int), caller));
     return TTUP_OK;
@@ -222,12 +228,12 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     int nblk = (int)(hw / 4 / 256 / 8);           // 8 float4 per thread
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
-                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0, sl.cand_bf + (size_t)b0 * c.K);
+                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0, sl.cand_bf + (size_t)b0 * c.K, 2.f * c.eps * CertState::GUARD, sl.guard_cnt + b0);
     TTUP_LAUNCH_CHECK();
     PlanArgs a;
     a.cand_idx = sl.cand_idx; a.cand_cnt = sl.cand_cnt; a.cand_crop = sl.cand_crop; a.crop_rec = sl.crop_rec; a.n_crops = sl.n_crops;
     a.status = sl.status; a.stats = c.stats; a.cand_bf = sl.cand_bf; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
-    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0; a.exact = c.exact_windows ? 1 : 0;
+    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0; a.exact = c.exact_windows ? 1 : 0; a.guard_cnt = sl.guard_cnt;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -319,6 +325,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_crop, nb * c.K * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_val, nb * c.K * sizeof(float)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_bf, nb * c.K * sizeof(float)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.guard_cnt, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_win, nb * c.K * 9 * sizeof(float)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_crops, sizeof(int)));
@@ -356,7 +363,7 @@ extern "C" int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_de
     int nblk = (int)(hw / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, n_maps), dim3(256), 0, (hipStream_t)stream, heat_dev, (const long long*)argmax_dev, hw, 2.f * eps_abs, K,
-                       cand_idx_dev, cand_cnt_dev, cand_bf_dev);
+                       cand_idx_dev, cand_cnt_dev, cand_bf_dev, 0.f, (int*)nullptr);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }

@@ -39,6 +39,7 @@ struct Op {
 struct CertState {
     bool enabled = false;
     float eps = 0.f;                     // bound on |bf16 heatmap - fp32 heatmap| (absolute, calibrated by the caller)
+    static constexpr float GUARD = 1.25f;   // a heatmap with an empty guard band stays certified when eps is widened by up to this factor
     int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
     int K = 32;                          // candidates kept per heatmap
     int maxc = 4;                        // crops per heatmap
@@ -51,6 +52,7 @@ struct CertState {
     struct Slot {
         int* cand_idx = nullptr; int* cand_cnt = nullptr; int* cand_crop = nullptr; float* cand_val = nullptr; float* cand_win = nullptr;
         float* cand_bf = nullptr;           // the bf16 path's value of every candidate (audit: |bf16 - fp32| at the candidates is free)
+        int* guard_cnt = nullptr;           // pixels per heatmap in the guard band below the candidate band
         int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
         hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
     } slot[2];

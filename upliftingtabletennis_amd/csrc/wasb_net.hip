@@ -11,6 +11,7 @@
 //   * the batch is processed in micro-batches so that intermediate tensors stay near the Infinity Cache.
 #include "wasb_net.h"
 #include <string.h>
+#include <stdlib.h>
 #include <memory>
 
 using namespace ttup;
@@ -734,7 +735,9 @@ extern "C" int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_o
     TTUP_HIP_CHECK(hipEventCreate(&e1));
     int rc = TTUP_OK;
     net->use_lane(0);
+    static const int only_op = getenv("TTUP_TIME_ONLY_OP") ? atoi(getenv("TTUP_TIME_ONLY_OP")) : -1;      // debugging aid: time a single op
     for (int i = 0; i < n && rc == TTUP_OK; ++i) {
+        if (only_op >= 0 && i != only_op) { ms_out[i] = 0.f; op_info(net, i, info_out + 8 * i, nullptr); continue; }
         const Op& op = net->ops[i];
         auto once = [&]() { return (op.kind == Op::UPSUM_HEAD || op.head) ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st); };
         rc = once();                       // warm-up launch of this op

@@ -107,7 +107,7 @@ class BallDetector:
                 heat, idx, win = m.forward(x, want_heatmap=True, want_peaks=True)
                 if not m.certified:
                     break
-                status, info = m.certify_status(x.shape[0]), m.certify_info()
+                status, info = m.certify_status(x.shape[0]), m.certify_info()          # (masked status: the float entry re-runs the whole chunk on a widening)
                 err = m.note_error(m.decode_info(info.cpu().numpy())[1])
                 for t in picks:        # eps audit: the bf16 heatmap of a random triple against the fp32 twin
                     err = max(err, m.note_error(float((heat[t] - m._twin().forward(x[t:t + 1])[0][0]).abs().max().item()), 1))
@@ -161,18 +161,23 @@ class BallDetector:
         picks = self._audit_picks(fr.shape[0] - 2)
         while True:
             audit = m.audit_async(fr, picks) if picks else None
+            eps_used = m.eps if m.certified else None
             _, idx, win = m.forward_frames(fr, want_heatmap=False)
             if not m.certified:
                 return idx, win
-            status, info = m.certify_status(idx.shape[0]), m.certify_info()
+            status, info = m.certify_status(idx.shape[0], raw=True), m.certify_info()
             err = m.note_error(m.decode_info(info.cpu().numpy())[1])
             if audit is not None:
                 err = max(err, m.audit_result(audit))
             picks = []
+            st = status.cpu().numpy()
             if m.eps_violated(err):
                 m.widen_eps(err)
-                continue
-            m.fix_uncertified(idx, win, frames_u8=fr, status=status)
+                todo = m.recertify_subset(idx, win, st, eps_used, fr)       # only the heatmaps whose guard band is not empty
+                if todo is None:
+                    continue                                              # eps grew past the guard factor: the whole call again
+                st[todo] = 1
+            m.fix_uncertified(idx, win, frames_u8=fr, status=st)
             return idx, win
 
     def predict_clip(self, images):
@@ -308,6 +313,7 @@ class TableTennisPipeline:
         # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
         self.table_detector.model.set_priority(True)
         self.uplifting_model = UpliftingModel()
+        self.uplifting_model.model.isolate(True)        # may run beside the detectors of a following call (co-residency guard)
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
 
     def predict(self, images, fps):
@@ -379,7 +385,7 @@ class TableTennisPipeline:
                     fr = frames[t_next:t_next + nt + 2]
                     _, idx, win = bd.model.forward_frames(fr, want_heatmap=False)
                     # status / info of THIS call, copied right behind it (the handle's per-call slot flips with the next call)
-                    status = bd.model.certify_status(nt) if bd.model.certified else None
+                    status = bd.model.certify_status(nt, raw=True) if bd.model.certified else None
                     info = bd.model.certify_info() if bd.model.certified else None
                     ball_calls.append((t_next, nt, idx, win, status, info, bd.model.eps if bd.model.certified else None))
                 t_next += nt
@@ -412,12 +418,19 @@ class TableTennisPipeline:
             if m.eps_violated(err):
                 m.widen_eps(err)
         for (t0, nt, idx, win, status, info, eps_used) in ball_calls:
-            if status is not None and eps_used < m.eps:
-                # rare: an audit found eps too small -> this call again under the widened eps (audited, blocking)
-                idx, win = bd._certified_peaks(frames[t0:t0 + nt + 2])
-            elif status is not None and (status.cpu().numpy() == 2).any():
+            st = status.cpu().numpy() if status is not None else None
+            if st is not None and eps_used < m.eps:
+                # an audit found eps too small: the heatmaps of this call whose guard band is not empty are run again under the
+                # widened eps; the whole call only when eps grew past the guard factor (audited, blocking; rare)
+                todo = m.recertify_subset(idx, win, st, eps_used, frames[t0:t0 + nt + 2])
+                if todo is None:
+                    idx, win = bd._certified_peaks(frames[t0:t0 + nt + 2])
+                    st = None
+                else:
+                    st[todo] = 1
+            if st is not None and ((st & 3) == 2).any():
                 # rare: crop budget exceeded -> those frames on the full-frame fp32 path (with the call's own status)
-                m.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2], status=status)
+                m.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2], status=st)
             ball_out.append(refine.refine_windows_device(idx, win, bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
         pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
         return pos, kp

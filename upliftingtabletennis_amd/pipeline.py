@@ -101,8 +101,9 @@ class StreamWorker:
     Certified argmax (`certify=True`, bf16): eps -- the bound on |bf16 heatmap - fp32 heatmap| the certification rests on -- is
     estimated on the first clip and then AUDITED while the worker runs: one random triple per `audit_every` triples is re-run on
     the fp32 twin on a side stream, and every fp32 crop the certification computes anyway reports the error at its candidates.
-    eps starts at 1.75 times the largest error of the calibration frames; when an observed error comes within the safety factor (1.5) of
-    eps, eps is widened (to 1.75 times that error) and the clips certified under the old value are re-run.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
+    eps is 1.5 times the largest error seen so far (calibration frames, audits); a new maximum widens it, and of the clips certified
+    under the old value only the heatmaps whose guard band (pixels between 2 eps and 2.5 eps below the maximum) is not empty are
+    run again -- the whole clip only when eps grows by more than a quarter at once.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
                  traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False):
@@ -117,12 +118,14 @@ class StreamWorker:
         self.max_segments = max(64, (max_triples + traj_len - 1) // traj_len)
         self.up = uplift.get_model('connectstage', uplift_size, 'dynamic', 'new', state_dict=uplift_state_dict,
                                    max_batch=self.max_segments, max_len=seq_len, device=self.device)
+        self.up.isolate(True)          # the uplift of clip k runs beside the detector of clip k+1 (csrc/uplift.hip, co-residency guard)
         # certified argmax (the fp32 path's indices from the bf16 path, csrc/certify.hip): calibrated on the first clip seen
         self.certify = bool(certify) and dtype == 'bf16'
         self.exact_windows = bool(exact_windows)
         self.certify_eps = None
         self.fp32_reruns = 0
         self.recertified_clips = 0
+        self.recertified_heatmaps = 0
         self.audit_every = int(audit_every)
         self._since_audit = 0
         self._rng = np.random.default_rng(audit_seed)
@@ -139,6 +142,7 @@ class StreamWorker:
         a['eps'] = self.certify_eps
         a['max_err_over_eps'] = (a['max_err_seen'] / self.certify_eps) if self.certify_eps else None
         a['recertified_clips'] = self.recertified_clips
+        a['recertified_heatmaps'] = self.recertified_heatmaps
         return a
 
     def detect(self, frames_u8):
@@ -162,7 +166,7 @@ class StreamWorker:
         xyv = self._refine.refine_windows_device(idx, win, self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
         # status and info belong to THIS call: both are copied right behind it in stream order, before another call can flip the
         # handle's per-call slot
-        status = self.net.certify_status(idx.shape[0]) if self.certify else None
+        status = self.net.certify_status(idx.shape[0], raw=True) if self.certify else None          # bit 2 = guard band not empty
         info = self.net.certify_info() if self.certify else None
         return xyv, idx, win, status, info
 
@@ -181,7 +185,7 @@ class StreamWorker:
         """Rare slow path: heatmaps the certified argmax could not settle inside its crop budget are re-run on the full-frame
         fp32 handle, so that every detection comes from the fp32 argmax.  `status_host` is the status of the call that produced
         idx / win (not of whatever the handle ran last)."""
-        bad = np.nonzero(status_host == 2)[0]
+        bad = np.nonzero((status_host & 3) == 2)[0]
         if bad.size == 0:
             return xyv
         self.fp32_reruns += self.net.fix_uncertified(idx, win, frames_u8=frames_u8, status=status_host)
@@ -219,9 +223,23 @@ class StreamWorker:
         spin = self._uplift.transform_rotationaxes(rot, p3)
         return spin, p3, mask.sum(1).to(torch.int64).to(self.device)
 
+    def _recertify(self, frames_u8, xyv, idx, win, status_host, eps_used):
+        """The clip was certified under `eps_used` and eps has grown since.  Heatmaps with an empty guard band keep their result; the
+        others are run again under the current eps (`WASBNet.recertify_subset`).  Returns the updated xyv, or None when eps grew
+        past the guard factor and the whole clip has to be run again."""
+        todo = self.net.recertify_subset(idx, win, status_host, eps_used, frames_u8)
+        if todo is None:
+            return None
+        self.recertified_heatmaps += int(todo.size)
+        if todo.size:
+            sel = torch.as_tensor(todo, device=self.device)
+            xyv[sel] = self._refine.refine_windows_device(idx[sel], win[sel], self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
+            status_host[todo] = 1          # settled under the current eps (repaired inside when over budget)
+        return xyv
+
     def _detect_blocking(self, frames_u8):
         """One clip, start to finish, with the audit folded in: (xyv device tensor) whose every index is certified under the
-        current eps.  Loops only when an audit widens eps (then at most a couple of times: eps only grows)."""
+        current eps.  Loops only when an audit widens eps past the guard factor (eps only grows)."""
         while True:
             eps_used = self._calibrated(frames_u8)
             ticket = self._start_audit(frames_u8)
@@ -229,10 +247,14 @@ class StreamWorker:
             if status is None:
                 return xyv
             n_crops, cand_err = self.net.decode_info(info.cpu().numpy())
+            st = status.cpu().numpy()
             if self._after_clip(n_crops, cand_err, ticket) or eps_used < self.certify_eps:
-                self.recertified_clips += 1
-                continue
-            return self._repair(frames_u8, xyv, idx, win, status.cpu().numpy())
+                out = self._recertify(frames_u8, xyv, idx, win, st, eps_used)
+                if out is None:
+                    self.recertified_clips += 1
+                    continue
+                xyv = out
+            return self._repair(frames_u8, xyv, idx, win, st)
 
     def process_clip(self, frames_u8, table_px, fps):
         xyv = self._detect_blocking(frames_u8)
@@ -291,13 +313,19 @@ class StreamWorker:
         if ticket.get('status') is not None:
             n_crops, cand_err = self.net.decode_info(ticket['info'].numpy())
             widened = self._after_clip(n_crops, cand_err, ticket.get('audit'))
+            st = ticket['status'].numpy()
             if widened or ticket['eps'] < self.certify_eps:
-                # this clip was certified under an eps that an audit has since found too small: run it again (blocking; rare)
-                self.recertified_clips += 1
-                ticket['xyv'] = self._detect_blocking(ticket['frames'])
+                # this clip was certified under an eps that an audit has since found too small: the heatmaps whose guard band is
+                # not empty are run again (a few per clip); the whole clip only when eps grew past the guard factor (blocking; rare)
+                out = self._recertify(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], st, ticket['eps'])
+                if out is None:
+                    self.recertified_clips += 1
+                    out = self._detect_blocking(ticket['frames'])
+                    st = None
+                ticket['xyv'] = out
                 ticket['host'].copy_(ticket['xyv'])
-            elif (ticket['status'].numpy() == 2).any():
-                ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], ticket['status'].numpy())
+            if st is not None and ((st & 3) == 2).any():
+                ticket['xyv'] = self._repair(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], st)
                 ticket['host'].copy_(ticket['xyv'])
         # the uplift (about a hundred small launches for a handful of trajectories) runs on a side stream, so it shares
         # the GPU with the detector of the clip submitted in the meantime instead of queueing behind it
@@ -313,7 +341,7 @@ class StreamWorker:
         cur = torch.cuda.current_stream(self.device)
         for t in (spin, p3, nvalid):
             t.record_stream(cur)
-        status_host = None if ticket.get('status') is None else ticket['status'].numpy().copy()
+        status_host = None if ticket.get('status') is None else (ticket['status'].numpy() & 3)          # 0 / 1 / 2 (guard bit dropped)
         for k in ('host', 'status', 'info'):
             self._unpin('xyv' if k == 'host' else k, ticket.get(k))
             ticket[k] = None

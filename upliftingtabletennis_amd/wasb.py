@@ -106,7 +106,8 @@ class WASBNet:
     # an empirical bound -- measured (`calibrate`), then audited for as long as the handle runs (`audit_async` / the candidate-level
     # error the crops give for free, `certify_info`) and widened when an audit comes within the safety factor of it.
     SAFETY = 1.5           # an observed error within this factor of eps triggers a widening (and a re-run of the affected work)
-    HEADROOM = 1.75        # eps is set to this factor times the largest error seen: a new maximum up to a sixth above the old one fits
+    HEADROOM = 1.5         # eps is set to this factor times the largest error seen (= SAFETY: every new maximum widens eps -- which is cheap:
+                           # only the heatmaps whose guard band is not empty are run again, `recertify_subset`)
 
     def set_certify(self, eps_abs, crop=0, max_crops_per_map=0, exact_windows=None):
         """eps_abs bounds |bf16 heatmap - fp32 heatmap|; < 0 switches the certification off.  exact_windows=True: every heatmap
@@ -221,12 +222,16 @@ class WASBNet:
         """Crops the following forward calls may use (saves empty fp32 passes when the typical count is known)."""
         _lib.check(self._lib.ttup_wasb_certify_budget(self._handle, int(max_crops)))
 
-    def certify_status(self, batch):
-        """Per-heatmap status of the last forward: 0 single candidate, 1 resolved on fp32 crops, 2 not certified."""
+    GUARD = 1.25           # csrc/wasb_net.h CertState::GUARD: widening eps by up to this factor keeps heatmaps with an empty guard band valid
+
+    def certify_status(self, batch, raw=False):
+        """Per-heatmap status of the last forward: 0 single candidate, 1 resolved on fp32 crops, 2 not certified.
+        raw=True keeps bit 2 (value 4): the guard band below the candidate band is NOT empty, i.e. the heatmap has to be run again
+        when eps is widened (heatmaps without it keep their result under any eps up to GUARD times the one they ran with)."""
         st = torch.empty((batch,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ttup_wasb_certify_status(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
-        return st
+        return st if raw else st & 3
 
     def certify_info(self):
         """(2,) int32 device tensor of the last forward, in stream order: [crops it asked for, bits of the largest |bf16 - fp32|
@@ -257,7 +262,7 @@ class WASBNet:
             raise ValueError('fix_uncertified covers one forward call of at most max_batch=%d heatmaps' % self.max_batch)
         if status is None:
             status = self.certify_status(idx.shape[0])
-        st = status.cpu().numpy() if torch.is_tensor(status) else np.asarray(status)
+        st = (status.cpu().numpy() if torch.is_tensor(status) else np.asarray(status)) & 3
         bad = np.nonzero(st == 2)[0]
         if bad.size:
             twin = self._twin()
@@ -268,6 +273,35 @@ class WASBNet:
                 idx[t] = i1[0]
                 win[t] = w1[0]
         return int(bad.size)
+
+    def recertify_subset(self, idx, win, status_raw, eps_used, frames_u8):
+        """eps has been widened since the call that produced (idx, win, status_raw) from the uint8 clip `frames_u8`.  Heatmaps whose
+        guard band was empty keep their certified result (same candidate set under any eps up to GUARD * eps_used); the others are
+        run again one triple at a time under the current eps and repaired on the fp32 handle if they overflow the budget.  Returns the indices re-run, or None when eps grew past the guard factor (the caller then re-runs the
+        whole call)."""
+        if self.eps > eps_used * self.GUARD * (1 - 1e-6):
+            return None
+        st = status_raw.cpu().numpy() if torch.is_tensor(status_raw) else np.asarray(status_raw)
+        todo = np.nonzero((st & 4) != 0)[0]
+        if todo.size == 0:
+            return todo
+        # a one-sample certified handle of its own (same weights, same per-tile arithmetic as the production handle: its bf16
+        # heatmaps are bit-identical, tests/test_certify_audit_gpu.py): the re-runs never touch the production handle's lanes or its
+        # per-call certification slots, which a clip in flight may still be using
+        h = self.__dict__.get('_recert')
+        if h is None:
+            h = self._recert = WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='bf16', device=self.device)
+            h._f32_twin = self._twin()
+        if not h.certified or h.eps != self.eps or h.exact_windows != self.exact_windows:
+            h.set_certify(self.eps, exact_windows=self.exact_windows)
+        for t in todo:
+            t = int(t)
+            fr = frames_u8[t:t + 3]
+            _, i1, w1 = h.forward_frames(fr, want_heatmap=False)
+            h.fix_uncertified(i1, w1, frames_u8=fr, status=h.certify_status(1))
+            idx[t] = i1[0]
+            win[t] = w1[0]
+        return todo
 
     def set_priority(self, high=True):
         """Run this handle's kernels ahead of (high) / behind other handles sharing the GPU."""
