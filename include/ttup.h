@@ -184,11 +184,6 @@ int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* ta
                         const float* times_dev, int batch, int len, float* rot_dev, float* pos_dev,
                         int check_mask, void* stream);
 
-/* Co-residency guard (on != 0): every workgroup of this handle's kernels reserves 84 KB of LDS, so that none shares a CU with a
- * workgroup of the CNN's 16-channel chain kernel (measured: sharing a CU with it corrupts single words of the attention kernel's
- * staged keys; csrc/uplift.hip).  For handles that run next to a CNN handle on other streams; off by default. */
-int ttup_uplift_set_isolated(ttup_uplift* net, int on);
-
 /* ---------------------------------------------------------------- a7: spin frame change
  * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */
 int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream);

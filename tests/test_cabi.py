@@ -31,6 +31,44 @@ def test_header_symbols_exported(lib):
     assert lib.ttup_version() >= 100
 
 
+def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):
+    """csrc/common.h: v_pk_*_f32 instructions that carry op_sel / op_sel_hi / neg modifiers were measured to return wrong values on
+    gfx950 beside another kernel's LDS-fed MFMAs (tools/pk_coresidency_repro.hip).  The shipped library must contain none: every
+    gfx950 code object of libttup.so is disassembled and scanned (the plain element-wise forms are fine and stay)."""
+    import struct
+    objcopy, objdump = '/opt/rocm/lib/llvm/bin/llvm-objcopy', '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not (os.path.exists(objcopy) and os.path.exists(objdump)):
+        pytest.skip('llvm binutils not found')
+    fat = tmp_path / 'fat.bin'
+    subprocess.run([objcopy, '--dump-section', '.hip_fatbin=%s' % fat, _lib.LIB_PATH, str(tmp_path / 'stripped.so')], check=True)
+    data = fat.read_bytes()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    n_objects, n_packed, bad = 0, 0, []
+    start = data.find(magic)
+    while start >= 0:
+        (n_entries,) = struct.unpack_from('<Q', data, start + len(magic))
+        p = start + len(magic) + 8
+        for _ in range(n_entries):
+            off, size, tlen = struct.unpack_from('<QQQ', data, p)
+            triple = data[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if 'gfx950' not in triple or size == 0:
+                continue
+            co = tmp_path / ('dev%d.co' % n_objects)
+            co.write_bytes(data[start + off:start + off + size])
+            n_objects += 1
+            asm = subprocess.run([objdump, '-d', '--no-show-raw-insn', str(co)], check=True, capture_output=True, text=True).stdout
+            for line in asm.splitlines():
+                if re.search(r'v_pk_[a-z]+_f32', line):
+                    n_packed += 1
+                    if re.search(r'op_sel|neg_lo|neg_hi', line):
+                        bad.append(line.strip())
+        start = data.find(magic, start + 1)
+    assert n_objects >= 8, 'expected one gfx950 code object per translation unit, found %d' % n_objects
+    assert n_packed > 0, 'the scan found no packed fp32 instruction at all: is the disassembly empty?'
+    assert not bad, '%d swizzled packed fp32 instructions, e.g. %s' % (len(bad), bad[:3])
+
+
 def test_argument_validation_without_gpu(lib):
     assert lib.ttup_refine_windows(None, None, 1, 4, 4, 10, 10, 0, None, None) == _lib.EINVAL
     assert b'null' in lib.ttup_last_error()

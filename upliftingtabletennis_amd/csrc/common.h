@@ -31,6 +31,21 @@ void set_error(const char* fmt, ...);   // thread-local, returned by ttup_last_e
 
 #define TTUP_LAUNCH_CHECK()  TTUP_HIP_CHECK(hipGetLastError())
 
+// Packed fp32 instructions WITH operand swizzles (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 carrying op_sel, op_sel_hi or neg
+// modifiers) return wrong values on MI355X (gfx950, ROCm 7.2.0) while a wave of ANOTHER kernel on the same CU feeds MFMAs from LDS
+// reads -- which the CNN's chain kernels do all the time.  Measured with tools/pk_coresidency_repro.hip: 24 % of the results of a
+// 20-line rotation kernel are wrong beside a 20-line ds_read -> MFMA loop, none with the same source compiled without packed fp32;
+// the plain element-wise forms (all that the convolution epilogues contain) are not affected.  Translation units whose fp32
+// vector code the compiler turns into swizzled packed forms (the uplift transformer's RoPE / softmax arithmetic, the refine fit)
+// bracket their device code with these two; tests/test_cabi.py checks the device ISA of the whole library for such instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TTUP_NO_PACKED_FP32_BEGIN _Pragma("clang attribute push(__attribute__((target(\"no-packed-fp32-ops\"))), apply_to = function)")
+#define TTUP_NO_PACKED_FP32_END _Pragma("clang attribute pop")
+#else
+#define TTUP_NO_PACKED_FP32_BEGIN
+#define TTUP_NO_PACKED_FP32_END
+#endif
+
 typedef uint16_t bf16_t;   // raw bits
 
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {

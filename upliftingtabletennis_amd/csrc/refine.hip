@@ -9,6 +9,9 @@
 //   torch.argmax), gathers the zero-padded window and stores index + window.
 // Kernel 3 (fit): one lane per map runs the L-BFGS-B fit of lbfgsb.h in fp64 and rescales to image pixels.
 #include "common.h"
+
+TTUP_NO_PACKED_FP32_BEGIN      // the fit runs beside the CNN of the next micro-batch (common.h)
+
 #include "lbfgsb.h"
 
 namespace ttup {
@@ -270,3 +273,5 @@ extern "C" int ttup_refine(const float* heat_dev, int n_maps, int height, int wi
     if (!out_xyv_dev) return TTUP_OK;
     return ttup_refine_windows((const int64_t*)am, wn, n_maps, height, width, img_w, img_h, variant, out_xyv_dev, stream);
 }
+
+TTUP_NO_PACKED_FP32_END

@@ -23,6 +23,8 @@
 
 using namespace ttup;
 
+TTUP_NO_PACKED_FP32_BEGIN      // this unit's kernels run beside the CNN's chain kernels (common.h)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -376,9 +378,6 @@ struct ttup_uplift {
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *x2 = nullptr, *tok = nullptr, *ttok = nullptr, *h1 = nullptr;
     float *m1 = nullptr, *m2 = nullptr, *tmask = nullptr, *txy = nullptr, *tmp_small = nullptr;
     int* flags_dev = nullptr;
-    // Workgroups of this handle's kernels reserve ISOLATED_LDS bytes of LDS each, so that none of them shares a CU with a workgroup
-    // of the CNN's 16-channel chain (77.5 KB each, two per CU): see ttup_uplift_set_isolated
-    bool isolated = false;
     ~ttup_uplift() { for (void* p : allocs) if (p) (void)hipFree(p); }
 };
 
@@ -467,9 +466,6 @@ int make_head(ttup_uplift* net, Reader& r, Head* h) {
     return make_linear(net, r, 3, D / 4, true, &h->fc3);
 }
 
-constexpr size_t ISOLATED_LDS = 84 * 1024;          // > 160 KB - 77.5 KB: no room beside a workgroup of bb_chain2_kernel
-thread_local bool g_isolated = false;                // set by ttup_uplift_forward around its launches
-
 int run_linear(const Linear& L, const float* x, int ldx, long long M, const float* gamma, const float* beta, int relu,
                const float* res, int ldr, float* out, int ldo, hipStream_t st) {
     if (M == 0) return TTUP_OK;
@@ -488,8 +484,7 @@ int run_linear(const Linear& L, const float* x, int ldx, long long M, const floa
     const bool big = M >= 128 * 512;
     const int ntw = L.n > 128 ? 3 : L.n > 64 ? 2 : 1;
     const int bm = big ? 128 : 64;
-    size_t smem = (size_t)4 * bm * (L.k / 4 + 4) * sizeof(float);
-    if (g_isolated && smem < ISOLATED_LDS) smem = ISOLATED_LDS;
+    const size_t smem = (size_t)4 * bm * (L.k / 4 + 4) * sizeof(float);
     const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((L.n + 64 * ntw - 1) / (64 * ntw)));
 #define TTUP_LIN(LN_, NTW_, MH_)                                                                                              \
     do {                                                                                                                      \
@@ -515,12 +510,7 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
     const int S = a.S;
     const int P = S <= 16 ? 16 : S <= 32 ? 32 : S <= 64 ? 64 : 128;
     const int threads = P == 128 ? 128 : 64, G = threads / P;
-    size_t smem = ((size_t)G * (2 * S * HD + 16) + (size_t)G * S) * sizeof(float);
-    if (g_isolated && smem < ISOLATED_LDS) {
-        smem = ISOLATED_LDS;
-        (void)ensure_max_lds((const void*)attention_kernel<HD, 16>, 160 * 1024); (void)ensure_max_lds((const void*)attention_kernel<HD, 32>, 160 * 1024);
-        (void)ensure_max_lds((const void*)attention_kernel<HD, 64>, 160 * 1024); (void)ensure_max_lds((const void*)attention_kernel<HD, 128>, 160 * 1024);
-    }
+    const size_t smem = ((size_t)G * (2 * S * HD + 16) + (size_t)G * S) * sizeof(float);
     const dim3 grid((unsigned)((a.n_seq + G - 1) / G), a.heads);
     switch (P) {
         case 16: hipLaunchKernelGGL((attention_kernel<HD, 16>), grid, dim3(threads), smem, st, a); break;
@@ -697,20 +687,6 @@ extern "C" int ttup_uplift_create(const void* blob, size_t blob_bytes, int max_b
     return TTUP_OK;
 }
 
-// Co-residency guard.  Measured on MI355X (ROCm 7.2): when workgroups of this handle's attention / linear kernels share a CU with
-// workgroups of the CNN's bb_chain2_kernel, single dwords of the attention kernel's staged K rows come out wrong (a 32-bit word that
-// looks like a bf16 pair of the chain; pos3d off by up to 4e-3) -- only with the chain's MFMAs executing, only on a shared CU, never
-// with any other kernel of the library, torch's kernels or the fp32 path as the victim or the aggressor; every access of both kernels
-// is inside its own LDS allocation and register budget.  The cause is not understood; the guard is: with
-// isolation on, every workgroup of this handle reserves 84 KB of LDS, which leaves no room for it beside a 77.5-KB chain workgroup.
-// Callers that run the uplift next to the CNN (StreamWorker, the hub pipeline) switch it on; a stand-alone uplift (config 3) keeps
-// four workgroups per CU.
-extern "C" int ttup_uplift_set_isolated(ttup_uplift* net, int on) {
-    TTUP_REQUIRE(net, TTUP_EINVAL, "ttup_uplift_set_isolated: null handle");
-    net->isolated = on != 0;
-    return TTUP_OK;
-}
-
 extern "C" void ttup_uplift_destroy(ttup_uplift* net) {
     if (!net) return;
     (void)hipDeviceSynchronize();
@@ -724,7 +700,6 @@ extern "C" int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, cons
     TTUP_REQUIRE(len > 0 && len <= net->max_len, TTUP_EINVAL, "ttup_uplift_forward: sequence length %d outside [1,%d]", len, net->max_len);
     hipStream_t st = (hipStream_t)stream;
     if (batch == 0) return TTUP_OK;
-    struct Iso { Iso(bool v) { g_isolated = v; } ~Iso() { g_isolated = false; } } iso(net->isolated);
     TTUP_HIP_CHECK(hipMemsetAsync(net->flags_dev, 0, sizeof(int), st));
     const long long cap = net->chunk;      // scratch is sized for `chunk` trajectories of max_len tokens
     for (int b0 = 0; b0 < batch; b0 += (int)cap) {
@@ -752,3 +727,5 @@ extern "C" int ttup_transform_rotationaxes(const float* rot_dev, const float* po
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
+
+TTUP_NO_PACKED_FP32_END

@@ -313,7 +313,6 @@ class TableTennisPipeline:
         # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
         self.table_detector.model.set_priority(True)
         self.uplifting_model = UpliftingModel()
-        self.uplifting_model.model.isolate(True)        # may run beside the detectors of a following call (co-residency guard)
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
 
     def predict(self, images, fps):

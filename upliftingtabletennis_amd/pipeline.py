@@ -118,7 +118,6 @@ class StreamWorker:
         self.max_segments = max(64, (max_triples + traj_len - 1) // traj_len)
         self.up = uplift.get_model('connectstage', uplift_size, 'dynamic', 'new', state_dict=uplift_state_dict,
                                    max_batch=self.max_segments, max_len=seq_len, device=self.device)
-        self.up.isolate(True)          # the uplift of clip k runs beside the detector of clip k+1 (csrc/uplift.hip, co-residency guard)
         # certified argmax (the fp32 path's indices from the bf16 path, csrc/certify.hip): calibrated on the first clip seen
         self.certify = bool(certify) and dtype == 'bf16'
         self.exact_windows = bool(exact_windows)

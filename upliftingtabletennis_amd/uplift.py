@@ -28,11 +28,6 @@ class MultiStageModel:
     def to(self, *a, **k):
         return self
 
-    def isolate(self, on=True):
-        """Co-residency guard (ttup_uplift_set_isolated): for a model that runs next to a CNN handle on other streams."""
-        _lib.check(self._lib.ttup_uplift_set_isolated(self._handle, 1 if on else 0))
-        return self
-
     def __del__(self):
         h, self._handle = getattr(self, '_handle', None), None
         if h:
