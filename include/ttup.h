@@ -135,6 +135,10 @@ int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops
  * caller) counts ALL of them, also those past K. */
 int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_dev, int n_maps, int height, int width, float eps_abs, int K,
                       int* cand_idx_dev, int* cand_cnt_dev, float* cand_bf_dev, void* stream);
+/* max |a - b| over n floats -> out_dev[0] (device, written on `stream`; NaN anywhere gives NaN).  The eps audit's error measure
+ * (upliftingtabletennis_amd/wasb.py: heatmap_error): one pass over the two heatmaps instead of three torch kernels, and free of
+ * packed fp32 instructions, which must not run beside the CNN (csrc/common.h). */
+int ttup_max_abs_diff(const float* a_dev, const float* b_dev, long long n, float* out_dev, void* stream);
 /* exact-window mode (on != 0): heatmaps with ONE candidate get an fp32 crop too, so that every returned 3x3 window -- not only
  * the near-ties' -- holds the fp32 path's values and the sub-pixel fit sees what the reference's fit sees (one 168x168 fp32
  * pass per heatmap: a parity / audit mode, off by default) */

@@ -46,6 +46,23 @@ def test_audit_twin_recomputes_the_production_heatmap_bit_for_bit():
     assert all(0.25 * e < v <= 1.25 * e for v in strips), (e, strips)
 
 
+def test_max_abs_diff_equals_the_torch_expression():
+    """ttup_max_abs_diff (the audit's error measure) == (a - b).abs().max(), bit for bit; ragged sizes, zero size, NaN."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for n in (1, 63, 4097, 704 * 1280, 3 * 704 * 1280 + 5):
+        a = torch.randn((n,), device='cuda', generator=g)
+        b = a + 1e-3 * torch.randn((n,), device='cuda', generator=g)
+        assert torch.equal(wasb.max_abs_diff(a, b), (a - b).abs().max())
+    assert float(wasb.max_abs_diff(a[:0], b[:0])) == 0.0
+    assert float(wasb.max_abs_diff(a, a)) == 0.0
+    b[1234] = float('nan')
+    assert torch.isnan(wasb.max_abs_diff(a, b))
+    b[1234] = float('inf')
+    assert float(wasb.max_abs_diff(a, b)) == float('inf')
+    with pytest.raises(ValueError):
+        wasb.max_abs_diff(a, b[:-1])
+
+
 def test_eps_audit_widens_on_brighter_frames_and_recertifies():
     """eps is calibrated on a dark clip; a later, much brighter clip has a larger bf16 error.  The side-stream audit (here one in
     two triples) must notice, widen eps and re-run the clip, after which every index is the fp32 argmax and the observed error sits

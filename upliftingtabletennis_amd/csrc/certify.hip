@@ -368,6 +368,37 @@ extern "C" int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_de
     return TTUP_OK;
 }
 
+// The audit's error measure, max |a - b| over n floats, in one pass and without torch's element-wise kernels (the audits run on a
+// side stream beside the CNN: no packed fp32 here, common.h).  NaN anywhere gives NaN (its bit pattern orders above +inf).
+TTUP_NO_PACKED_FP32_BEGIN
+namespace ttup { namespace {
+__global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    bool nan = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = fabsf(a[i] - b[i]);
+        nan |= d != d;
+        m = d > m ? d : m;
+    }
+    unsigned bits = nan ? 0x7fc00000u : __float_as_uint(m);            // non-negative floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(bits, off, 64); bits = o > bits ? o : bits; }
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
+}
+} }
+TTUP_NO_PACKED_FP32_END
+
+extern "C" int ttup_max_abs_diff(const float* a_dev, const float* b_dev, long long n, float* out_dev, void* stream) {
+    TTUP_REQUIRE(a_dev && b_dev && out_dev && n >= 0, TTUP_EINVAL, "ttup_max_abs_diff: bad argument");
+    TTUP_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), (hipStream_t)stream));
+    if (n == 0) return TTUP_OK;
+    long long nblk = (n + 256 * 16 - 1) / (256 * 16);
+    nblk = nblk > 2048 ? 2048 : nblk;
+    hipLaunchKernelGGL(max_abs_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev, n, (unsigned*)out_dev);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 extern "C" int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on) {
     TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_exact_windows: the certified argmax is not enabled on this handle");
     net->cert.exact_windows = on != 0;

@@ -110,7 +110,7 @@ class BallDetector:
                 status, info = m.certify_status(x.shape[0]), m.certify_info()          # (masked status: the float entry re-runs the whole chunk on a widening)
                 err = m.note_error(m.decode_info(info.cpu().numpy())[1])
                 for t in picks:        # eps audit: the bf16 heatmap of a random triple against the fp32 twin
-                    err = max(err, m.note_error(float((heat[t] - m._twin().forward(x[t:t + 1])[0][0]).abs().max().item()), 1))
+                    err = max(err, m.note_error(float(wasb.max_abs_diff(heat[t], m._twin().forward(x[t:t + 1])[0][0]).item()), 1))
                 picks = []
                 if m.eps_violated(err):
                     m.widen_eps(err)
@@ -137,7 +137,7 @@ class BallDetector:
             n = min(2, x.shape[0])
             hb, _ = m.forward(x[:n])
             twin = m._twin()
-            err = max(float((hb[k] - twin.forward(x[k:k + 1])[0][0]).abs().max().item()) for k in range(n))
+            err = max(float(wasb.max_abs_diff(hb[k], twin.forward(x[k:k + 1])[0][0]).item()) for k in range(n))
             m.set_certify(m.HEADROOM * err, exact_windows=exact)
             m.audit_state = dict(audited_frames=n, max_err_seen=err, widened=0)
         else:

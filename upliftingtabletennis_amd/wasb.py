@@ -149,7 +149,7 @@ class WASBNet:
         if x0 is None or self.W <= self.AUDIT_STRIP:
             hb, _, _ = self._audit_twin().forward_frames(fr, want_heatmap=True)
             hf, _ = self._twin().forward(preprocess_triples(fr, (self.W, self.H)))
-            return (hb[0] - hf[0]).abs().max()
+            return max_abs_diff(hb[0], hf[0])
         xs = preprocess_triples(fr, (self.W, self.H))[:, :, :, x0:x0 + self.AUDIT_STRIP].contiguous()
         tw = self.__dict__.get('_strip_twins')
         if tw is None:
@@ -158,7 +158,7 @@ class WASBNet:
                                       WASBNet(self._state_dict, resolution=res, max_batch=1, dtype='f32', device=self.device))
         hb, _ = tw[0].forward(xs)
         hf, _ = tw[1].forward(xs)
-        return (hb[0] - hf[0]).abs().max()
+        return max_abs_diff(hb[0], hf[0])
 
     def calibrate(self, frames_u8, n=8, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
         """First estimate of eps: HEADROOM * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
@@ -373,6 +373,22 @@ def preprocess_triples(frames_u8, dst_wh):
     with torch.cuda.device(frames_u8.device):
         _lib.check(lib.ttup_preprocess_triples(_lib.ptr(frames_u8), n, h, w, dst_wh[1], dst_wh[0], _lib.ptr(out), _lib.stream_ptr()))
     return out
+
+
+def max_abs_diff(a, b):
+    """max |a - b| of two float32 device tensors of equal size on the current stream -> 0-dim device tensor (ttup_max_abs_diff:
+    the audit's error measure without torch's element-wise kernels, which must not run beside the CNN -- csrc/common.h)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() != b.numel():
+        raise ValueError('max_abs_diff: two float32 tensors of equal size expected')
+    if a.numel() == 0:
+        return torch.zeros((), dtype=torch.float32, device=a.device)
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.ttup_max_abs_diff(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.stream_ptr()))
+    return out[0]
 
 
 _OP_KINDS = {0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem', 5: 'upsum_head'}
