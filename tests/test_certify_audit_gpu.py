@@ -139,6 +139,7 @@ def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
     worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=0)
     table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
     worker.process_clip(fr, table_px, 60.0)
+    worker.net.SUBSET_MAX_SHARE = 1.0           # this weight set guards most heatmaps: keep the subset path (default: whole call above 25 %)
     e0 = worker.certify_eps
     t = worker.submit(fr)
     torch.cuda.synchronize()
@@ -155,6 +156,16 @@ def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
     # the same clip run from scratch under the widened eps gives the same detections
     again = worker.process_clip(fr, table_px, 60.0)
     assert torch.equal(again['xyv'], o['xyv'])
+    # with the default share the same situation re-runs the whole clip in one batched pass instead: same detections
+    if n_guard > 3:
+        worker.net.SUBSET_MAX_SHARE = 0.25
+        e1 = worker.certify_eps
+        t = worker.submit(fr)
+        worker.certify_eps = worker.net.widen_eps(1.15 * e1 / worker.net.HEADROOM)
+        clips_before = worker.recertified_clips
+        o2 = worker.collect(t, table_px, 60.0)
+        assert worker.recertified_clips == clips_before + 1
+        assert torch.equal(o2['xyv'], worker.process_clip(fr, table_px, 60.0)['xyv'])
 
 
 def test_uplift_beside_the_cnn_is_bit_stable():

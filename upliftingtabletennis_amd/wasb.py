@@ -137,6 +137,7 @@ class WASBNet:
             self._bf16_twin = WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='bf16', device=self.device)
         return self._bf16_twin
 
+    SUBSET_MAX_SHARE = 0.25      # recertify_subset: above this share of guarded heatmaps the caller re-runs the whole call
     AUDIT_STRIP = 320      # columns of the image strip an audit re-computes (full height); calibration uses whole frames
 
     def heatmap_error(self, frames_u8, t, x0=None):
@@ -278,13 +279,15 @@ class WASBNet:
         """eps has been widened since the call that produced (idx, win, status_raw) from the uint8 clip `frames_u8`.  Heatmaps whose
         guard band was empty keep their certified result (same candidate set under any eps up to GUARD * eps_used); the others are
         run again one triple at a time under the current eps and repaired on the fp32 handle if they overflow the budget.  Returns the indices re-run, or None when eps grew past the guard factor (the caller then re-runs the
-        whole call)."""
+        whole call; also when more than SUBSET_MAX_SHARE of the heatmaps are guarded)."""
         if self.eps > eps_used * self.GUARD * (1 - 1e-6):
             return None
         st = status_raw.cpu().numpy() if torch.is_tensor(status_raw) else np.asarray(status_raw)
         todo = np.nonzero((st & 4) != 0)[0]
         if todo.size == 0:
             return todo
+        if todo.size > self.SUBSET_MAX_SHARE * st.size:
+            return None          # most of the call is guarded (near-ties everywhere): one batched re-run beats many single ones
         # a one-sample certified handle of its own (same weights, same per-tile arithmetic as the production handle: its bf16
         # heatmaps are bit-identical, tests/test_certify_audit_gpu.py): the re-runs never touch the production handle's lanes or its
         # per-call certification slots, which a clip in flight may still be using
