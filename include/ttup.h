@@ -85,6 +85,11 @@ int ttup_preprocess_frames(const uint8_t* frames_dev, int n_frames, int src_h, i
  */
 int  ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width, int max_batch,
                       int dtype, ttup_wasb** out);
+/* The same with the batching fixed by the caller: forward splits a batch into micro-batches of `micro_batch` samples and runs them
+ * round-robin on `lanes` internal streams (0 = the defaults: 8 and 2).  lanes = 1: everything on the caller's stream -- for a
+ * handle that runs side by side with another busy handle (the hub pipeline's table and ball detectors). */
+int  ttup_wasb_create_ex(const void* blob, size_t blob_bytes, int height, int width, int max_batch,
+                         int dtype, int micro_batch, int lanes, ttup_wasb** out);
 void ttup_wasb_destroy(ttup_wasb* net);
 
 /* x_dev: float32 (B,9,H,W) NCHW.  heat_dev: float32 (B,1,H,W) (nullable).

@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""BASELINE config 1 on the GPU: the hub entry point `full_pipeline` on one 48-frame 1280x720 clip (host numpy frames in,
-spin + 3D positions out), wall clock including the host->device upload of the frames."""
-import os, sys, time
-import numpy as np, torch
+"""BASELINE config 1 on the GPU alone: hubconf.full_pipeline().predict on a 48-frame 1280x720 host clip (bench.py's hub_clip_fps)."""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault('TTUP_SYNTHETIC_WEIGHTS', '1')      # no trained checkpoints offline
-import hubconf
-from upliftingtabletennis_amd import synth
-frames, _ = synth.synth_frames(48, 720, 1280, seed=0)      # 46 detections: the reference caps a rally at 50 tokens and needs one padded slot
+os.environ.setdefault('TTUP_SYNTHETIC_WEIGHTS', '1')
+import hubconf  # noqa: E402
+from upliftingtabletennis_amd import synth  # noqa: E402
+
+n = int(os.environ.get('TTUP_HUB_FRAMES', '48'))
+frames, _ = synth.synth_frames(n, 720, 1280, seed=0)
 images = [f for f in frames]
-pipe = hubconf.full_pipeline()
-pipe.predict(images[:8], 60.0)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    hub = hubconf.full_pipeline()
+for _ in range(2):
+    hub.predict(images, 60.0)
 torch.cuda.synchronize()
+reps = int(os.environ.get('TTUP_HUB_REPS', '8'))
 t0 = time.perf_counter()
-for _ in range(3):
-    spin, pos3d = pipe.predict(images, 60.0)
+for _ in range(reps):
+    spin, pos = hub.predict(images, 60.0)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 3
-print('full_pipeline.predict on %d frames: %.1f ms -> %.0f frames/s (table detection on every frame + ball detection + uplift; pos3d %s)'
-      % (len(images), dt * 1e3, len(images) / dt, tuple(pos3d.shape)))
+dt = (time.perf_counter() - t0) / reps
+print('hub predict, %d frames: %.2f ms per clip = %.1f frames/s' % (n, dt * 1e3, n / dt))

@@ -654,6 +654,15 @@ extern "C" int ttup_wasb_create(const void* blob, size_t blob_bytes, int height,
     return ttup_wasb_create_internal(blob, blob_bytes, height, width, max_batch, dtype, 0, 0, out);
 }
 
+// micro_batch / lanes: 0 = the defaults (8 frames, two lanes; TTUP_MICRO_BATCH / TTUP_LANES); lanes = 1 runs every micro-batch on
+// the caller's stream -- for a handle that shares the device with another busy handle (the hub pipeline's two detectors), where a
+// second lane only adds streams that collide on the runtime's few hardware queues
+extern "C" int ttup_wasb_create_ex(const void* blob, size_t blob_bytes, int height, int width, int max_batch, int dtype, int micro_batch, int lanes,
+                                   ttup_wasb** out) {
+    TTUP_REQUIRE(micro_batch >= 0 && lanes >= 0 && lanes <= 4, TTUP_EINVAL, "ttup_wasb_create_ex: micro_batch %d / lanes %d out of range", micro_batch, lanes);
+    return ttup_wasb_create_internal(blob, blob_bytes, height, width, max_batch, dtype, micro_batch, lanes, out);
+}
+
 extern "C" void ttup_wasb_destroy(ttup_wasb* net) {
     if (!net) return;
     (void)hipDeviceSynchronize();

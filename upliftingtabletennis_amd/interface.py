@@ -72,7 +72,7 @@ def _load_uplift_checkpoint():
 
 
 class BallDetector:
-    def __init__(self, model_name='segformerpp_b2', max_batch=32, dtype='bf16'):
+    def __init__(self, model_name='segformerpp_b2', max_batch=32, dtype='bf16', lanes=0):
         if 'segformerpp' in model_name or model_name == 'vitpose':
             raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference "
                                       "(KieDani/SegformerPlusPlus / mmcv); only 'wasb' is built" % model_name)
@@ -81,7 +81,7 @@ class BallDetector:
         self.resolution = (WIDTH, HEIGHT)
         sd, res, in_frames = _load_ball_checkpoint(model_name)
         self.model = wasb.get_model(model_name, in_frames=in_frames, resolution=res, pretraining=False, state_dict=sd,
-                                    max_batch=max_batch, dtype=dtype)
+                                    max_batch=max_batch, dtype=dtype, lanes=lanes)
         self.model_resolution = res
         self.max_batch = max_batch
 
@@ -213,7 +213,7 @@ def _load_table_checkpoint(model_name):
 
 
 class TableDetector:
-    def __init__(self, model_name='segformerpp_b2', max_batch=8, dtype='bf16'):
+    def __init__(self, model_name='segformerpp_b2', max_batch=8, dtype='bf16', lanes=0):
         if 'segformerpp' in model_name or model_name == 'vitpose':
             raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference; only 'hrnet' is built" % model_name)
         _lib.require_gpu()
@@ -221,7 +221,7 @@ class TableDetector:
         self.resolution = (WIDTH, HEIGHT)
         self.KEYPOINT_VISIBLE = KEYPOINT_VISIBLE
         sd, res = _load_table_checkpoint(model_name)
-        self.model = wasb.get_table_model(model_name, resolution=res, pretraining=False, state_dict=sd, max_batch=max_batch, dtype=dtype)
+        self.model = wasb.get_table_model(model_name, resolution=res, pretraining=False, state_dict=sd, max_batch=max_batch, dtype=dtype, lanes=lanes)
         self.model_resolution = res
         self.max_batch = max_batch
 
@@ -305,9 +305,14 @@ class TableTennisPipeline:
         self.device = torch.device('cuda')
         self.CHUNK = int(os.environ.get('TTUP_HUB_CHUNK', self.CHUNK))
         self.FIRST = int(os.environ.get('TTUP_HUB_FIRST', self.FIRST))
-        self.ball_detector = BallDetector(model_name='wasb', max_batch=max(max_batch, self.CHUNK))
+        # one lane per detector: the two handles already run side by side on their own streams; with two lanes each, four CNN streams
+        # (plus copy, audit and refine work) collide on the runtime's four hardware queues, and a high-priority table kernel queued
+        # behind a ball kernel is no longer ahead of it (measured on a 48-frame clip: 748-757 -> 804-820 frames/s; table lanes alone:
+        # 808-811; GPU_MAX_HW_QUEUES=8 with one lane each: 843)
+        lanes = int(os.environ.get('TTUP_HUB_LANES', '1'))
+        self.ball_detector = BallDetector(model_name='wasb', max_batch=max(max_batch, self.CHUNK), lanes=lanes)
         self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
-        self.table_detector = TableDetector(model_name='hrnet', max_batch=max(16, self.CHUNK))
+        self.table_detector = TableDetector(model_name='hrnet', max_batch=max(16, self.CHUNK), lanes=lanes)
         self.table_detector_aux = self.table_detector
         # the overlapped clip path runs both detectors side by side: the table detector goes first on the GPU, so that its
         # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
@@ -341,7 +346,8 @@ class TableTennisPipeline:
         frames = torch.empty((n, h0, w0, 3), dtype=torch.uint8, device=dev)
         st = self.__dict__.setdefault('_streams', None)
         if st is None:
-            st = self._streams = {k: torch.cuda.Stream(dev) for k in ('copy', 'ball', 'table')}
+            st = self._streams = {k: torch.cuda.Stream(dev) for k in ('ball', 'table')}
+            st['copy'] = st['table']          # uploads ride on the table stream (chunk k+1 behind the table pass of chunk k): one stream fewer
             self._pinned = [torch.empty((C, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
             self._pin_free = [None, None]
         if self._pinned[0].shape[1:] != (h0, w0, 3):

@@ -19,7 +19,7 @@ class WASBNet:
     """Callable like the reference nn.Module.  ``resolution`` is (W, H) as in the reference."""
     IN_CH, HEAD_OUT, OUT_CH = 9, 3, 1
 
-    def __init__(self, state_dict, resolution=(1280, 704), in_frames=3, max_batch=64, dtype='bf16', device='cuda:0'):
+    def __init__(self, state_dict, resolution=(1280, 704), in_frames=3, max_batch=64, dtype='bf16', device='cuda:0', lanes=0):
         _lib.require_gpu()
         if in_frames * 3 != self.IN_CH:
             raise ValueError('only in_frames=%d (%d input channels) is built' % (self.IN_CH // 3, self.IN_CH))
@@ -36,8 +36,8 @@ class WASBNet:
         blob = weights.pack_wasb_blob(state_dict, in_ch=self.IN_CH, head_out=self.HEAD_OUT)
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = self._lib.ttup_wasb_create(blob, len(blob), self.H, self.W, self.max_batch,
-                                            _lib.DTYPE_F32 if dtype == 'f32' else _lib.DTYPE_BF16, ctypes.byref(self._handle))
+            rc = self._lib.ttup_wasb_create_ex(blob, len(blob), self.H, self.W, self.max_batch,
+                                               _lib.DTYPE_F32 if dtype == 'f32' else _lib.DTYPE_BF16, 0, int(lanes), ctypes.byref(self._handle))
         _lib.check(rc)
 
     # nn.Module surface used by the reference call sites
@@ -325,8 +325,8 @@ class MyHRNet(WASBNet):
     3-channel single-frame input and 13 heatmap channels; ``model(x) -> heat (B,13,H,W)`` (a tensor, not a tuple)."""
     IN_CH, HEAD_OUT, OUT_CH = 3, 13, 13
 
-    def __init__(self, state_dict, resolution=(1280, 704), max_batch=16, dtype='bf16', device='cuda:0'):
-        super().__init__(state_dict, resolution=resolution, in_frames=1, max_batch=max_batch, dtype=dtype, device=device)
+    def __init__(self, state_dict, resolution=(1280, 704), max_batch=16, dtype='bf16', device='cuda:0', lanes=0):
+        super().__init__(state_dict, resolution=resolution, in_frames=1, max_batch=max_batch, dtype=dtype, device=device, lanes=lanes)
         self.number_output_channels = 13
 
     def forward(self, x, want_peaks=False):
