@@ -91,6 +91,10 @@ int  ttup_wasb_create(const void* blob, size_t blob_bytes, int height, int width
 int  ttup_wasb_create_ex(const void* blob, size_t blob_bytes, int height, int width, int max_batch,
                          int dtype, int micro_batch, int lanes, ttup_wasb** out);
 void ttup_wasb_destroy(ttup_wasb* net);
+/* The handle's internal HIP streams -> out[0..*n_out): the lane streams (none for a single-lane handle), then the stream of the
+ * certified argmax's fp32 passes when it is enabled.  HIP maps all streams of a process onto a few hardware queues; work on two
+ * streams of one queue never overlaps (tools/queue_probe.py measures which ones do). */
+int  ttup_wasb_streams(ttup_wasb* net, void** out, int cap, int* n_out);
 
 /* x_dev: float32 (B,9,H,W) NCHW.  heat_dev: float32 (B,1,H,W) (nullable).
  * argmax_dev: int64 (B) flat index of the first maximum of each heatmap (nullable).

@@ -20,6 +20,7 @@ SIGNATURES = {
     'ttup_device_count': (_i, []),
     'ttup_preprocess_triples': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'ttup_wasb_create': (_i, [_vp, _sz, _i, _i, _i, _i, _c.POINTER(_vp)]),
+    'ttup_wasb_streams': (_i, [_vp, _c.POINTER(_vp), _i, _c.POINTER(_i)]),
     'ttup_wasb_create_ex': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)]),
     'ttup_wasb_destroy': (None, [_vp]),
     'ttup_wasb_forward': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

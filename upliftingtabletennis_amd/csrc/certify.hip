@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restri
     }
     unsigned bits = nan ? 0x7fc00000u : __float_as_uint(m);            // non-negative floats order like their bit patterns
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(bits, off, 64); bits = o > bits ? o : bits; }
+    for (int k = 0; k < 6; ++k) { const unsigned o = __shfl_xor(bits, 32 >> k, 64); bits = o > bits ? o : bits; }
     if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
 }
 } }

@@ -663,6 +663,17 @@ extern "C" int ttup_wasb_create_ex(const void* blob, size_t blob_bytes, int heig
     return ttup_wasb_create_internal(blob, blob_bytes, height, width, max_batch, dtype, micro_batch, lanes, out);
 }
 
+// The handle's internal streams: its lane streams (none for a single-lane handle), then the stream of the certified argmax's fp32
+// passes (when enabled).  For callers that want to know which streams share a hardware queue (tools/queue_probe.py).
+extern "C" int ttup_wasb_streams(ttup_wasb* net, void** out, int cap, int* n_out) {
+    TTUP_REQUIRE(net && out && n_out && cap >= 0, TTUP_EINVAL, "ttup_wasb_streams: bad argument");
+    int n = 0;
+    for (auto& L : net->lanes) if (L.stream && n < cap) out[n++] = (void*)L.stream;
+    if (net->cert.enabled && net->cert.stream && n < cap) out[n++] = (void*)net->cert.stream;
+    *n_out = n;
+    return TTUP_OK;
+}
+
 extern "C" void ttup_wasb_destroy(ttup_wasb* net) {
     if (!net) return;
     (void)hipDeviceSynchronize();

@@ -306,6 +306,13 @@ class WASBNet:
             win[t] = w1[0]
         return todo
 
+    def internal_streams(self):
+        """The handle's own HIP streams as torch ExternalStreams: lanes first, then the certified argmax's fp32 stream."""
+        out = (ctypes.c_void_p * 8)()
+        n = ctypes.c_int(0)
+        _lib.check(self._lib.ttup_wasb_streams(self._handle, out, 8, ctypes.byref(n)))
+        return [torch.cuda.ExternalStream(int(out[k]), device=self.device) for k in range(n.value)]
+
     def set_priority(self, high=True):
         """Run this handle's kernels ahead of (high) / behind other handles sharing the GPU."""
         with torch.cuda.device(self.device):
