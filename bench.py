@@ -376,6 +376,13 @@ def main():
     # unset; the direct path and the self-spawned path end up with the same explicit setting here.
     host_threads = int(os.environ.get('TTUP_THREADS_PER_RANK', max(1, min(8, (os.cpu_count() or 8) // max(1, world)))))
     torch.set_num_threads(host_threads)
+    # The worker and ALL its streams first, the process group after them: HIP maps streams onto four hardware queues in the order in
+    # which they are created, the pipeline's throughput depends on that mapping by up to 6 % (tools/queue_probe.py),
+    # and RCCL takes streams of its own -- every rank of an N-GPU run thus gets the mapping the single-GPU run has.
+    pipe = Pipeline(device, seed=rank, certify=not a.no_certify)
+    for _ in range(a.warmup):
+        pipe.step()
+    pipe.worker.submit_streams()
     dist = None
     collective = None
     if world > 1:
@@ -391,9 +398,6 @@ def main():
         collective = {'backend': dist.get_backend(), 'ranks': int(ones.item()), 'world_size': dist.get_world_size()}
         if collective['ranks'] != world:
             raise SystemExit('bench.py: all_reduce saw %d of %d ranks' % (collective['ranks'], world))
-    pipe = Pipeline(device, seed=rank, certify=not a.no_certify)
-    for _ in range(a.warmup):
-        pipe.step()
 
     def barrier():
         if dist is not None:

@@ -267,14 +267,20 @@ class StreamWorker:
     def submit(self, frames_u8):
         # consecutive clips are issued on two alternating streams: the fp32 crop passes of the certified argmax (the handle's own
         # stream, behind clip k's bf16 pass) then overlap with the bf16 micro-batches of clip k+1 instead of delaying them
-        subs = self.__dict__.setdefault('_sub', None)
-        if subs is None:
-            subs = self._sub = {'streams': [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], 'next': 0}
+        subs = self.submit_streams()
         sub = subs['streams'][subs['next']]
         subs['next'] ^= 1
         sub.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(sub):
             return self._submit(frames_u8, sub)
+
+    def submit_streams(self):
+        """The two alternating streams `submit` issues clips on (created on first use; callers that are about to create other
+        streams -- a process group -- call this first so that the worker's stream-to-queue mapping does not depend on them)."""
+        subs = self.__dict__.setdefault('_sub', None)
+        if subs is None:
+            subs = self._sub = {'streams': [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], 'next': 0}
+        return subs
 
     def _pinned(self, key, like):
         """A pinned host buffer shaped like `like` from the worker's pool (returned to it by collect): any number of clips may be
