@@ -75,6 +75,11 @@ def test_argument_validation_without_gpu(lib):
     h = ctypes.c_void_p()
     assert lib.ttup_wasb_create(b'x' * 64, 64, 63, 64, 1, 0, ctypes.byref(h)) == _lib.EINVAL     # height not a multiple of 8
     assert lib.ttup_uplift_create(b'NOTMAGIC' + b'\0' * 64, 72, 1, 8, ctypes.byref(h)) == _lib.EFORMAT
+    assert lib.ttup_wasb_create_ex(b'x' * 64, 64, 64, 64, 1, 0, 0, 5, ctypes.byref(h)) == _lib.EINVAL     # at most four lanes
+    assert b'lanes' in lib.ttup_last_error()
+    n = ctypes.c_int(0)
+    assert lib.ttup_wasb_streams(None, None, 0, ctypes.byref(n)) == _lib.EINVAL
+    assert lib.ttup_max_abs_diff(None, None, 4, None, None) == _lib.EINVAL
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     assert lib.ttup_refine_workspace_bytes(4, 704, 1280) >= 4 * 44
