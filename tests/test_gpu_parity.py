@@ -456,6 +456,28 @@ def test_ball_detector_clip_path_equals_triple_path():
     assert det.predict_clip(images[:2]).shape == (0, 3)
 
 
+def test_single_lane_handle_equals_the_two_lane_handle():
+    """ttup_wasb_create_ex(lanes = 1) -- what the hub pipeline gives its detectors -- runs every micro-batch on the caller's stream;
+    heatmaps, argmax and windows are bit-identical to the default two-lane handle (same kernels per micro-batch), also on a
+    side stream, and the handle reports no internal lane streams."""
+    sd = weights.random_wasb_state_dict(5, planted=True)
+    fr = torch.from_numpy(synth.synth_frames(26, 720, 1280, seed=9)[0]).cuda()
+    two = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=24, dtype='bf16')
+    one = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=24, dtype='bf16', lanes=1)
+    assert len(two.internal_streams()) == 2 and len(one.internal_streams()) == 0
+    h2, i2, w2 = two.forward_frames(fr, want_heatmap=True)
+    h1, i1, w1 = one.forward_frames(fr, want_heatmap=True)
+    assert torch.equal(h1, h2) and torch.equal(i1, i2) and torch.equal(w1, w2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _, i3, w3 = one.forward_frames(fr, want_heatmap=False)
+    side.synchronize()
+    assert torch.equal(i3, i2) and torch.equal(w3, w2)
+    with pytest.raises(ValueError):
+        wasb.WASBNet(sd, resolution=(1280, 704), max_batch=24, dtype='bf16', lanes=5)
+
+
 def test_table_detector_and_full_pipeline_surface():
     from upliftingtabletennis_amd.interface import TableDetector, TableTennisPipeline
     frames, track = synth.synth_frames(8, 720, 1280, seed=4)
