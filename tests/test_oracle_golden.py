@@ -113,6 +113,25 @@ def test_resize_unpinned_self_consistency():
     assert (np.diff(r[:, 0, 0]) >= 0).all()
 
 
+def test_resize_unpinned_agrees_with_an_independent_bilinear():
+    """cv2 is not in the image, so the fixed-point restatement of cv2.resize cannot be pinned on cv2 itself.  Independent
+    evidence for its geometry (half-pixel centres, edge clamp) and rounding: torch's bilinear interpolation in float64 with the
+    same convention (align_corners=False, no antialiasing) is the exact value of what the 11-bit fixed-point scheme approximates --
+    the restatement must be within ONE grey level of it everywhere and equal to its rounding on most pixels (the rest are
+    roundings flipped by the coefficients' 1/2048 quantisation)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(1)
+    for (h, w, dh, dw) in ((720, 1280, 704, 1280), (90, 160, 88, 157), (64, 48, 100, 75)):
+        smooth = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3)).astype(np.float64)
+        img = np.clip(np.kron(smooth, np.ones((8, 8, 1)))[:h, :w] + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+        out = glue_ref.resize_linear_u8(img, dw, dh).astype(np.float64)
+        ref = F.interpolate(torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None], size=(dh, dw), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+        d = np.abs(out - ref)
+        assert d.max() <= 1.0, (h, w, dh, dw, d.max())
+        assert (out == np.rint(ref)).mean() > 0.85 and d.mean() < 0.3, ((out == np.rint(ref)).mean(), d.mean())      # measured: 0.89-0.93, 0.25
+
+
 @pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160'])
 def test_table_hrnet_oracle_matches_reference(golden, name):
     """f1: the same oracle graph with 3 input / 13 output channels == reference MyHRNet (tabledetection/models/hrnet.py)."""
