@@ -1,6 +1,8 @@
 """The certified argmax's supporting machinery on the MI355X box (-m gpu): the continuous eps audit (side-stream fp32 re-runs,
 candidate-level errors from the crops, widening + re-certification), the repair path of pipelined clips, and the per-handle
 serialisation of consecutive calls issued on different streams."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -206,6 +208,28 @@ def test_uplift_beside_the_cnn_is_bit_stable():
     print('\nuplift beside the CNN: %d of 30 calls differ from the idle result (worst |dpos| %.2e); %.2f ms alone, up to %.2f ms beside the CNN'
           % (bad, worst, alone_ms, slowest))
     assert bad == 0
+
+
+def test_packed_fp32_reproducer_victims_without_swizzles_are_clean(tmp_path):
+    """tools/pk_coresidency_repro.hip, the stand-alone reproducer behind csrc/common.h's TTUP_NO_PACKED_FP32_*: compiled and run
+    here.  The two kinds of code the library ships -- packed fp32 disabled (uplift, refine), packed fp32 without operand swizzles
+    (convolution epilogues) -- must come out clean beside every neighbour; the count for the swizzled forms is reported (160 runs
+    in 4 x 4 x 10; 40 wrong on this pool: every run beside the LDS-fed MFMA neighbour)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not found')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / 'pk_repro'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-fno-fast-math', '-o', str(exe), os.path.join(root, 'tools', 'pk_coresidency_repro.hip')],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=600).stdout
+    m = re.search(r'swizzled packed fp32: (\d+), packed fp32 disabled: (\d+), packed fp32 without swizzles: (\d+)', out)
+    assert m, out[-500:]
+    print('\nreproducer: runs with wrong results -- swizzled packed fp32 %s, packed fp32 disabled %s, packed fp32 without swizzles %s (of 160 each)' % m.groups())
+    assert int(m.group(2)) == 0 and int(m.group(3)) == 0
 
 
 @pytest.mark.parametrize('lanes', ['1', '2'])
