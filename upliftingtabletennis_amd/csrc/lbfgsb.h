@@ -388,8 +388,6 @@ TTUP_HD inline void fit_gaussian_lbfgsb(const GaussProblem& P, GaussFit* out) {
         for (int i = 0; i < 4; ++i) { d[i] = z[i] - x[i]; xold[i] = x[i]; gold[i] = g[i]; }
         const double fold = f;
         // ---- line search (lnsrlb)
-        double dtd = 0.0;
-        for (int i = 0; i < 4; ++i) dtd += d[i] * d[i];
         double stpmx = 1e10;
         if (iter == 0) stpmx = 1.0;
         else {

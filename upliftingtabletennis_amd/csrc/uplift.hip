@@ -342,11 +342,6 @@ __global__ void prepare_kernel(const float* mask, const float* table, float* m1,
         txy[j * 2] = table[j * 3]; txy[j * 2 + 1] = table[j * 3 + 1];
     }
 }
-__global__ void copy_strided_kernel(const float* src, int lds, float* dst, int ldd, int cols, long long rows) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    dst[(i / cols) * ldd + i % cols] = src[(i / cols) * lds + i % cols];
-}
 __global__ void rotationaxes_kernel(const float* rot, const float* pos, int B, int T, float* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
