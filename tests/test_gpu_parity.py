@@ -375,6 +375,36 @@ def test_chain_runtime_epilogue_form_matches_compiled_forms(tmp_path):
     assert np.array_equal(outs['compiled']['idx'], outs['runtime']['idx'])
 
 
+def test_frame_record_fast_path_is_bit_identical(tmp_path):
+    """preprocess_frames4_kernel (equal source / network width: four pixels per thread, table in LDS) writes the records the
+    general kernel writes: heatmaps, indices and windows of `forward_frames` are bit-identical with TTUP_NO_PRE4=1 (read once per
+    process, hence the child processes).  720 -> 704 rows (real vertical interpolation), 704 -> 704 (identity rows), and a width
+    the fast path refuses (not a multiple of 4: both runs take the general kernel)."""
+    import subprocess, sys
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from upliftingtabletennis_amd import synth, wasb, weights\n"
+        "sd = weights.random_wasb_state_dict(41, planted=True)\n"
+        "out = {}\n"
+        "for k, (sh, sw, nh, nw) in enumerate(((720, 1280, 704, 1280), (704, 1280, 704, 1280), (90, 168, 88, 168))):\n"
+        "    fr = torch.from_numpy(synth.synth_frames(6, sh, sw, seed=41 + k)[0]).cuda()\n"
+        "    net = wasb.WASBNet(sd, resolution=(nw, nh), max_batch=4, dtype='bf16')\n"
+        "    h, i, w = net.forward_frames(fr, want_heatmap=True)\n"
+        "    out['h%%d' %% k], out['i%%d' %% k], out['w%%d' %% k] = h.cpu().numpy(), i.cpu().numpy(), w.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for tag, env in (('fast', {}), ('general', {'TTUP_NO_PRE4': '1'})):
+        out = str(tmp_path / (tag + '.npz'))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, '-c', script, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    for k in outs['fast'].files:
+        assert np.array_equal(outs['fast'][k], outs['general'][k]), k
+
+
 @pytest.mark.parametrize('bias', [float('-inf'), float('nan'), float('inf'), -0.0])
 def test_fused_head_argmax_special_values(bias):
     """The stage-4 tail keeps its per-tile argmax partial as a 64-bit key (order-preserving value bits, NaN on top, -0 == +0,

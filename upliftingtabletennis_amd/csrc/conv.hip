@@ -2366,6 +2366,66 @@ __global__ void preprocess_kernel(PreArgs a) {
     }
 }
 
+// Frame records (one 4-channel bf16 record per pixel of ONE frame: the production input of the stem) when source and network
+// width are equal, as for 1280x720 frames at 1280x704 -- the horizontal taps are (2048, 0), only rows are interpolated.  Four
+// pixels of four rows per thread: the 12 source bytes of a row are three aligned words, the normalisation table sits in LDS (the general
+// kernel's three dependent table loads per pixel from memory were what it waited for), two 16-byte stores.  Same integer arithmetic
+// per pixel as preprocess_kernel: bit-identical records.
+constexpr int PRE4_ROWS = 4;          // output rows per workgroup: the table load and its barrier are paid once for 4096 pixels
+__global__ __launch_bounds__(256) void preprocess_frames4_kernel(PreArgs a) {
+    __shared__ float s_lut[768];
+    const int x = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4, yb = (int)blockIdx.y * PRE4_ROWS, t = blockIdx.z;
+    const bool live = x < a.dst_w;
+    const uint8_t* img = a.frames + (size_t)(a.first_triple + t) * a.src_h * a.src_w * 3;
+    int b0[PRE4_ROWS], b1[PRE4_ROWS];
+    u32x4 r0[PRE4_ROWS], r1[PRE4_ROWS];
+    // all loads of the workgroup's rows first (one memory round trip), the table while they travel
+#pragma unroll
+    for (int r = 0; r < PRE4_ROWS; ++r) {
+        const int y = yb + r;
+        int y0 = y, y1 = y;
+        b0[r] = 2048; b1[r] = 0;
+        r0[r] = u32x4{0u, 0u, 0u, 0u}; r1[r] = u32x4{0u, 0u, 0u, 0u};
+        if (y >= a.dst_h) continue;
+        if (a.src_h != a.dst_h) axis_tap_y(y, a.scale_y, a.src_h, y0, y1, b0[r], b1[r]);
+        if (live) {
+            const unsigned* p0 = (const unsigned*)(img + ((size_t)y0 * a.src_w + x) * 3);
+            r0[r] = u32x4{p0[0], p0[1], p0[2], 0u};
+            if (b1[r]) {                                     // wave-uniform (a row property): a tap with weight 0 is not loaded
+                const unsigned* p1 = (const unsigned*)(img + ((size_t)y1 * a.src_w + x) * 3);
+                r1[r] = u32x4{p1[0], p1[1], p1[2], 0u};
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < 768; k += 256) s_lut[k] = a.lut[k];
+    __syncthreads();
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < PRE4_ROWS; ++r) {
+        const int y = yb + r;
+        if (y >= a.dst_h) break;
+        const unsigned w0[3] = {r0[r].x, r0[r].y, r0[r].z}, w1[3] = {r1[r].x, r1[r].y, r1[r].z};
+        unsigned rec[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int i = 3 * j + c;
+                const int top = (int)((w0[i >> 2] >> (8 * (i & 3))) & 255) * 2048;
+                const int bot = (int)((w1[i >> 2] >> (8 * (i & 3))) & 255) * 2048;
+                int q = (((b0[r] * (top >> 4)) >> 16) + ((b1[r] * (bot >> 4)) >> 16) + 2) >> 2;
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                v[c] = s_lut[c * 256 + q];
+            }
+            rec[2 * j] = pack2(v[0], v[1]); rec[2 * j + 1] = pack2(v[2], 0.f);
+        }
+        u32x4* o = (u32x4*)((bf16_t*)a.out + (((size_t)t * a.dst_h + y) * a.dst_w + x) * 4);
+        o[0] = u32x4{rec[0], rec[1], rec[2], rec[3]};
+        o[1] = u32x4{rec[4], rec[5], rec[6], rec[7]};
+    }
+}
+
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
                       void* out, int out_layout, int dtype, int first_triple, int n_triples, int frames_per_sample, hipStream_t stream) {
     TTUP_REQUIRE(frames_per_sample == 1 || frames_per_sample == 3, TTUP_EINVAL, "frames_per_sample must be 1 or 3");
@@ -2381,7 +2441,10 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     TTUP_REQUIRE(dst_h <= 65535 && n_triples <= 65535, TTUP_EINVAL, "preprocess: grid limit (rows, samples <= 65535)");
     const dim3 grid((unsigned)cdiv(dst_w, 256), (unsigned)dst_h, (unsigned)n_triples);
     TTUP_REQUIRE(out_layout != TTUP_LAYOUT_NHWC4_FRAME || (frames_per_sample == 1 && dtype == TTUP_DTYPE_BF16), TTUP_EINVAL, "per-frame records are bf16, one frame per sample");
-    if ((dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32) && out_layout != TTUP_LAYOUT_NHWC4_FRAME)
+    static const bool no_fast = getenv("TTUP_NO_PRE4") != nullptr;
+    if (out_layout == TTUP_LAYOUT_NHWC4_FRAME && src_w == dst_w && dst_w % 4 == 0 && !no_fast)
+        hipLaunchKernelGGL(preprocess_frames4_kernel, dim3((unsigned)cdiv(dst_w, 1024), (unsigned)cdiv(dst_h, PRE4_ROWS), (unsigned)n_triples), dim3(256), 0, stream, a);
+    else if ((dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32) && out_layout != TTUP_LAYOUT_NHWC4_FRAME)
         hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(preprocess_kernel<bf16_t>, grid, dim3(256), 0, stream, a);
