@@ -167,6 +167,7 @@ def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
         clips_before = worker.recertified_clips
         o2 = worker.collect(t, table_px, 60.0)
         assert worker.recertified_clips == clips_before + 1
+        assert torch.equal(t['idx'], ref_idx)              # the ticket describes the pass that produced its detections
         assert torch.equal(o2['xyv'], worker.process_clip(fr, table_px, 60.0)['xyv'])
 
 

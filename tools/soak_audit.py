@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Soak of the certified argmax on CHANGING content (bench.py's clip repeats 34 frames): TTUP_SOAK_CLIPS clips of 66 frames each
+(new background, noise, blob size, brightness gain and trajectory per clip) through StreamWorker with the continuous eps audit on;
+every clip is checked against the full-frame fp32 path (index and 3x3 window of every triple).  Prints one JSON line: clips, frames,
+mismatches against the fp32 argmax, the trajectory of eps, widenings, re-certified heatmaps / clips, crops per heatmap.
+    python tools/soak_audit.py > profiles/r3_soak_audit.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from upliftingtabletennis_amd import pipeline, synth, wasb, weights  # noqa: E402
+
+N_CLIPS = int(os.environ.get('TTUP_SOAK_CLIPS', '40'))
+N_FRAMES = 66
+dev = torch.device('cuda:0')
+sd = weights.random_wasb_state_dict(0, planted=True)
+usd = weights.random_uplift_state_dict(0, 'large')
+worker = pipeline.StreamWorker(dev, sd, usd, net_wh=(1280, 704), max_triples=N_FRAMES - 2, traj_len=32, seq_len=50, audit_every=16)
+twin = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=1, dtype='f32')
+table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+rng = np.random.default_rng(2026)
+mismatch_idx = mismatch_win = frames_total = 0
+eps_track = []
+t0 = time.time()
+for c in range(N_CLIPS):
+    frames, _ = synth.synth_frames(N_FRAMES, 720, 1280, seed=1000 + c, sigma=float(rng.uniform(1.2, 4.0)))
+    gain = float(rng.uniform(0.6, 1.6))                                   # darker / brighter clips: the bf16 error scales with the activations
+    frames = np.clip(np.rint(frames.astype(np.float32) * gain), 0, 255).astype(np.uint8)
+    fr = torch.from_numpy(frames).to(dev)
+    ticket = worker.submit(fr)
+    out = worker.collect(ticket, table_px, 60.0)
+    x = wasb.preprocess_triples(fr, (1280, 704))
+    for k in range(x.shape[0]):
+        _, i1, w1 = twin.forward(x[k:k + 1], want_heatmap=False, want_peaks=True)
+        ok_i = bool(torch.equal(i1[0], ticket['idx'][k]))
+        mismatch_idx += not ok_i
+        if ok_i and int(out['status'][k]) != 0:                           # windows are the fp32 path's where an fp32 crop was evaluated
+            mismatch_win += not bool(torch.equal(w1[0], ticket['win'][k]))
+    frames_total += x.shape[0]
+    a = worker.audit
+    eps_track.append(round(float(a['eps']), 5))
+cs = worker.net.certify_stats()
+a = worker.audit
+print(json.dumps({
+    'tool': 'tools/soak_audit.py', 'clips': N_CLIPS, 'triples_checked_against_fp32': frames_total,
+    'argmax_mismatches': int(mismatch_idx), 'fp32_window_mismatches': int(mismatch_win),
+    'eps_first': eps_track[0], 'eps_last': eps_track[-1], 'eps_by_clip': eps_track,
+    'eps_widened': int(a['widened']), 'audited_frames': int(a['audited_frames']), 'max_err_seen': round(float(a['max_err_seen']), 5),
+    'max_err_over_eps': round(float(a['max_err_over_eps']), 4), 'recertified_heatmaps': int(a['recertified_heatmaps']),
+    'recertified_clips': int(a['recertified_clips']), 'fp32_full_frame_reruns': int(worker.fp32_reruns),
+    'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 4), 'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 4),
+    'content': 'synthetic clips, per clip: new background / noise / trajectory, blob sigma 1.2-4 px, brightness gain 0.6-1.6; planted-peak weights (seed 0)',
+    'seconds': round(time.time() - t0, 1)}))

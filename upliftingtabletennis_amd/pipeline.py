@@ -236,15 +236,16 @@ class StreamWorker:
             status_host[todo] = 1          # settled under the current eps (repaired inside when over budget)
         return xyv
 
-    def _detect_blocking(self, frames_u8):
+    def _detect_blocking(self, frames_u8, full=False):
         """One clip, start to finish, with the audit folded in: (xyv device tensor) whose every index is certified under the
-        current eps.  Loops only when an audit widens eps past the guard factor (eps only grows)."""
+        current eps; full=True: (xyv, idx, win, host status 0/1/2) of the pass that produced it.  Loops only when an audit widens
+        eps past the guard factor (eps only grows)."""
         while True:
             eps_used = self._calibrated(frames_u8)
             ticket = self._start_audit(frames_u8)
             xyv, idx, win, status, info = self._detect(frames_u8)
             if status is None:
-                return xyv
+                return (xyv, idx, win, None) if full else xyv
             n_crops, cand_err = self.net.decode_info(info.cpu().numpy())
             st = status.cpu().numpy()
             if self._after_clip(n_crops, cand_err, ticket) or eps_used < self.certify_eps:
@@ -253,7 +254,8 @@ class StreamWorker:
                     self.recertified_clips += 1
                     continue
                 xyv = out
-            return self._repair(frames_u8, xyv, idx, win, st)
+            xyv = self._repair(frames_u8, xyv, idx, win, st)
+            return (xyv, idx, win, st & 3) if full else xyv
 
     def process_clip(self, frames_u8, table_px, fps):
         xyv = self._detect_blocking(frames_u8)
@@ -315,6 +317,7 @@ class StreamWorker:
     def collect(self, ticket, table_px, fps):
         ticket['done'].synchronize()
         torch.cuda.current_stream(self.device).wait_stream(ticket['stream'])
+        rerun_status = None
         if ticket.get('status') is not None:
             n_crops, cand_err = self.net.decode_info(ticket['info'].numpy())
             widened = self._after_clip(n_crops, cand_err, ticket.get('audit'))
@@ -325,7 +328,8 @@ class StreamWorker:
                 out = self._recertify(ticket['frames'], ticket['xyv'], ticket['idx'], ticket['win'], st, ticket['eps'])
                 if out is None:
                     self.recertified_clips += 1
-                    out = self._detect_blocking(ticket['frames'])
+                    # the ticket then describes the pass that produced its detections (indices, windows, status), not the stale one
+                    out, ticket['idx'], ticket['win'], rerun_status = self._detect_blocking(ticket['frames'], full=True)
                     st = None
                 ticket['xyv'] = out
                 ticket['host'].copy_(ticket['xyv'])
@@ -347,6 +351,8 @@ class StreamWorker:
         for t in (spin, p3, nvalid):
             t.record_stream(cur)
         status_host = None if ticket.get('status') is None else (ticket['status'].numpy() & 3)          # 0 / 1 / 2 (guard bit dropped)
+        if status_host is not None and rerun_status is not None:
+            status_host = rerun_status
         for k in ('host', 'status', 'info'):
             self._unpin('xyv' if k == 'host' else k, ticket.get(k))
             ticket[k] = None
