@@ -211,6 +211,23 @@ def test_uplift_beside_the_cnn_is_bit_stable():
     assert bad == 0
 
 
+def test_soak_on_changing_content_matches_the_fp32_path():
+    """tools/soak_audit.py with 8 clips: new background / noise / trajectory / blob size / brightness per clip, the continuous audit
+    on (one triple per 16), every triple compared with the full-frame fp32 path: no index and no fp32-window mismatch, whatever the
+    audits widen on the way (profiles/r3_soak_audit.json holds the 40-clip run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e['TTUP_SOAK_CLIPS'] = '8'
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'soak_audit.py')], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    print('\nsoak: %d triples, eps %.4f -> %.4f (%d widenings), %d clips re-run, %.2f crops per heatmap' % (
+        d['triples_checked_against_fp32'], d['eps_first'], d['eps_last'], d['eps_widened'], d['recertified_clips'], d['crops_per_heatmap']))
+    assert d['triples_checked_against_fp32'] == 8 * 64 and d['argmax_mismatches'] == 0 and d['fp32_window_mismatches'] == 0
+
+
 def test_packed_fp32_reproducer_victims_without_swizzles_are_clean(tmp_path):
     """tools/pk_coresidency_repro.hip, the stand-alone reproducer behind csrc/common.h's TTUP_NO_PACKED_FP32_*: compiled and run
     here.  The two kinds of code the library ships -- packed fp32 disabled (uplift, refine), packed fp32 without operand swizzles
