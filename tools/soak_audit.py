@@ -18,7 +18,8 @@ from upliftingtabletennis_amd import pipeline, synth, wasb, weights  # noqa: E40
 N_CLIPS = int(os.environ.get('TTUP_SOAK_CLIPS', '40'))
 N_FRAMES = 66
 dev = torch.device('cuda:0')
-sd = weights.random_wasb_state_dict(0, planted=True)
+W_SEED, W_EPS = int(os.environ.get('TTUP_SOAK_WEIGHT_SEED', '0')), float(os.environ.get('TTUP_SOAK_WEIGHT_NOISE', '0.2'))      # noise scale of the random part of the planted weights
+sd = weights.random_wasb_state_dict(W_SEED, planted=True, eps=W_EPS)
 usd = weights.random_uplift_state_dict(0, 'large')
 worker = pipeline.StreamWorker(dev, sd, usd, net_wh=(1280, 704), max_triples=N_FRAMES - 2, traj_len=32, seq_len=50, audit_every=16)
 twin = wasb.WASBNet(sd, resolution=(1280, 704), max_batch=1, dtype='f32')
@@ -54,5 +55,5 @@ print(json.dumps({
     'max_err_over_eps': round(float(a['max_err_over_eps']), 4), 'recertified_heatmaps': int(a['recertified_heatmaps']),
     'recertified_clips': int(a['recertified_clips']), 'fp32_full_frame_reruns': int(worker.fp32_reruns),
     'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 4), 'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 4),
-    'content': 'synthetic clips, per clip: new background / noise / trajectory, blob sigma 1.2-4 px, brightness gain 0.6-1.6; planted-peak weights (seed 0)',
+    'content': 'synthetic clips, per clip: new background / noise / trajectory, blob sigma 1.2-4 px, brightness gain 0.6-1.6; planted-peak weights (seed %d, noise scale %g)' % (W_SEED, W_EPS),
     'seconds': round(time.time() - t0, 1)}))
