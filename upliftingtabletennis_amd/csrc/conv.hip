@@ -2442,7 +2442,7 @@ int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w,
     const dim3 grid((unsigned)cdiv(dst_w, 256), (unsigned)dst_h, (unsigned)n_triples);
     TTUP_REQUIRE(out_layout != TTUP_LAYOUT_NHWC4_FRAME || (frames_per_sample == 1 && dtype == TTUP_DTYPE_BF16), TTUP_EINVAL, "per-frame records are bf16, one frame per sample");
     static const bool no_fast = getenv("TTUP_NO_PRE4") != nullptr;
-    if (out_layout == TTUP_LAYOUT_NHWC4_FRAME && src_w == dst_w && dst_w % 4 == 0 && !no_fast)
+    if (out_layout == TTUP_LAYOUT_NHWC4_FRAME && src_w == dst_w && dst_w % 4 == 0 && ((size_t)frames & 3) == 0 && !no_fast)      // aligned 12-byte row loads
         hipLaunchKernelGGL(preprocess_frames4_kernel, dim3((unsigned)cdiv(dst_w, 1024), (unsigned)cdiv(dst_h, PRE4_ROWS), (unsigned)n_triples), dim3(256), 0, stream, a);
     else if ((dtype == TTUP_DTYPE_F32 || out_layout == TTUP_LAYOUT_NCHW_F32) && out_layout != TTUP_LAYOUT_NHWC4_FRAME)
         hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, stream, a);
