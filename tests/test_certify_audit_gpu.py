@@ -111,7 +111,7 @@ def test_pipelined_repair_uses_the_tickets_own_status():
     worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=0)
     table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
     worker.process_clip(clips[0], table_px, 60.0)
-    worker.certify_eps = worker.net.widen_eps(worker.certify_eps * 4)        # more candidates than the 32 kept per heatmap on some maps
+    worker.certify_eps = worker.net.widen_eps(worker.certify_eps * 4)        # more candidates than the 256 kept per heatmap on some maps
     tickets = [worker.submit(c) for c in clips[:2]]
     outs = [worker.collect(tickets[0], table_px, 60.0)]
     tickets.append(worker.submit(clips[2]))

@@ -210,7 +210,7 @@ def test_certified_argmax_small_and_switch_off(golden):
     net.set_certify(0.03 * float(g[name + '/heat'].max() - g[name + '/heat'].min()))
     _, i1, w1 = net.forward(x, want_heatmap=False, want_peaks=True)
     st = net.certify_status(b).cpu().numpy()
-    ok = st != 2                       # a noise heatmap can hold more than the 32 candidates kept per map: flagged, not resolved
+    ok = st != 2                       # a noise heatmap can hold more than the 256 candidates kept per map: flagged, not resolved
     assert (st == 1).any(), st
     assert np.array_equal(i1.cpu().numpy()[ok], g[name + '/argmax'][ok])     # the reference's own argmax on noise weights
     f32 = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='f32')

@@ -68,26 +68,35 @@ __device__ __forceinline__ void core_range(int o, int c, int full, int R, int& l
     hi = (o + c == full) ? full : o + c - R - 1;
 }
 
-// ---- 2. one workgroup per heatmap; lane 0 sorts the (few) candidates and assigns them to crops
+// ---- 2. one workgroup (one wave) per heatmap: the wave sorts the candidates by index (the scan appends in arbitrary order; a
+// rank sort: every lane counts the smaller indices of its elements), lane 0 assigns them to crops.  K is sized for the flat top of
+// a wide saturated blob (a few hundred equal pixels inside one crop core), which used to overflow a 32-entry list and send the
+// heatmap to the full-frame fp32 path.
+constexpr int CERT_MAX_K = 512;
 __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
-    if (threadIdx.x != 0) return;
+    __shared__ int s_idx[CERT_MAX_K];
+    __shared__ float s_bf[CERT_MAX_K];
+    const int lane = threadIdx.x;
     const int map = a.map0 + blockIdx.x;
     const int cnt = a.cand_cnt[map];
-    atomicAdd(&a.stats[0], 1ull);
     const int gbit = a.guard_cnt[map] > 0 ? 4 : 0;          // status bit 2: the guard band is not empty
+    if (lane == 0) atomicAdd(&a.stats[0], 1ull);
     // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
-    if (cnt <= 0 || (cnt == 1 && !a.exact)) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); return; }
-    if (cnt > a.K) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
-    if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
+    if (cnt <= 0 || (cnt == 1 && !a.exact)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } return; }
+    if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } return; }
     int* ci = a.cand_idx + (size_t)map * a.K;
     float* cb = a.cand_bf + (size_t)map * a.K;
-    for (int i = 1; i < cnt; ++i) {             // insertion sort (the scan appends in arbitrary order)
-        const int v = ci[i];
-        const float vb = cb[i];
-        int j = i - 1;
-        while (j >= 0 && ci[j] > v) { ci[j + 1] = ci[j]; cb[j + 1] = cb[j]; --j; }
-        ci[j + 1] = v; cb[j + 1] = vb;
+    for (int i = lane; i < cnt; i += 64) { s_idx[i] = ci[i]; s_bf[i] = cb[i]; }
+    __syncthreads();
+    for (int i = lane; i < cnt; i += 64) {
+        const int v = s_idx[i];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += s_idx[j] < v;          // pixel indices are distinct: ranks are a permutation
+        ci[rank] = v; cb[rank] = s_bf[i];
     }
+    __syncthreads();
+    if (lane != 0) return;
+    if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
     int my_crop[8], my_y0[8], my_x0[8], n_my = 0;
     for (int k = 0; k < cnt; ++k) {
         const int cy = ci[k] / a.W, cx = ci[k] % a.W;
@@ -315,6 +324,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     c.CH = net->max_batch < 64 ? net->max_batch : 64;
     c.max_crops = 2 * net->max_batch > c.CH ? 2 * net->max_batch : c.CH;   // two crops per heatmap on average (exact-window mode: one each + the near-ties); the overflow is flagged
     c.nchunks = cdiv(c.max_crops, c.CH);
+    TTUP_REQUIRE(c.K <= CERT_MAX_K, TTUP_EINVAL, "ttup_wasb_set_certify: candidate list %d longer than the plan kernel's %d", c.K, CERT_MAX_K);
     TTUP_REQUIRE(c.nchunks <= 64, TTUP_EINVAL, "ttup_wasb_set_certify: max_batch %d too large", net->max_batch);
     c.max_crops = c.nchunks * c.CH;
     c.budget = net->max_batch < c.max_crops ? (net->max_batch > c.CH ? net->max_batch : c.CH) : c.max_crops;      // default: one crop per heatmap
