@@ -97,7 +97,10 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     __syncthreads();
     if (lane != 0) return;
     if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
-    int my_crop[8], my_y0[8], my_x0[8], n_my = 0;
+    // crops of this heatmap first in local slots; ids on the shared crop list are taken only once it is known that the heatmap stays
+    // within its budget (a heatmap that overflows after three crops used to leave those three on the list: wasted fp32 passes and
+    // budget taken from the heatmaps behind it)
+    int my_y0[8], my_x0[8], n_my = 0;
     for (int k = 0; k < cnt; ++k) {
         const int cy = ci[k] / a.W, cx = ci[k] % a.W;
         int found = -1;
@@ -109,19 +112,22 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         }
         if (found < 0) {
             if (n_my >= a.maxc) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
-            const int id = atomicAdd(a.n_crops, 1);
-            if (id >= a.max_crops) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
             int y0 = ((cy - a.Hc / 2) / 8) * 8, x0 = ((cx - a.Wc / 2) / 8) * 8;
             y0 = y0 < 0 ? 0 : (y0 > a.H - a.Hc ? a.H - a.Hc : y0);
             x0 = x0 < 0 ? 0 : (x0 > a.W - a.Wc ? a.W - a.Wc : x0);
-            my_crop[n_my] = id; my_y0[n_my] = y0; my_x0[n_my] = x0;
-            int* rec = a.crop_rec + 4 * id;
-            rec[0] = map; rec[1] = y0; rec[2] = x0; rec[3] = 0;
+            my_y0[n_my] = y0; my_x0[n_my] = x0;
             found = n_my++;
-            atomicAdd(&a.stats[4], 1ull);
         }
-        a.cand_crop[(size_t)map * a.K + k] = my_crop[found];
+        a.cand_crop[(size_t)map * a.K + k] = found;          // local slot for now
     }
+    const int base = atomicAdd(a.n_crops, n_my);
+    for (int c = 0; c < n_my && base + c < a.max_crops; ++c) {          // (records also for a list that fills up half way: the slots are run)
+        int* rec = a.crop_rec + 4 * (base + c);
+        rec[0] = map; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
+    }
+    if (base + n_my > a.max_crops) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }      // crop list full
+    for (int k = 0; k < cnt; ++k) a.cand_crop[(size_t)map * a.K + k] += base;
+    atomicAdd(&a.stats[4], (unsigned long long)n_my);
     a.status[map] = 1 | gbit;
     atomicAdd(&a.stats[2], 1ull);
     atomicAdd(&a.stats[5], (unsigned long long)cnt);
