@@ -112,9 +112,30 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         }
         if (found < 0) {
             if (n_my >= a.maxc) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
-            int y0 = ((cy - a.Hc / 2) / 8) * 8, x0 = ((cx - a.Wc / 2) / 8) * 8;
-            y0 = y0 < 0 ? 0 : (y0 > a.H - a.Hc ? a.H - a.Hc : y0);
-            x0 = x0 < 0 ? 0 : (x0 > a.W - a.Wc ? a.W - a.Wc : x0);
+            // A new crop, centred on the bounding box of the candidates from k on that can share it (k is the top-most uncovered
+            // one: the list is sorted by index).  With the origin ROUNDED to a multiple of 8 the core covers centre - 7 .. centre + 7
+            // at least, so a cluster of up to 15 x 15 pixels -- the flat top of a saturated blob -- takes ONE crop (a crop centred on
+            // the first candidate, the top row of the blob, left its lower half to a second crop).
+            const int span_y = a.Hc - 2 * a.R - 2 - 7, span_x = a.Wc - 2 * a.R - 2 - 7;
+            int ylo = cy, yhi = cy, xlo = cx, xhi = cx;
+            for (int j = k + 1; j < cnt; ++j) {
+                const int yj = ci[j] / a.W, xj = ci[j] % a.W;
+                if (yj - cy >= span_y) break;
+                const int nxlo = xj < xlo ? xj : xlo, nxhi = xj > xhi ? xj : xhi;
+                if (nxhi - nxlo >= span_x) continue;
+                xlo = nxlo; xhi = nxhi; yhi = yj;
+            }
+            auto origin = [](int c, int crop, int full) {
+                int o = ((c - crop / 2 + 4) >> 3) << 3;
+                return o < 0 ? 0 : (o > full - crop ? full - crop : o);
+            };
+            int y0 = origin((ylo + yhi) / 2, a.Hc, a.H), x0 = origin((xlo + xhi) / 2, a.Wc, a.W);
+            {
+                int cylo, cyhi, cxlo, cxhi;
+                core_range(y0, a.Hc, a.H, a.R, cylo, cyhi);
+                core_range(x0, a.Wc, a.W, a.R, cxlo, cxhi);
+                if (!(cy >= cylo && cy < cyhi && cx >= cxlo && cx < cxhi)) { y0 = origin(cy, a.Hc, a.H); x0 = origin(cx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
+            }
             my_y0[n_my] = y0; my_x0[n_my] = x0;
             found = n_my++;
         }

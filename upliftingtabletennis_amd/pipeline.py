@@ -203,8 +203,14 @@ class StreamWorker:
         if net.eps_violated(err):
             self.certify_eps = net.widen_eps(err)
             widened = True
-        # crop budget of the next clips: twice the crops this clip asked for (+ slack); clips that outgrow it are flagged and repaired
-        net.certify_budget(2 * n_crops + 16)
+        # crop budget of the next clips (it sizes the number of fp32 passes a call provisions; an unused pass still costs its launches):
+        # one and a half times the most any of the last eight clips asked for (+ slack) -- content that alternates between easy and
+        # hard clips keeps the hard clips' budget (twice the LAST clip's count sent 40 % of a hard clip that followed an easy one to
+        # the full-frame fp32 path); clips that outgrow it are flagged and repaired
+        hist = self.__dict__.setdefault('_crop_hist', [])
+        hist.append(int(n_crops))
+        del hist[:-8]
+        net.certify_budget(3 * max(hist) // 2 + 16)
         return widened
 
     def uplift_segments(self, positions, table_px, fps):
