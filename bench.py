@@ -260,43 +260,6 @@ def extras(device):
         torch.cuda.empty_cache()
     except Exception as e:          # the regime leg must not take the headline line down
         out['noise_weights_fps'] = {'error': repr(e)[:300]}
-    # the full pipeline on the headline weights but CHANGING content: four clips with their own background, noise, trajectory, blob
-    # size (sigma 1.3 / 2 / 3 / 4 px: the wide ones have flat, saturated tops, i.e. near-ties on every heatmap) and brightness gain,
-    # fed in turn -- the certification load of the headline clip (one blob size, one gain) is at the easy end
-    try:
-        from upliftingtabletennis_amd import synth
-        pv = Pipeline(device, seed=0, certify=True, planted=True)
-        clips = []
-        for c, (sigma, gain) in enumerate(((1.3, 0.7), (2.0, 1.0), (3.0, 1.3), (4.0, 1.6))):
-            base, _ = synth.synth_frames(34, H_SRC, W_SRC, seed=100 + c, sigma=sigma)
-            base = np.clip(np.rint(base.astype(np.float32) * gain), 0, 255).astype(np.uint8)
-            reps = (TRIPLES + 2 + len(base) - 1) // len(base)
-            clips.append(torch.from_numpy(np.concatenate([base] * reps)[:TRIPLES + 2]).to(device))
-        for cl in clips:                     # warm-up: every clip once (the audits settle eps for this content)
-            pv.worker.collect(pv.worker.submit(cl), pv.table_px, pv.fps)
-        pv.net.certify_stats(reset=True)
-        torch.cuda.synchronize()
-        k = 8
-        t0 = time.perf_counter()
-        tk = None
-        for i in range(k):
-            nx = pv.worker.submit(clips[i % len(clips)])
-            if tk is not None:
-                pv.worker.collect(tk, pv.table_px, pv.fps)
-            tk = nx
-        pv.worker.collect(tk, pv.table_px, pv.fps)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / k
-        cs, au = pv.net.certify_stats(), pv.worker.audit
-        out['varied_content_fps'] = {'value': round(TRIPLES / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2),
-                                     'config': 'the headline pipeline and weights on four alternating clips: blob sigma 1.3 / 2 / 3 / 4 px, brightness gain 0.7 / 1.0 / 1.3 / 1.6, own background and noise each',
-                                     'eps_abs': round(au['eps'], 6), 'eps_widened': au['widened'], 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3),
-                                     'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
-                                     'recertified_clips': au['recertified_clips'], 'recertified_heatmaps': au['recertified_heatmaps']}
-        del pv, clips
-        torch.cuda.empty_cache()
-    except Exception as e:
-        out['varied_content_fps'] = {'error': repr(e)[:300]}
     # config 3: uplift only, 10 000 trajectories x 120 steps (+1 padded token)
     B, T = 10000, 120
     arrs = [torch.from_numpy(a).to(device) for a in synth.synth_trajectories(2000, T, seed=0, pad=1)]
@@ -353,6 +316,44 @@ def extras(device):
     out['trajgen_traj_s'] = {'value': round(len(tr) / dt, 1), 'unit': 'trajectories/s', 'seconds': round(dt, 3),
                              'config': 'BASELINE config 5: 125000 accepted final_lose trajectories, device RK4 + selection, reference-format dicts on the host',
                              'device_seeds_s': round(262144 / dt_dev, 1), 'device_accepted_traj_s': round(acc / dt_dev, 1)}
+    # (last of the legs: every pipeline built here shifts the stream -> hardware-queue mapping of what follows)
+    # the full pipeline on the headline weights but CHANGING content: four clips with their own background, noise, trajectory, blob
+    # size (sigma 1.3 / 2 / 3 / 4 px: the wide ones have flat, saturated tops, i.e. near-ties on every heatmap) and brightness gain,
+    # fed in turn -- the certification load of the headline clip (one blob size, one gain) is at the easy end
+    try:
+        from upliftingtabletennis_amd import synth
+        pv = Pipeline(device, seed=0, certify=True, planted=True)
+        clips = []
+        for c, (sigma, gain) in enumerate(((1.3, 0.7), (2.0, 1.0), (3.0, 1.3), (4.0, 1.6))):
+            base, _ = synth.synth_frames(34, H_SRC, W_SRC, seed=100 + c, sigma=sigma)
+            base = np.clip(np.rint(base.astype(np.float32) * gain), 0, 255).astype(np.uint8)
+            reps = (TRIPLES + 2 + len(base) - 1) // len(base)
+            clips.append(torch.from_numpy(np.concatenate([base] * reps)[:TRIPLES + 2]).to(device))
+        for cl in clips:                     # warm-up: every clip once (the audits settle eps for this content)
+            pv.worker.collect(pv.worker.submit(cl), pv.table_px, pv.fps)
+        pv.net.certify_stats(reset=True)
+        torch.cuda.synchronize()
+        k = 8
+        t0 = time.perf_counter()
+        tk = None
+        for i in range(k):
+            nx = pv.worker.submit(clips[i % len(clips)])
+            if tk is not None:
+                pv.worker.collect(tk, pv.table_px, pv.fps)
+            tk = nx
+        pv.worker.collect(tk, pv.table_px, pv.fps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        cs, au = pv.net.certify_stats(), pv.worker.audit
+        out['varied_content_fps'] = {'value': round(TRIPLES / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2),
+                                     'config': 'the headline pipeline and weights on four alternating clips: blob sigma 1.3 / 2 / 3 / 4 px, brightness gain 0.7 / 1.0 / 1.3 / 1.6, own background and noise each',
+                                     'eps_abs': round(au['eps'], 6), 'eps_widened': au['widened'], 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3),
+                                     'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
+                                     'recertified_clips': au['recertified_clips'], 'recertified_heatmaps': au['recertified_heatmaps']}
+        del pv, clips
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out['varied_content_fps'] = {'error': repr(e)[:300]}
     return out
 
 
