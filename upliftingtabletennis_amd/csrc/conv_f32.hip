@@ -24,9 +24,13 @@ struct ConvF32Args {
     int tiles_x, tiles_per_img, wstr;
 };
 
-template <int KS, int S, int MT>
+// RPW = output rows per wave (tile of 4 * RPW rows x 16 columns): 2 in general; 4 for cout = 16, whose waves otherwise do 36 MFMAs
+// per (tile, channel chunk) item around two barriers and an LDS commit -- those layers ran at 69 TFLOP/s against the 106 of the
+// 64-channel one (now 78; 128->16: 89 -> 105).  The k order per output pixel (chunk, tap, channel) does not depend on the tile: the
+// results are bit-identical for every RPW.
+template <int KS, int S, int MT, int RPW>
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvF32Args a) {
-    constexpr int TH = 8, TW = 16, CK = 8, TAPS = KS * KS, PAD = KS / 2;
+    constexpr int TH = 4 * RPW, TW = 16, CK = 8, TAPS = KS * KS, PAD = KS / 2;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, NPIX = IH * IW;
     constexpr int NPAD = ((NPIX + 15) / 32) * 32 + 16;            // >= NPIX, = 16 mod 32
     static_assert(NPAD >= NPIX, "plane stride");
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvF32Args a) {
             if (u < W_UNITS) *(f32x4*)(s_w + (u / CQ) * wstr + (u % CQ) * 4) = pw[k];
         }
     };
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][RPW];
     if (n_items > 0) issue(0);
     for (int item = 0; item < n_items; ++item) {
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
@@ -99,29 +103,33 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvF32Args a) {
         if (item + 1 < n_items) issue(item + 1);
         if (chunk == 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[m][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = tap / KS, dx = tap % KS;
 #pragma unroll
             for (int kk = 0; kk < CK / 4; ++kk) {
-                const float* xp = s_x + (kk * 4 + g) * NPAD + ((2 * wave) * S + dy) * IW + n * S + dx;
-                const float b0 = xp[0], b1 = xp[S * IW];
+                const float* xp = s_x + (kk * 4 + g) * NPAD + ((RPW * wave) * S + dy) * IW + n * S + dx;
+                float bq[RPW];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) bq[r] = xp[r * S * IW];
                 const float* wp = s_w + (tap * CK + kk * 4 + g) * wstr + n;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const float af = wp[m * 16];
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[m][1], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bq[r], acc[m][r], 0, 0, 0);
                 }
             }
         }
         if (chunk != nchunk - 1) continue;
-        // epilogue: lane (n, g) holds couts m*16 + 4g .. +3 of pixel (row 2*wave + t, column n)
+        // epilogue: lane (n, g) holds couts m*16 + 4g .. +3 of pixel (row RPW*wave + t, column n)
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int oy = oy0 + 2 * wave + t2, ox = ox0 + n;
+        for (int t2 = 0; t2 < RPW; ++t2) {
+            const int oy = oy0 + RPW * wave + t2, ox = ox0 + n;
             if (oy >= a.OH || ox >= a.OW) continue;
             const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.cout;
 #pragma unroll
@@ -139,22 +147,33 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvF32Args a) {
     }
 }
 
+template <int KS, int S, int MT, int RPW>
+static int launch_f32_rpw(ConvF32Args& a, hipStream_t st);
+
 template <int KS, int S, int MT>
 static int launch_f32_t(ConvF32Args& a, hipStream_t st) {
-    constexpr int TH = 8, TW = 16, CK = 8, TAPS = KS * KS;
+    static const bool rpw2 = getenv("TTUP_F32_RPW2") != nullptr;          // cross-check: the 8-row tiles for every layer
+    constexpr int RPW = MT == 1 ? 4 : 2;          // measured: cout 16 +12...17 % with 16-row tiles, cout 32 -5...-11 %
+    if (RPW == 4 && rpw2) return launch_f32_rpw<KS, S, MT, 2>(a, st);
+    return launch_f32_rpw<KS, S, MT, RPW>(a, st);
+}
+
+template <int KS, int S, int MT, int RPW>
+static int launch_f32_rpw(ConvF32Args& a, hipStream_t st) {
+    constexpr int TH = 4 * RPW, TW = 16, CK = 8, TAPS = KS * KS;
     constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS, NPIX = IH * IW;
     constexpr int NPAD = ((NPIX + 15) / 32) * 32 + 16;
     a.tiles_x = cdiv(a.OW, TW);
     a.tiles_per_img = a.tiles_x * cdiv(a.OH, TH);
     a.wstr = a.cout + (a.cout > 16 ? 16 : 0);
     const size_t smem = (size_t)(CK * NPAD + TAPS * CK * a.wstr) * sizeof(float);
-    if (int rc = ensure_max_lds((const void*)conv_f32_mfma_kernel<KS, S, MT>, smem)) return rc;
+    if (int rc = ensure_max_lds((const void*)conv_f32_mfma_kernel<KS, S, MT, RPW>, smem)) return rc;
     const long long total = (long long)a.tiles_per_img * a.batch;
     if (total == 0) return TTUP_OK;
     int per_cu = (int)((160 * 1024) / smem);
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
     const int grid = total < 256 * per_cu ? (int)total : 256 * per_cu;
-    hipLaunchKernelGGL((conv_f32_mfma_kernel<KS, S, MT>), dim3(grid), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((conv_f32_mfma_kernel<KS, S, MT, RPW>), dim3(grid), dim3(256), smem, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
