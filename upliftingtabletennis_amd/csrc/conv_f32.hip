@@ -155,6 +155,8 @@ static int launch_f32_t(ConvF32Args& a, hipStream_t st) {
     static const bool rpw2 = getenv("TTUP_F32_RPW2") != nullptr;          // cross-check: the 8-row tiles for every layer
     constexpr int RPW = MT == 1 ? 4 : 2;          // measured: cout 16 +12...17 % with 16-row tiles, cout 32 -5...-11 %
     if (RPW == 4 && rpw2) return launch_f32_rpw<KS, S, MT, 2>(a, st);
+    // fewer 8-row tiles than CUs (the 1/8-resolution layers of one frame: 110 tiles): 4-row tiles fill twice as many CUs
+    if (RPW == 2 && !rpw2 && (long long)cdiv(a.OW, 16) * cdiv(a.OH, 8) * a.batch < 256) return launch_f32_rpw<KS, S, MT, 1>(a, st);
     return launch_f32_rpw<KS, S, MT, RPW>(a, st);
 }
 
