@@ -98,3 +98,27 @@ def test_gather_records_single_process():
     rec = {'a': torch.arange(6).reshape(3, 2)}
     got = pipeline.gather_records(rec, None)
     assert torch.equal(got['a'][0], rec['a'])
+
+
+def test_crop_budget_follows_the_largest_demand_of_recent_clips():
+    """StreamWorker._after_clip sizes the crop budget of the next calls from the last eight clips' demand (1.5 x the largest + 16):
+    a hard clip behind an easy one keeps its budget (the round's varied-content regime lost 40 % of such a clip's heatmaps to the
+    full-frame fp32 path under 'twice the last clip').  Host logic only: the handle is a stub."""
+    class Net:
+        def __init__(self):
+            self.budgets = []
+        def note_error(self, e, n=0):
+            return e
+        def eps_violated(self, e):
+            return False
+        def certify_budget(self, n):
+            self.budgets.append(n)
+    w = object.__new__(pipeline.StreamWorker)
+    w.net = Net()
+    w.certify_eps = 0.05
+    for n_crops in (15, 68, 256, 256, 15, 68):
+        assert w._after_clip(n_crops, 0.01, None) is False
+    assert w.net.budgets == [38, 118, 400, 400, 400, 400]
+    for n_crops in (10,) * 8:                      # the hard clips age out of the window
+        w._after_clip(n_crops, 0.01, None)
+    assert w.net.budgets[-1] == 31
