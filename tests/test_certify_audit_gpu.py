@@ -214,7 +214,7 @@ def test_uplift_beside_the_cnn_is_bit_stable():
 def test_soak_on_changing_content_matches_the_fp32_path():
     """tools/soak_audit.py with 8 clips: new background / noise / trajectory / blob size / brightness per clip, the continuous audit
     on (one triple per 16), every triple compared with the full-frame fp32 path: no index and no fp32-window mismatch, whatever the
-    audits widen on the way (profiles/r3_soak_audit.json holds the 40-clip run)."""
+    audits widen on the way (profiles/r3_soak_audit.json holds a 160-clip run)."""
     import json
     import subprocess
     import sys
