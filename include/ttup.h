@@ -50,6 +50,10 @@ typedef struct ttup_wasb   ttup_wasb;
 typedef struct ttup_uplift ttup_uplift;
 
 int         ttup_version(void);
+/* 16 hex digits: the hash of the sources (csrc/*.hip, csrc/*.h, include/ttup.h) and compiler flags this library was built
+ * from, compiled in by upliftingtabletennis_amd/build.py (source_id()).  The Python binding refuses a library whose id differs
+ * from its source tree's, so a run proves which kernels it ran. */
+const char* ttup_build_id(void);
 const char* ttup_last_error(void);
 /* number of visible HIP devices, <0 on error; does not initialise a context */
 int         ttup_device_count(void);
@@ -130,10 +134,13 @@ int ttup_peak_hbm(size_t bytes, double* out_host, void* stream);
  * returns peaks re-evaluates the pixels within 2*eps_abs of the bf16 maximum on fp32 receptive-field crops (crop x crop pixels,
  * 0 = 168, the smallest that holds the 72-pixel receptive-field radius on both sides; at most max_crops_per_map per heatmap, 0 = 4) inside the same call, without host synchronisation, and returns the
  * fp32 winner and its fp32 3x3 window.  eps_abs < 0 switches it off.  csrc/certify.hip.
- * status (after a forward, per heatmap), bits 0-1: 0 = one candidate (the bf16 index is certain), 1 = resolved on fp32 crops,
- * 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned); bit 2 (value 4): the GUARD band -- the pixels
- * between 2*eps_abs and 2*1.25*eps_abs below the maximum -- is not empty: a heatmap WITHOUT that bit has the same candidates, and
- * so the same certified result, under any eps up to 1.25*eps_abs (a caller that widens eps re-runs only the heatmaps with it).
+ * status (after a forward, per heatmap; ttup_wasb_certify_status): 0 = one candidate (the bf16 index is certain), 1 = resolved on
+ * fp32 crops, 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned).
+ * flags (ttup_wasb_certify_flags): the status with bit 2 (value 4) set when the GUARD band -- the pixels between 2*eps_abs and
+ * 2*1.25*eps_abs below the maximum -- is not empty: a heatmap WITHOUT that bit has the same candidates, and so the same certified
+ * result, under any eps up to 1.25*eps_abs (a caller that widens eps re-runs only the heatmaps with it).
+ * Both copies (and ttup_wasb_certify_info) belong to the handle's LAST forward and are ordered by the library against the next
+ * forward that reuses the per-call slot, whatever stream that one is issued on.
  * stats (cumulated, synchronises): {heatmaps, single-candidate, resolved, not certified, crops, candidates of resolved,
  * bits of max |bf16 - fp32| seen at a candidate (a float in the low 32 bits: the free part of the eps audit), single-candidate
  * heatmaps cropped in exact-window mode}. */
@@ -156,6 +163,7 @@ int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on);
  * |bf16 - fp32| seen so far at any candidate of any call (stats[6]); both copied in stream order, no synchronisation */
 int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream);
 int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
+int ttup_wasb_certify_flags(ttup_wasb* net, int batch, int* flags_dev, void* stream);
 /* crops the following forward calls may use (default: max_batch, i.e. one per heatmap): the call enqueues ceil(budget / 64) fp32
  * passes sized on the device, so a caller that knows its typical crop count (stats / status of earlier calls) saves the empty
  * passes; heatmaps beyond the budget are flagged 2 */

@@ -28,7 +28,24 @@ def test_header_symbols_exported(lib):
     assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ttup_version() >= 100
+    assert lib.ttup_version() >= 101
+
+
+def test_library_carries_the_hash_of_this_trees_sources(lib, tmp_path, monkeypatch):
+    """nothing tied the loaded libttup.so to HEAD's sources (objects are git-ignored and travel to the GPU box as
+    built).  build.py hashes csrc/*.hip, csrc/*.h, include/ttup.h and the flags into the library; the binding refuses a mismatch."""
+    from upliftingtabletennis_amd import build
+    assert lib.ttup_build_id().decode() == build.source_id() == _lib.build_id()
+    assert re.fullmatch(r'[0-9a-f]{16}', build.source_id())
+    # a different tree (one more source file) -> a different id -> the check raises
+    real = build.source_id
+    monkeypatch.setattr(build, 'source_id', lambda: 'f' * 16)
+    monkeypatch.delenv('TTUP_LIB', raising=False)
+    monkeypatch.delenv('TTUP_ALLOW_STALE_LIB', raising=False)
+    with pytest.raises(RuntimeError, match='built from other sources'):
+        _lib._check_build_id(lib)
+    monkeypatch.setattr(build, 'source_id', real)
+    _lib._check_build_id(lib)
 
 
 def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):

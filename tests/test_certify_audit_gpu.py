@@ -130,6 +130,42 @@ def test_pipelined_repair_uses_the_tickets_own_status():
     assert n_flagged == worker.fp32_reruns
 
 
+def test_slot_reuse_after_a_whole_clip_rerun_keeps_every_tickets_status():
+    """Round-3 advisor (medium): a whole-clip re-run inside collect() is ONE extra forward on the production handle, which flips the
+    per-call slot: from then on clip m on stream X reuses the slot of clip m-1 on stream Y while m-1's status / info copies may still
+    be pending.  The library orders the slot's reset behind those copies (per-slot read events).  Here: a collect-time whole-clip
+    re-run, then four more clips two deep in the pipeline, many of their heatmaps over the candidate budget (status 2): every
+    ticket must carry its OWN status, every flagged heatmap must be repaired, every index must be the fp32 path's."""
+    sd = weights.random_wasb_state_dict(3)
+    usd = weights.random_uplift_state_dict(3, 'large')
+    clips = [torch.from_numpy(synth.synth_frames(14, H, W, seed=60 + k)[0]).cuda() for k in range(5)]
+    worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=0)
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    worker.process_clip(clips[0], table_px, 60.0)
+    worker.certify_eps = worker.net.widen_eps(worker.certify_eps * 2)
+    t0 = worker.submit(clips[0])
+    worker.certify_eps = worker.net.widen_eps(worker.certify_eps * 2 / worker.net.HEADROOM)      # past the guard factor: whole clip again
+    o0 = worker.collect(t0, table_px, 60.0)
+    assert worker.recertified_clips >= 1
+    refs = [_fp32_peaks(sd, c, (W, H)) for c in clips]
+    assert torch.equal(t0['idx'], refs[0][0])
+    for rep in range(3):
+        tickets, outs = [worker.submit(clips[1]), worker.submit(clips[2])], []
+        for k in (3, 4):
+            outs.append(worker.collect(tickets[len(outs)], table_px, 60.0))
+            tickets.append(worker.submit(clips[k]))
+        outs += [worker.collect(t, table_px, 60.0) for t in tickets[2:]]
+        n_flagged = 0
+        for k, (t, o) in enumerate(zip(tickets, outs)):
+            ref_idx, ref_win, ref_xyv = refs[k + 1]
+            n_flagged += int((o['status'] == 2).sum())
+            assert torch.equal(t['idx'], ref_idx), (rep, k)
+            fp32_win = torch.from_numpy(o['status'] != 0).cuda()
+            assert torch.equal(t['win'][fp32_win], ref_win[fp32_win]) and torch.equal(o['xyv'][fp32_win], ref_xyv[fp32_win])
+        assert n_flagged > 0, 'premise: some heatmaps must overflow the candidate budget'
+    print('\n%d heatmaps flagged in the last round, %d fp32 re-runs in all, %d whole-clip re-runs' % (n_flagged, worker.fp32_reruns, worker.recertified_clips))
+
+
 def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
     """eps is widened by 15 % between submit and collect (what a new error maximum does).  Heatmaps whose guard band -- the pixels
     between 2 eps and 2.5 eps below the maximum -- is empty have the same candidate set under the new eps and keep their result;

@@ -16,6 +16,7 @@ _vp, _i, _sz = _c.c_void_p, _c.c_int, _c.c_size_t
 # name -> (restype, argtypes): every symbol include/ttup.h declares
 SIGNATURES = {
     'ttup_version': (_i, []),
+    'ttup_build_id': (_c.c_char_p, []),
     'ttup_last_error': (_c.c_char_p, []),
     'ttup_device_count': (_i, []),
     'ttup_preprocess_triples': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -37,6 +38,7 @@ SIGNATURES = {
     'ttup_wasb_certify_exact_windows': (_i, [_vp, _i]),
     'ttup_wasb_certify_info': (_i, [_vp, _vp, _vp]),
     'ttup_wasb_certify_status': (_i, [_vp, _i, _vp, _vp]),
+    'ttup_wasb_certify_flags': (_i, [_vp, _i, _vp, _vp]),
     'ttup_wasb_certify_stats': (_i, [_vp, _vp, _i]),
     'ttup_wasb_set_priority': (_i, [_vp, _i]),
     'ttup_wasb_micro_batch': (_i, [_vp]),
@@ -76,8 +78,26 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        _check_build_id(lib)
         _lib = lib
     return _lib
+
+
+def build_id():
+    """The source hash compiled into the loaded library (ttup_build_id)."""
+    return load().ttup_build_id().decode()
+
+
+def _check_build_id(lib):
+    """The library must have been built from THIS tree's sources (a stale libttup.so would otherwise pass for HEAD's
+    kernels).  TTUP_LIB (ablation builds of a modified copy) and TTUP_ALLOW_STALE_LIB=1 skip the check."""
+    if 'TTUP_LIB' in os.environ or os.environ.get('TTUP_ALLOW_STALE_LIB') == '1':
+        return
+    from . import build
+    have, want = lib.ttup_build_id().decode(), build.source_id()
+    if have != want:
+        raise RuntimeError('libttup.so was built from other sources (library %s, tree %s): rebuild it with '
+                           '`python -m upliftingtabletennis_amd.build`' % (have, want))
 
 
 def check(rc):

@@ -50,7 +50,11 @@ int device_normalise_lut(const float** lut_dev) {
 }
 }  // namespace ttup
 
-extern "C" int ttup_version(void) { return 100; }
+#ifndef TTUP_BUILD_ID
+#error "TTUP_BUILD_ID is not defined: build with `python -m upliftingtabletennis_amd.build` (it hashes the sources into the library)"
+#endif
+extern "C" int ttup_version(void) { return 101; }
+extern "C" const char* ttup_build_id(void) { return TTUP_BUILD_ID; }
 extern "C" const char* ttup_last_error(void) { return ttup::get_error(); }
 extern "C" int ttup_device_count(void) {
     int n = 0;

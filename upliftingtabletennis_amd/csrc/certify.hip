@@ -235,6 +235,8 @@ void cert_free(ttup_wasb* net) {
         void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.read_status) (void)hipEventDestroy(sl.read_status);
+        if (sl.read_info) (void)hipEventDestroy(sl.read_info);
         sl = CertState::Slot();
     }
     if (c.stats) (void)hipFree(c.stats);
@@ -250,6 +252,8 @@ int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
     c.cur ^= 1;
     CertState::Slot& sl = c.slot[c.cur];
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // the call that last used this slot has finished its fp32 passes
+    TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_status, 0));   // ... and its caller's status / info copies have been made
+    TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_info, 0));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.guard_cnt, 0, (size_t)batch * sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.n_crops, 0, sizeof(int), caller));
@@ -370,6 +374,8 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.status, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipMemset(sl.status, 0, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_status, hipEventDisableTiming));
+        TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_info, hipEventDisableTiming));
     }
     TTUP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     TTUP_HIP_CHECK(hipEventCreateWithFlags(&c.lanes_done, hipEventDisableTiming));
@@ -445,17 +451,39 @@ extern "C" int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on) {
 extern "C" int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream) {
     TTUP_REQUIRE(net && info_dev, TTUP_EINVAL, "ttup_wasb_certify_info: null pointer");
     TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_info: the certified argmax is not enabled on this handle");
-    TTUP_HIP_CHECK(hipMemcpyAsync(info_dev, net->cert.slot[net->cert.cur].n_crops, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    CertState::Slot& sl = net->cert.slot[net->cert.cur];
+    TTUP_HIP_CHECK(hipMemcpyAsync(info_dev, sl.n_crops, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     TTUP_HIP_CHECK(hipMemcpyAsync(info_dev + 1, net->cert.stats + 6, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));      // low word (little endian)
+    TTUP_HIP_CHECK(hipEventRecord(sl.read_info, (hipStream_t)stream));
     return TTUP_OK;
 }
 
-extern "C" int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream) {
-    TTUP_REQUIRE(net && status_dev, TTUP_EINVAL, "ttup_wasb_certify_status: null pointer");
-    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_status: the certified argmax is not enabled on this handle");
-    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "ttup_wasb_certify_status: batch %d outside [0,%d]", batch, net->max_batch);
-    TTUP_HIP_CHECK(hipMemcpyAsync(status_dev, net->cert.slot[net->cert.cur].status, (size_t)batch * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+namespace ttup { namespace {
+__global__ void cert_status_copy_kernel(const int* __restrict__ src, int* __restrict__ dst, int n, int mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] & mask;
+}
+int copy_status(ttup_wasb* net, int batch, int* status_dev, int mask, hipStream_t st, const char* who) {
+    TTUP_REQUIRE(net && status_dev, TTUP_EINVAL, "%s: null pointer", who);
+    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "%s: the certified argmax is not enabled on this handle", who);
+    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "%s: batch %d outside [0,%d]", who, batch, net->max_batch);
+    CertState::Slot& sl = net->cert.slot[net->cert.cur];
+    if (batch > 0) {
+        hipLaunchKernelGGL(cert_status_copy_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, st, (const int*)sl.status, status_dev, batch, mask);
+        TTUP_LAUNCH_CHECK();
+    }
+    TTUP_HIP_CHECK(hipEventRecord(sl.read_status, st));
     return TTUP_OK;
+}
+} }
+
+// 0 / 1 / 2 per heatmap, as in ABI version 100 (the guard bit is NOT part of this value: callers compare it with 1 and 2)
+extern "C" int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream) {
+    return copy_status(net, batch, status_dev, 3, (hipStream_t)stream, "ttup_wasb_certify_status");
+}
+// status | 4 where the guard band is not empty
+extern "C" int ttup_wasb_certify_flags(ttup_wasb* net, int batch, int* flags_dev, void* stream) {
+    return copy_status(net, batch, flags_dev, 7, (hipStream_t)stream, "ttup_wasb_certify_flags");
 }
 
 extern "C" int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host, int reset) {

@@ -55,6 +55,11 @@ struct CertState {
         int* guard_cnt = nullptr;           // pixels per heatmap in the guard band below the candidate band
         int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
         hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
+        // the caller's copies of this slot's status / crop count (ttup_wasb_certify_status / _flags / _info, on whatever stream the
+        // caller issued them) have finished: the next call that takes the slot waits for them before it zeroes the slot (a call
+        // issued on ANOTHER stream -- e.g. after an odd number of extra calls changed the stream / slot pairing -- would otherwise
+        // reset the status under a pending copy; round-3 advisor, medium)
+        hipEvent_t read_status = nullptr, read_info = nullptr;
     } slot[2];
     int cur = 0;                            // slot of the call being issued / last issued
     unsigned long long* stats = nullptr;

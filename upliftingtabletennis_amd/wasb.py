@@ -231,8 +231,9 @@ class WASBNet:
         when eps is widened (heatmaps without it keep their result under any eps up to GUARD times the one they ran with)."""
         st = torch.empty((batch,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.ttup_wasb_certify_status(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
-        return st if raw else st & 3
+            fn = self._lib.ttup_wasb_certify_flags if raw else self._lib.ttup_wasb_certify_status
+            _lib.check(fn(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
+        return st
 
     def certify_info(self):
         """(2,) int32 device tensor of the last forward, in stream order: [crops it asked for, bits of the largest |bf16 - fp32|
