@@ -50,7 +50,7 @@ typedef struct ttup_wasb   ttup_wasb;
 typedef struct ttup_uplift ttup_uplift;
 
 int         ttup_version(void);
-/* 16 hex digits: the hash of the sources (csrc/*.hip, csrc/*.h, include/ttup.h) and compiler flags this library was built
+/* 16 hex digits: the hash of the sources (every .hip and .h under csrc/, include/ttup.h) and compiler flags this library was built
  * from, compiled in by upliftingtabletennis_amd/build.py (source_id()).  The Python binding refuses a library whose id differs
  * from its source tree's, so a run proves which kernels it ran. */
 const char* ttup_build_id(void);
@@ -164,6 +164,10 @@ int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on);
 int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream);
 int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream);
 int ttup_wasb_certify_flags(ttup_wasb* net, int batch, int* flags_dev, void* stream);
+/* measurement: by how much the fp32 winner of each heatmap of the last forward leads the best OTHER candidate on the fp32 crops
+ * (float32 (batch); +inf where there was one candidate or the heatmap was not resolved).  A margin below the accuracy of the fp32
+ * path against the reference's own fp32 arithmetic marks a heatmap whose argmax the reference itself does not determine. */
+int ttup_wasb_certify_margins(ttup_wasb* net, int batch, float* margin_dev, void* stream);
 /* crops the following forward calls may use (default: max_batch, i.e. one per heatmap): the call enqueues ceil(budget / 64) fp32
  * passes sized on the device, so a caller that knows its typical crop count (stats / status of earlier calls) saves the empty
  * passes; heatmaps beyond the budget are flagged 2 */

@@ -39,3 +39,23 @@ def check_spin_pos(spin, pos3d, g, name, tol):
     assert d_norm <= tol and d_z <= tol, '|spin| / spin_z off by %.3e / %.3e rel (bar %.1e)' % (d_norm, d_z, tol)
     assert d_xy <= tol + turn, 'local spin x/y off by %.3e rel (bar %.1e + frame turn %.3e)' % (d_xy, tol, turn)
     return dp / pscale, d_norm, d_z, d_xy
+
+
+def hard_cases(g):
+    """Iterate the near-tie fixture tests/golden/wasb_hard.npz (tools/make_goldens.py gen_hard): yields
+    (key, weight seed, weight noise, clip seed, sigma, gain, n_frames, h, w) per clip."""
+    for si in range(int(g['n_sets'][0])):
+        for ci in range(int(g['n_clips'][si])):
+            key = 'set%d/clip%d' % (si, ci)
+            wseed, cseed, nf, h, w = [int(v) for v in g[key + '/meta']]
+            weps, sigma, gain = [float(v) for v in g[key + '/params']]
+            yield key, wseed, weps, cseed, sigma, gain, nf, h, w
+
+
+def hard_frames(g, key, cseed, sigma, gain, nf, h, w):
+    """The clip of a hard case, regenerated from its seed; the fixture's sha256 proves it is the one the reference ran on."""
+    import hashlib
+    from upliftingtabletennis_amd import synth
+    frames, _ = synth.hard_clip(nf, h, w, seed=cseed, sigma=sigma, gain=gain)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g[key + '/frames_sha256']), 'regenerated frames differ from the fixture\'s (%s)' % key
+    return frames

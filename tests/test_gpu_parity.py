@@ -472,6 +472,48 @@ def test_table_hrnet_matches_reference(golden, name):
     assert np.median(hm) < 1e-5 and hm.max() < 0.6
 
 
+@pytest.mark.parametrize('label,planted,eps', [('planted, all heads, noise 1.0', True, 1.0), ('planted, all heads, noise 0.2', True, 0.2), ('noise', False, 1.0)])
+def test_table_keypoints_certified_against_the_fp32_path(label, planted, eps):
+    """the 13 keypoint heatmaps of the table detector get the ball detector's guarantee -- the reference takes their
+    argmax from fp32 heatmaps (tabledetection/helper_tabledetection.py:50-156 behind interface.py:148-172).  64 frames of 1280x720
+    (four clips with their own background / blob size / gain) through a bf16 MyHRNet with the multi-channel certified argmax (one
+    scan / plan per heatmap, fp32 crops SHARED by the channels of a frame): every one of the 64 x 13 indices must equal the fp32
+    path's, and wherever an fp32 crop was evaluated the 3x3 window too.  The raw bf16 agreement is reported."""
+    sd = weights.random_wasb_state_dict(17, planted=planted, in_ch=3, head_out=13, eps=eps, plant_all_heads=planted)
+    clips = [synth.hard_clip(16, 720, 1280, seed=300 + c, sigma=sg, gain=gn)[0] for c, (sg, gn) in enumerate(((2.0, 1.0), (1.3, 0.7), (3.0, 1.3), (4.0, 1.6)))]
+    fr = torch.from_numpy(np.concatenate(clips)).cuda()
+    n, K = fr.shape[0], 13
+    net = wasb.get_table_model('hrnet', resolution=(1280, 704), state_dict=sd, max_batch=16, dtype='bf16')
+    f32 = wasb.get_table_model('hrnet', resolution=(1280, 704), state_dict=sd, max_batch=1, dtype='f32')
+    raw = torch.cat([net.forward_frames(fr[b0:b0 + 16])[1] for b0 in range(0, n, 16)]).cpu().numpy()
+    eps_abs = net.calibrate(fr, n=4)
+    assert net.certified and eps_abs > 0
+    idx, win, status = [], [], []
+    reruns = 0
+    for b0 in range(0, n, 16):
+        _, i1, w1 = net.forward_frames(fr[b0:b0 + 16])
+        st = net.certify_status(i1.shape[0]).cpu().numpy()
+        reruns += net.fix_uncertified(i1, w1, frames_u8=fr[b0:b0 + 16], status=st)
+        idx.append(i1); win.append(w1); status.append(st)
+    idx, win, status = torch.cat(idx).cpu().numpy(), torch.cat(win).cpu().numpy(), np.concatenate(status)
+    assert idx.shape == (n * K,) and win.shape == (n * K, 9) and status.shape == (n * K,)
+    ref_idx, ref_win = [], []
+    x = wasb.preprocess_frames(fr, (1280, 704))
+    for t in range(n):
+        _, i1, w1 = wasb.WASBNet.forward(f32, x[t:t + 1], want_heatmap=False, want_peaks=True)
+        ref_idx.append(i1.cpu().numpy()); ref_win.append(w1.cpu().numpy())
+    ref_idx, ref_win = np.concatenate(ref_idx), np.concatenate(ref_win)
+    cs = net.certify_stats()
+    print('\n[table, %s] eps %.4g: raw bf16 agreement %.4f, certified %.4f; single / resolved / flagged = %d / %d / %d of %d heatmaps, %d crops for %d frames '
+          '(%.2f per frame), %d frames re-run on the full-frame fp32 path'
+          % (label, eps_abs, (raw == ref_idx).mean(), (idx == ref_idx).mean(), (status == 0).sum(), (status == 1).sum(), (status == 2).sum(), n * K,
+             cs['crops'], n, cs['crops'] / n, reruns))
+    assert np.array_equal(idx, ref_idx)
+    exact = status != 0
+    assert np.array_equal(win[exact], ref_win[exact])
+    assert cs['heatmaps'] == n * K
+
+
 def test_ball_detector_clip_path_equals_triple_path():
     """`predict_clip` (frames uploaded once, fused pre-processing / CNN / argmax / windows) returns the positions `predict`
     returns for the (prev, curr, next) triples the reference builds; the planted weights give an unambiguous peak."""

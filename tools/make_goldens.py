@@ -321,6 +321,73 @@ def gen_fullsize():
           % (dt, b, torch.get_num_threads(), [(int(i % w), int(i // w)) for i in idx], track[1:1 + b].tolist(), flat[:, -2:].tolist()))
 
 
+HARD_SETS = [          # (weight seed, weight noise scale, [(clip seed, blob sigma, brightness gain), ...])
+    (0, 0.2, [(2000, 3.0, 1.3), (2001, 3.5, 1.5), (2002, 4.0, 1.6), (2003, 4.0, 1.3),      # bench.py's weights on the soak's hard content
+               # three clips picked (from seeds 2020-2059, reference run on 168x168 crops around the blob) for holding the SMALLEST reference
+               # top-2 margins: 2e-5, 1.4e-4, 1.8e-4 -- frames on which two fp32 evaluations need not agree
+               (2050, 3.8, 1.6), (2046, 3.4, 1.3), (2024, 3.7, 1.4)]),
+    (21, 1.0, [(2010, 3.5, 1.5), (2011, 4.0, 1.3)]),                                           # noisy planted weights: near-ties across the frame
+]
+HARD_FRAMES = 6           # per clip -> 4 triples
+
+
+def gen_hard():
+    """reference `WASBNet` (balldetection/models/wasb.py:596-608) at 704x1280 on NEAR-TIE content -- wide saturated
+    blobs (flat-topped heatmaps) on bench.py's planted weights, plus noisy planted weights (seed 21, noise 1) -- batch 1 per triple
+    like interface.py:102-119.  Per triple: the reference's argmax, its 16 largest values with their indices (the tied set under
+    any tolerance), the zero-padded 3x3 window (tabledetection/helper_tabledetection.py:63-77), a 32x32 crop around the argmax and
+    a 16x16 sub-sampling of the heatmap (what the test measures its HIP-fp32-vs-reference bound on).  Frames are generated AT the
+    network resolution (the unpinned cv2.resize is then the identity) by `synth.hard_clip`; their sha256 travels with the fixture."""
+    from upliftingtabletennis_amd import weights, synth
+    from oracle import glue_ref
+    h, w = 704, 1280
+    out, t0, n_tr = {}, time.time(), 0
+    margins = []
+    for si, (wseed, weps, clips) in enumerate(HARD_SETS):
+        sd = weights.random_wasb_state_dict(wseed, planted=True, eps=weps)
+        model, _ = ref_wasb(sd)
+        for ci, (cseed, sigma, gain) in enumerate(clips):
+            frames, track = synth.hard_clip(HARD_FRAMES, h, w, seed=cseed, sigma=sigma, gain=gain)
+            key = 'set%d/clip%d' % (si, ci)
+            nt = HARD_FRAMES - 2
+            rec = dict(argmax=np.zeros(nt, np.int64), top_idx=np.zeros((nt, 16), np.int64), top_val=np.zeros((nt, 16), np.float32),
+                       win=np.zeros((nt, 9), np.float32), crop32=np.zeros((nt, 32, 32), np.float32), crop32_origin=np.zeros((nt, 2), np.int64),
+                       sub16=np.zeros((nt, h // 16, w // 16), np.float32))
+            for t in range(nt):
+                x = glue_ref.triple_to_tensor(frames[t], frames[t + 1], frames[t + 2], (w, h))[None]
+                with torch.no_grad():
+                    heat, _ = model(torch.from_numpy(x))
+                hm = heat.numpy()[0, 0]
+                flat = hm.reshape(-1)
+                idx = int(flat.argmax())                                       # first maximum, like torch.argmax
+                assert idx == int(torch.argmax(heat.reshape(-1)))
+                order = np.argsort(-flat, kind='stable')[:16]
+                rec['argmax'][t] = idx
+                rec['top_idx'][t], rec['top_val'][t] = order, flat[order]
+                pad = np.pad(hm, 1)
+                y, xq = idx // w, idx % w
+                rec['win'][t] = pad[y:y + 3, xq:xq + 3].reshape(-1)
+                y0, x0 = int(np.clip(y - 16, 0, h - 32)), int(np.clip(xq - 16, 0, w - 32))
+                rec['crop32'][t], rec['crop32_origin'][t] = hm[y0:y0 + 32, x0:x0 + 32], (y0, x0)
+                rec['sub16'][t] = hm[::16, ::16]
+                margins.append(float(flat[order[0]] - flat[order[1]]))
+                n_tr += 1
+                print('hard %s t%d: argmax (%d,%d) blob (%.1f,%.1f) max %.4f margin %.5f  [%.0f s]'
+                      % (key, t, xq, y, track[t + 1][0], track[t + 1][1], flat[idx], margins[-1], time.time() - t0), flush=True)
+            for k, v in rec.items():
+                out['%s/%s' % (key, k)] = v
+            out[key + '/meta'] = np.array([wseed, cseed, HARD_FRAMES, h, w], np.int64)
+            out[key + '/params'] = np.array([weps, sigma, gain], np.float64)
+            out[key + '/frames_sha256'] = np.array(hashlib.sha256(frames.tobytes()).hexdigest())
+    out['n_sets'] = np.array([len(HARD_SETS)])
+    out['n_clips'] = np.array([len(c) for _, _, c in HARD_SETS])
+    out['ref_seconds_per_triple'] = np.array((time.time() - t0) / n_tr)
+    np.savez_compressed(os.path.join(OUT, 'wasb_hard.npz'), **out)
+    m = np.array(margins)
+    print('hard: %d triples, %.1f s each; reference top-2 margins: min %.2e median %.2e max %.2e; %d below 0.09, %d below 1e-3'
+          % (n_tr, (time.time() - t0) / n_tr, m.min(), np.median(m), m.max(), (m < 0.09).sum(), (m < 1e-3).sum()))
+
+
 def install_mujoco_standin(history):
     """`mujoco` is not importable here.  The reference's generator only needs containers (MjModel/MjData), the
     fixed camera pose and `mj_step`.  This stand-in provides the containers and REPLAYS states that oracle/trajgen_ref.py
@@ -613,6 +680,6 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib', 'e2e']
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib', 'e2e', 'hard']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'e2e': gen_e2e}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'e2e': gen_e2e, 'hard': gen_hard}[w_]()

@@ -39,6 +39,7 @@ SIGNATURES = {
     'ttup_wasb_certify_info': (_i, [_vp, _vp, _vp]),
     'ttup_wasb_certify_status': (_i, [_vp, _i, _vp, _vp]),
     'ttup_wasb_certify_flags': (_i, [_vp, _i, _vp, _vp]),
+    'ttup_wasb_certify_margins': (_i, [_vp, _i, _vp, _vp]),
     'ttup_wasb_certify_stats': (_i, [_vp, _vp, _i]),
     'ttup_wasb_set_priority': (_i, [_vp, _i]),
     'ttup_wasb_micro_batch': (_i, [_vp]),

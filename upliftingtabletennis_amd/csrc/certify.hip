@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void cert_scan_kernel(const float* __restrict_
 
 struct PlanArgs {
     int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats; float* cand_bf;
-    int K, maxc, max_crops, H, W, Hc, Wc, R, map0, exact;
+    int K, maxc, max_crops, H, W, Hc, Wc, R, frame0, exact;
+    int C, maxf;          // heatmap channels per frame (1 ball, 13 table keypoints) and crops a frame may use in all
     const int* guard_cnt;
+    float* margin;
 };
 
 // valid core of a crop along one axis: positions whose value AND 3x3 neighbourhood are exact
@@ -68,90 +70,119 @@ __device__ __forceinline__ void core_range(int o, int c, int full, int R, int& l
     hi = (o + c == full) ? full : o + c - R - 1;
 }
 
-// ---- 2. one workgroup (one wave) per heatmap: the wave sorts the candidates by index (the scan appends in arbitrary order; a
-// rank sort: every lane counts the smaller indices of its elements), lane 0 assigns them to crops.  K is sized for the flat top of
-// a wide saturated blob (a few hundred equal pixels inside one crop core), which used to overflow a 32-entry list and send the
-// heatmap to the full-frame fp32 path.
+// ---- 2. one workgroup (one wave) per FRAME, its C heatmaps (channels) in turn: the wave sorts a heatmap's candidates by index (the
+// scan appends in arbitrary order; a rank sort: every lane counts the smaller indices of its elements), lane 0 assigns them to crops.
+// The crops belong to the frame: a crop is one fp32 pass over a window of the frame and yields ALL C channels there, so the
+// keypoint heatmaps of the table detector share crops (the ball detector has C = 1).  K is sized for the flat top of a wide
+// saturated blob (a few hundred equal pixels inside one crop core), which used to overflow a 32-entry list and send the heatmap
+// to the full-frame fp32 path.
 constexpr int CERT_MAX_K = 512;
+constexpr int CERT_MAX_FRAME_CROPS = 16;
+constexpr int CERT_PENDING = 8;          // provisional status of a heatmap whose crops wait for their ids on the shared list
 __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     __shared__ int s_idx[CERT_MAX_K];
     __shared__ float s_bf[CERT_MAX_K];
+    __shared__ int my_y0[CERT_MAX_FRAME_CROPS], my_x0[CERT_MAX_FRAME_CROPS];
+    __shared__ int n_my_s;
     const int lane = threadIdx.x;
-    const int map = a.map0 + blockIdx.x;
-    const int cnt = a.cand_cnt[map];
-    const int gbit = a.guard_cnt[map] > 0 ? 4 : 0;          // status bit 2: the guard band is not empty
-    if (lane == 0) atomicAdd(&a.stats[0], 1ull);
-    // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
-    if (cnt <= 0 || (cnt == 1 && !a.exact)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } return; }
-    if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } return; }
-    int* ci = a.cand_idx + (size_t)map * a.K;
-    float* cb = a.cand_bf + (size_t)map * a.K;
-    for (int i = lane; i < cnt; i += 64) { s_idx[i] = ci[i]; s_bf[i] = cb[i]; }
+    const int frame = a.frame0 + blockIdx.x;
+    if (lane == 0) n_my_s = 0;
     __syncthreads();
-    for (int i = lane; i < cnt; i += 64) {
-        const int v = s_idx[i];
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) rank += s_idx[j] < v;          // pixel indices are distinct: ranks are a permutation
-        ci[rank] = v; cb[rank] = s_bf[i];
+    for (int ch = 0; ch < a.C; ++ch) {
+        const int map = frame * a.C + ch;
+        const int cnt = a.cand_cnt[map];
+        const int gbit = a.guard_cnt[map] > 0 ? 4 : 0;          // status bit 2: the guard band is not empty
+        if (lane == 0) { atomicAdd(&a.stats[0], 1ull); a.margin[map] = __int_as_float(0x7f800000); }
+        // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
+        if (cnt <= 0 || (cnt == 1 && !a.exact)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }
+        if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
+        int* ci = a.cand_idx + (size_t)map * a.K;
+        float* cb = a.cand_bf + (size_t)map * a.K;
+        __syncthreads();                                          // (the previous channel's lane-0 pass has finished with s_idx)
+        for (int i = lane; i < cnt; i += 64) { s_idx[i] = ci[i]; s_bf[i] = cb[i]; }
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) {
+            const int v = s_idx[i];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += s_idx[j] < v;          // pixel indices are distinct: ranks are a permutation
+            ci[rank] = v; cb[rank] = s_bf[i];
+        }
+        __syncthreads();
+        if (lane != 0) continue;
+        if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
+        // crops the frame has so far (from its earlier channels) are tried first; new ones are added behind them and dropped again
+        // if this heatmap turns out to need more than its budget (a heatmap that overflows after three crops used to leave those
+        // three on the list: wasted fp32 passes and budget taken from the heatmaps behind it)
+        int n_my = n_my_s;
+        const int n_before = n_my;
+        bool over = false;
+        for (int k = 0; k < cnt && !over; ++k) {
+            const int cy = ci[k] / a.W, cx = ci[k] % a.W;
+            int found = -1;
+            for (int c = 0; c < n_my && found < 0; ++c) {
+                int ylo, yhi, xlo, xhi;
+                core_range(my_y0[c], a.Hc, a.H, a.R, ylo, yhi);
+                core_range(my_x0[c], a.Wc, a.W, a.R, xlo, xhi);
+                if (cy >= ylo && cy < yhi && cx >= xlo && cx < xhi) found = c;
+            }
+            if (found < 0) {
+                if (n_my - n_before >= a.maxc || n_my >= a.maxf) { over = true; break; }
+                // A new crop, centred on the bounding box of the candidates from k on that can share it (k is the top-most uncovered
+                // one: the list is sorted by index).  With the origin ROUNDED to a multiple of 8 the core covers centre - 7 .. centre + 7
+                // at least, so a cluster of up to 15 x 15 pixels -- the flat top of a saturated blob -- takes ONE crop (a crop centred on
+                // the first candidate, the top row of the blob, left its lower half to a second crop).
+                const int span_y = a.Hc - 2 * a.R - 2 - 7, span_x = a.Wc - 2 * a.R - 2 - 7;
+                int ylo = cy, yhi = cy, xlo = cx, xhi = cx;
+                for (int j = k + 1; j < cnt; ++j) {
+                    const int yj = ci[j] / a.W, xj = ci[j] % a.W;
+                    if (yj - cy >= span_y) break;
+                    const int nxlo = xj < xlo ? xj : xlo, nxhi = xj > xhi ? xj : xhi;
+                    if (nxhi - nxlo >= span_x) continue;
+                    xlo = nxlo; xhi = nxhi; yhi = yj;
+                }
+                auto origin = [](int c, int crop, int full) {
+                    int o = ((c - crop / 2 + 4) >> 3) << 3;
+                    return o < 0 ? 0 : (o > full - crop ? full - crop : o);
+                };
+                int y0 = origin((ylo + yhi) / 2, a.Hc, a.H), x0 = origin((xlo + xhi) / 2, a.Wc, a.W);
+                {
+                    int cylo, cyhi, cxlo, cxhi;
+                    core_range(y0, a.Hc, a.H, a.R, cylo, cyhi);
+                    core_range(x0, a.Wc, a.W, a.R, cxlo, cxhi);
+                    if (!(cy >= cylo && cy < cyhi && cx >= cxlo && cx < cxhi)) { y0 = origin(cy, a.Hc, a.H); x0 = origin(cx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
+                }
+                my_y0[n_my] = y0; my_x0[n_my] = x0;
+                found = n_my++;
+            }
+            a.cand_crop[(size_t)map * a.K + k] = found;          // slot in the frame's list for now
+        }
+        if (over) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); continue; }          // (n_my_s keeps the list without this heatmap's new crops)
+        n_my_s = n_my;
+        a.status[map] = CERT_PENDING | gbit;
     }
     __syncthreads();
     if (lane != 0) return;
-    if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
-    // crops of this heatmap first in local slots; ids on the shared crop list are taken only once it is known that the heatmap stays
-    // within its budget (a heatmap that overflows after three crops used to leave those three on the list: wasted fp32 passes and
-    // budget taken from the heatmaps behind it)
-    int my_y0[8], my_x0[8], n_my = 0;
-    for (int k = 0; k < cnt; ++k) {
-        const int cy = ci[k] / a.W, cx = ci[k] % a.W;
-        int found = -1;
-        for (int c = 0; c < n_my && found < 0; ++c) {
-            int ylo, yhi, xlo, xhi;
-            core_range(my_y0[c], a.Hc, a.H, a.R, ylo, yhi);
-            core_range(my_x0[c], a.Wc, a.W, a.R, xlo, xhi);
-            if (cy >= ylo && cy < yhi && cx >= xlo && cx < xhi) found = c;
-        }
-        if (found < 0) {
-            if (n_my >= a.maxc) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }
-            // A new crop, centred on the bounding box of the candidates from k on that can share it (k is the top-most uncovered
-            // one: the list is sorted by index).  With the origin ROUNDED to a multiple of 8 the core covers centre - 7 .. centre + 7
-            // at least, so a cluster of up to 15 x 15 pixels -- the flat top of a saturated blob -- takes ONE crop (a crop centred on
-            // the first candidate, the top row of the blob, left its lower half to a second crop).
-            const int span_y = a.Hc - 2 * a.R - 2 - 7, span_x = a.Wc - 2 * a.R - 2 - 7;
-            int ylo = cy, yhi = cy, xlo = cx, xhi = cx;
-            for (int j = k + 1; j < cnt; ++j) {
-                const int yj = ci[j] / a.W, xj = ci[j] % a.W;
-                if (yj - cy >= span_y) break;
-                const int nxlo = xj < xlo ? xj : xlo, nxhi = xj > xhi ? xj : xhi;
-                if (nxhi - nxlo >= span_x) continue;
-                xlo = nxlo; xhi = nxhi; yhi = yj;
-            }
-            auto origin = [](int c, int crop, int full) {
-                int o = ((c - crop / 2 + 4) >> 3) << 3;
-                return o < 0 ? 0 : (o > full - crop ? full - crop : o);
-            };
-            int y0 = origin((ylo + yhi) / 2, a.Hc, a.H), x0 = origin((xlo + xhi) / 2, a.Wc, a.W);
-            {
-                int cylo, cyhi, cxlo, cxhi;
-                core_range(y0, a.Hc, a.H, a.R, cylo, cyhi);
-                core_range(x0, a.Wc, a.W, a.R, cxlo, cxhi);
-                if (!(cy >= cylo && cy < cyhi && cx >= cxlo && cx < cxhi)) { y0 = origin(cy, a.Hc, a.H); x0 = origin(cx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
-            }
-            my_y0[n_my] = y0; my_x0[n_my] = x0;
-            found = n_my++;
-        }
-        a.cand_crop[(size_t)map * a.K + k] = found;          // local slot for now
-    }
+    const int n_my = n_my_s;
+    if (n_my == 0) return;
     const int base = atomicAdd(a.n_crops, n_my);
     for (int c = 0; c < n_my && base + c < a.max_crops; ++c) {          // (records also for a list that fills up half way: the slots are run)
         int* rec = a.crop_rec + 4 * (base + c);
-        rec[0] = map; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
+        rec[0] = frame; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
     }
-    if (base + n_my > a.max_crops) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); return; }      // crop list full
-    for (int k = 0; k < cnt; ++k) a.cand_crop[(size_t)map * a.K + k] += base;
-    atomicAdd(&a.stats[4], (unsigned long long)n_my);
-    a.status[map] = 1 | gbit;
-    atomicAdd(&a.stats[2], 1ull);
-    atomicAdd(&a.stats[5], (unsigned long long)cnt);
+    const bool full = base + n_my > a.max_crops;                          // crop list full: the frame's heatmaps stay uncertified
+    if (!full) atomicAdd(&a.stats[4], (unsigned long long)n_my);
+    for (int ch = 0; ch < a.C; ++ch) {
+        const int map = frame * a.C + ch;
+        const int st = a.status[map];
+        if (!(st & CERT_PENDING)) continue;
+        const int gbit = st & 4;
+        if (full) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); continue; }
+        const int cnt = a.cand_cnt[map];
+        for (int k = 0; k < cnt; ++k) a.cand_crop[(size_t)map * a.K + k] += base;
+        a.status[map] = 1 | gbit;
+        atomicAdd(&a.stats[2], 1ull);
+        atomicAdd(&a.stats[5], (unsigned long long)cnt);
+    }
 }
 
 __global__ void cert_active_kernel(const int* n_crops, int* n_active, int CH, int nchunks, int max_crops) {
@@ -183,7 +214,7 @@ __global__ void cert_gather_kernel(const float* __restrict__ x, int in_ch, int H
 __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ cand_crop,
                                    const int* __restrict__ status, const int* __restrict__ crop_rec, const float* __restrict__ crop_heat,
                                    int K, int H, int W, int Hc, int Wc, int crop0, int CH, int n_maps, float* __restrict__ cand_val, float* __restrict__ cand_win,
-                                   const float* __restrict__ cand_bf, unsigned long long* __restrict__ stats) {
+                                   const float* __restrict__ cand_bf, unsigned long long* __restrict__ stats, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_maps * K) return;
     const int map = i / K, k = i % K;
@@ -192,7 +223,7 @@ __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* 
     if (id < crop0 || id >= crop0 + CH) return;
     const int* rec = crop_rec + 4 * id;
     const int gy = cand_idx[i] / W, gx = cand_idx[i] % W;
-    const float* h = crop_heat + (size_t)(id - crop0) * Hc * Wc;
+    const float* h = crop_heat + ((size_t)(id - crop0) * C + map % C) * Hc * Wc;          // crop_heat (CH, C, Hc, Wc)
     const float vf = h[(size_t)(gy - rec[1]) * Wc + (gx - rec[2])];
     cand_val[i] = vf;
     // audit of the error bound: |bf16 - fp32| at every candidate comes for free here; the running maximum sits in stats[6] (the
@@ -210,19 +241,22 @@ __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* 
 // ---- 4b. the fp32 winner of every heatmap that needed crops
 __global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ status,
                                     const float* __restrict__ cand_val, const float* __restrict__ cand_win, int K, int n_maps,
-                                    long long* __restrict__ argmax, float* __restrict__ win) {
+                                    long long* __restrict__ argmax, float* __restrict__ win, float* __restrict__ margin) {
     const int map = blockIdx.x * blockDim.x + threadIdx.x;
     if (map >= n_maps || (status[map] & 3) != 1) return;
     const int cnt = cand_cnt[map];
     float bv = cand_val[(size_t)map * K];
     long long bi = cand_idx[(size_t)map * K];
     int bk = 0;
+    float second = -__int_as_float(0x7f800000);
     for (int k = 1; k < cnt; ++k) {
         const float v = cand_val[(size_t)map * K + k];
         const long long i = cand_idx[(size_t)map * K + k];
-        if (better(v, i, bv, bi)) { bv = v; bi = i; bk = k; }
+        if (better(v, i, bv, bi)) { second = bv; bv = v; bi = i; bk = k; }
+        else if (v > second) second = v;
     }
     argmax[map] = bi;
+    margin[map] = bv - second;          // how far the fp32 winner is ahead of the best other candidate (measurement: "reference-ambiguous" share)
     for (int t = 0; t < 9; ++t) win[(size_t)map * 9 + t] = cand_win[((size_t)map * K + bk) * 9 + t];
 }
 
@@ -232,7 +266,7 @@ void cert_free(ttup_wasb* net) {
     CertState& c = net->cert;
     if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
     for (auto& sl : c.slot) {
-        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt};
+        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt, sl.margin};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.read_status) (void)hipEventDestroy(sl.read_status);
@@ -254,10 +288,11 @@ int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // the call that last used this slot has finished its fp32 passes
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_status, 0));   // ... and its caller's status / info copies have been made
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_info, 0));
-    TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, (size_t)batch * sizeof(int), caller));
-    TTUP_HIP_CHECK(hipMemsetAsync(sl.guard_cnt, 0, (size_t)batch * sizeof(int), caller));
+    const size_t maps = (size_t)batch * net->n_out;
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, maps * sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.guard_cnt, 0, maps * sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.n_crops, 0, sizeof(int), caller));
-    TTUP_HIP_CHECK(hipMemsetAsync(sl.status, 0, (size_t)batch * sizeof(int), caller));
+    TTUP_HIP_CHECK(hipMemsetAsync(sl.status, 0, maps * sizeof(int), caller));
     return TTUP_OK;
 }
 
@@ -267,13 +302,15 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     const long long hw = (long long)net->H * net->W;
     int nblk = (int)(hw / 4 / 256 / 8);           // 8 float4 per thread
     nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
-    hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
-                       sl.cand_idx + (size_t)b0 * c.K, sl.cand_cnt + b0, sl.cand_bf + (size_t)b0 * c.K, 2.f * c.eps * CertState::GUARD, sl.guard_cnt + b0);
+    const int C = net->n_out;          // heat: (mb, C, H, W) -- map index = frame * C + channel
+    const size_t m0 = (size_t)b0 * C;
+    hipLaunchKernelGGL(cert_scan_kernel, dim3(nblk, mb * C), dim3(256), 0, st, heat, argmax, hw, 2.f * c.eps, c.K,
+                       sl.cand_idx + m0 * c.K, sl.cand_cnt + m0, sl.cand_bf + m0 * c.K, 2.f * c.eps * CertState::GUARD, sl.guard_cnt + m0);
     TTUP_LAUNCH_CHECK();
     PlanArgs a;
     a.cand_idx = sl.cand_idx; a.cand_cnt = sl.cand_cnt; a.cand_crop = sl.cand_crop; a.crop_rec = sl.crop_rec; a.n_crops = sl.n_crops;
     a.status = sl.status; a.stats = c.stats; a.cand_bf = sl.cand_bf; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
-    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.map0 = b0; a.exact = c.exact_windows ? 1 : 0; a.guard_cnt = sl.guard_cnt;
+    a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.frame0 = b0; a.C = C; a.maxf = c.maxf; a.exact = c.exact_windows ? 1 : 0; a.guard_cnt = sl.guard_cnt; a.margin = sl.margin;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -292,7 +329,8 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
     hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, sl.n_crops, sl.n_active, c.CH, c.nchunks, c.budget);
     TTUP_LAUNCH_CHECK();
     // fp32 passes that can hold crops of THIS call: at most maxc per heatmap, at most the caller's budget
-    int nch = cdiv(batch * c.maxc < c.budget ? batch * c.maxc : c.budget, c.CH);
+    const int C = net->n_out;
+    int nch = cdiv(batch * c.maxf < c.budget ? batch * c.maxf : c.budget, c.CH);
     nch = nch > c.nchunks ? c.nchunks : nch;
     for (int ch = 0; ch < nch; ++ch) {
         const int crop0 = ch * c.CH;
@@ -310,17 +348,17 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
         }
         cn->n_active = na;
         int rc = run_ops(cn, c.CH, st);
-        if (rc == TTUP_OK) rc = launch_head(cn->tensors[cn->t_out].ptr, cn->head_w_dev, cn->head_b_dev, 1, c.crop_heat, c.CH, c.Hc, c.Wc, 16, TTUP_DTYPE_F32, st, na);
+        if (rc == TTUP_OK) rc = launch_head(cn->tensors[cn->t_out].ptr, cn->head_w_dev, cn->head_b_dev, C, c.crop_heat, c.CH, c.Hc, c.Wc, 16, TTUP_DTYPE_F32, st, na);
         cn->n_active = nullptr;
         if (rc) return rc;
-        const int nthr = batch * c.K;
+        const int nthr = batch * C * c.K;
         hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.cand_crop,
-                           (const int*)sl.status, (const int*)sl.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch,
-                           sl.cand_val, sl.cand_win, (const float*)sl.cand_bf, c.stats);
+                           (const int*)sl.status, (const int*)sl.crop_rec, (const float*)c.crop_heat, c.K, net->H, net->W, c.Hc, c.Wc, crop0, c.CH, batch * C,
+                           sl.cand_val, sl.cand_win, (const float*)sl.cand_bf, c.stats, C);
         TTUP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.status,
-                       (const float*)sl.cand_val, (const float*)sl.cand_win, c.K, batch, (long long*)argmax_dev, win_dev);
+    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch * C, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.status,
+                       (const float*)sl.cand_val, (const float*)sl.cand_win, c.K, batch * C, (long long*)argmax_dev, win_dev, sl.margin);
     TTUP_LAUNCH_CHECK();
     TTUP_HIP_CHECK(hipEventRecord(sl.done, st));
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // outputs are final in the caller's stream order
@@ -336,8 +374,8 @@ int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, i
 extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, int max_crops_per_map) {
     TTUP_REQUIRE(net, TTUP_EINVAL, "ttup_wasb_set_certify: null handle");
     if (eps_abs < 0.f) { (void)hipDeviceSynchronize(); cert_free(net); return TTUP_OK; }
-    TTUP_REQUIRE(net->dtype == TTUP_DTYPE_BF16 && net->fused_head && net->n_out == 1, TTUP_EINVAL,
-                 "ttup_wasb_set_certify: the certified argmax applies to the bf16 ball detector (one heatmap per sample)");
+    TTUP_REQUIRE(net->dtype == TTUP_DTYPE_BF16, TTUP_EINVAL,
+                 "ttup_wasb_set_certify: the certified argmax applies to bf16 handles (an fp32 handle's argmax is the fp32 argmax)");
     TTUP_REQUIRE(eps_abs == eps_abs && crop >= 0 && max_crops_per_map >= 0 && max_crops_per_map <= 8, TTUP_EINVAL, "ttup_wasb_set_certify: bad argument");
     CertState& c = net->cert;
     if (c.enabled) { c.eps = eps_abs; if (crop == 0 && max_crops_per_map == 0) return TTUP_OK; }
@@ -345,6 +383,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     cert_free(net);
     c.eps = eps_abs;
     c.maxc = max_crops_per_map > 0 ? max_crops_per_map : 4;
+    c.maxf = c.maxc * net->n_out < CERT_MAX_FRAME_CROPS ? c.maxc * net->n_out : CERT_MAX_FRAME_CROPS;      // the channels of a frame share its crops
     int side = crop > 0 ? crop : 168;
     TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 24, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 24);
     c.Hc = side < net->H ? side : net->H;
@@ -359,7 +398,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     TTUP_REQUIRE(c.nchunks <= 64, TTUP_EINVAL, "ttup_wasb_set_certify: max_batch %d too large", net->max_batch);
     c.max_crops = c.nchunks * c.CH;
     c.budget = net->max_batch < c.max_crops ? (net->max_batch > c.CH ? net->max_batch : c.CH) : c.max_crops;      // default: one crop per heatmap
-    const size_t nb = (size_t)net->max_batch;
+    const size_t nb = (size_t)net->max_batch * net->n_out;          // heatmaps per call
     for (auto& sl : c.slot) {
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_idx, nb * c.K * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.cand_cnt, nb * sizeof(int)));
@@ -372,6 +411,8 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_crops, sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_active, (size_t)c.nchunks * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.status, nb * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.margin, nb * sizeof(float)));
+        TTUP_HIP_CHECK(hipMemset(sl.margin, 0x7f, nb * sizeof(float)));
         TTUP_HIP_CHECK(hipMemset(sl.status, 0, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_status, hipEventDisableTiming));
@@ -381,7 +422,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     TTUP_HIP_CHECK(hipEventCreateWithFlags(&c.lanes_done, hipEventDisableTiming));
     TTUP_HIP_CHECK(hipMalloc((void**)&c.stats, 8 * sizeof(unsigned long long)));
     TTUP_HIP_CHECK(hipMemset(c.stats, 0, 8 * sizeof(unsigned long long)));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * c.Hc * c.Wc * sizeof(float)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * net->n_out * c.Hc * c.Wc * sizeof(float)));
     const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
     if (rc) { cert_free(net); return rc; }
     c.enabled = true;
@@ -466,7 +507,7 @@ __global__ void cert_status_copy_kernel(const int* __restrict__ src, int* __rest
 int copy_status(ttup_wasb* net, int batch, int* status_dev, int mask, hipStream_t st, const char* who) {
     TTUP_REQUIRE(net && status_dev, TTUP_EINVAL, "%s: null pointer", who);
     TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "%s: the certified argmax is not enabled on this handle", who);
-    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch, TTUP_EINVAL, "%s: batch %d outside [0,%d]", who, batch, net->max_batch);
+    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch * net->n_out, TTUP_EINVAL, "%s: %d heatmaps outside [0,%d]", who, batch, net->max_batch * net->n_out);
     CertState::Slot& sl = net->cert.slot[net->cert.cur];
     if (batch > 0) {
         hipLaunchKernelGGL(cert_status_copy_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, st, (const int*)sl.status, status_dev, batch, mask);
@@ -480,6 +521,16 @@ int copy_status(ttup_wasb* net, int batch, int* status_dev, int mask, hipStream_
 // 0 / 1 / 2 per heatmap, as in ABI version 100 (the guard bit is NOT part of this value: callers compare it with 1 and 2)
 extern "C" int ttup_wasb_certify_status(ttup_wasb* net, int batch, int* status_dev, void* stream) {
     return copy_status(net, batch, status_dev, 3, (hipStream_t)stream, "ttup_wasb_certify_status");
+}
+// fp32 top-2 margin among the candidates of every heatmap of the last forward (+inf for single-candidate / unresolved heatmaps)
+extern "C" int ttup_wasb_certify_margins(ttup_wasb* net, int batch, float* margin_dev, void* stream) {
+    TTUP_REQUIRE(net && margin_dev, TTUP_EINVAL, "ttup_wasb_certify_margins: null pointer");
+    TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_margins: the certified argmax is not enabled on this handle");
+    TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch * net->n_out, TTUP_EINVAL, "ttup_wasb_certify_margins: %d heatmaps outside [0,%d]", batch, net->max_batch * net->n_out);
+    CertState::Slot& sl = net->cert.slot[net->cert.cur];
+    if (batch > 0) TTUP_HIP_CHECK(hipMemcpyAsync(margin_dev, sl.margin, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    TTUP_HIP_CHECK(hipEventRecord(sl.read_status, (hipStream_t)stream));
+    return TTUP_OK;
 }
 // status | 4 where the guard band is not empty
 extern "C" int ttup_wasb_certify_flags(ttup_wasb* net, int batch, int* flags_dev, void* stream) {

@@ -42,7 +42,8 @@ struct CertState {
     static constexpr float GUARD = 1.25f;   // a heatmap with an empty guard band stays certified when eps is widened by up to this factor
     int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
     int K = 256;                         // candidates kept per heatmap (<= CERT_MAX_K, csrc/certify.hip): the flat top of a saturated blob fits
-    int maxc = 4;                        // crops per heatmap
+    int maxc = 4;                        // new crops a heatmap may add
+    int maxf = 4;                        // crops per frame (the channels of a frame share them: min(16, maxc * channels))
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
     bool exact_windows = false;          // every heatmap gets an fp32 crop (also single-candidate ones): all 3x3 windows are fp32 values
@@ -54,6 +55,7 @@ struct CertState {
         float* cand_bf = nullptr;           // the bf16 path's value of every candidate (audit: |bf16 - fp32| at the candidates is free)
         int* guard_cnt = nullptr;           // pixels per heatmap in the guard band below the candidate band
         int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
+        float* margin = nullptr;            // fp32 top-2 margin among the candidates of a resolved heatmap (+inf: one candidate / not resolved)
         hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
         // the caller's copies of this slot's status / crop count (ttup_wasb_certify_status / _flags / _info, on whatever stream the
         // caller issued them) have finished: the next call that takes the slot waits for them before it zeroes the slot (a call

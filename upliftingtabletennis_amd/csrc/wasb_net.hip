@@ -528,6 +528,8 @@ int forward_micro(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev,
         float* wn = win_dev ? win_dev + (size_t)b0 * K * 9 : net->win_scratch;
         rc = refine_argmax(heat, mb * K, H, W, am, wn, net->refine_ws, net->refine_ws_bytes, st);
         if (rc) return rc;
+        // certified argmax of the multi-channel head (table keypoints): the same scan / plan per heatmap, crops shared by a frame's channels
+        if (net->cert.enabled && argmax_dev && win_dev) return cert_scan(net, heat, am, b0, mb, st);
     }
     return TTUP_OK;
 }
@@ -537,7 +539,7 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
     const int n_micro = (batch + net->micro - 1) / net->micro;
     const int n_lanes = n_micro < (int)net->lanes.size() ? (n_micro > 0 ? n_micro : 1) : (int)net->lanes.size();
     const hipStream_t caller = st;
-    const bool certify = net->cert.enabled && net->fused_head && argmax_dev && win_dev && batch > 0;
+    const bool certify = net->cert.enabled && argmax_dev && win_dev && batch > 0;
     // Consecutive calls may come in on different caller streams (StreamWorker.submit alternates two) while the activations, the
     // heatmap scratch and the argmax workspace of a lane belong to ONE micro-batch at a time.  Handles with lane streams run every
     // micro-batch on its lane's stream -- also when the call has a single micro-batch -- so stream order serialises the lane's

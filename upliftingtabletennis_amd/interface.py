@@ -71,94 +71,68 @@ def _load_uplift_checkpoint():
     return weights.random_uplift_state_dict(int(os.environ.get('TTUP_SEED', '0')), 'large'), 'large', 'global'
 
 
-class BallDetector:
-    def __init__(self, model_name='segformerpp_b2', max_batch=32, dtype='bf16', lanes=0):
-        if 'segformerpp' in model_name or model_name == 'vitpose':
-            raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference "
-                                      "(KieDani/SegformerPlusPlus / mmcv); only 'wasb' is built" % model_name)
-        _lib.require_gpu()
-        self.device = torch.device('cuda')
-        self.resolution = (WIDTH, HEIGHT)
-        sd, res, in_frames = _load_ball_checkpoint(model_name)
-        self.model = wasb.get_model(model_name, in_frames=in_frames, resolution=res, pretraining=False, state_dict=sd,
-                                    max_batch=max_batch, dtype=dtype, lanes=lanes)
-        self.model_resolution = res
-        self.max_batch = max_batch
-
-    AUDIT_EVERY = 256          # triples per audited triple (see _audit_picks)
-
-    def predict(self, images):
-        """images: list (length B) of [prev, curr, next] BGR uint8 HWC arrays.
-        Returns (pred_pos (B,3) float64 [x, y, confidence] in 1920x1080 px, preds (B,1,H,W) float32)."""
-        pred_pos, preds = [], []
-        w, h = self.model_resolution
-        m = self.model
-        for b0 in range(0, len(images), self.max_batch):
-            chunk = images[b0:b0 + self.max_batch]
-            xs = []
-            for imgs in chunk:
-                fr = torch.from_numpy(np.stack([np.asarray(i) for i in imgs])).to(self.device)   # (3,h,w,3) uint8
-                xs.append(wasb.preprocess_triples(fr, (w, h)))
-            x = torch.cat(xs)
-            self._calibrate(x=x)
-            picks = self._audit_picks(x.shape[0])
-            while True:
-                # peaks from the certified argmax (the fp32 index the reference's torch.argmax returns), table-variant fit (interface.py:116)
-                heat, idx, win = m.forward(x, want_heatmap=True, want_peaks=True)
-                if not m.certified:
-                    break
-                status, info = m.certify_status(x.shape[0]), m.certify_info()          # (masked status: the float entry re-runs the whole chunk on a widening)
-                err = m.note_error(m.decode_info(info.cpu().numpy())[1])
-                for t in picks:        # eps audit: the bf16 heatmap of a random triple against the fp32 twin
-                    err = max(err, m.note_error(float(wasb.max_abs_diff(heat[t], m._twin().forward(x[t:t + 1])[0][0]).item()), 1))
-                picks = []
-                if m.eps_violated(err):
-                    m.widen_eps(err)
-                    continue
-                m.fix_uncertified(idx, win, x=x, status=status)
-                break
-            pos = refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
-            pred_pos.append(pos.cpu().numpy())
-            preds.append(heat.cpu().numpy())
-        if not pred_pos:
-            return np.zeros((0, 3)), np.zeros((0, 1, h, w), np.float32)
-        return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
+class _CertifiedDetector:
+    """What the two detectors share: the certified argmax (csrc/certify.hip) of a bf16 handle -- first estimate of the error bound
+    eps on the first input, the running audit, widening + re-certification, repair of over-budget heatmaps on the fp32 twin.
+    `self.model` is a wasb.WASBNet (one heatmap per triple) or a wasb.MyHRNet (13 keypoint heatmaps per frame)."""
+    AUDIT_EVERY = 256          # samples per audited sample (see _audit_picks)
+    NO_CERTIFY_ENV = ('TTUP_NO_CERTIFY',)
 
     def _calibrate(self, frames=None, x=None):
-        """Certified argmax (csrc/certify.hip): a first estimate of the bf16 path's error bound eps is measured on the first input
-        this detector sees, against the fp32 path; the audits (`_audit_picks`, the crops' candidate errors) keep checking it on later
-        inputs and widen it when one comes within the safety factor.  Every returned index is the fp32 argmax as long as eps bounds
-        the frame's error."""
+        """A first estimate of the bf16 path's error bound eps is measured on the first input this detector sees, against the fp32
+        path; the audits (`_audit_picks`, the crops' candidate errors) keep checking it on later inputs and widen it when one comes
+        within the safety factor.  Every returned index is the fp32 argmax as long as eps bounds the frame's error."""
         m = self.model
-        if m.certified or m.dtype != 'bf16' or os.environ.get('TTUP_NO_CERTIFY') == '1':
+        if m.certified or m.dtype != 'bf16' or any(os.environ.get(k) == '1' for k in self.NO_CERTIFY_ENV):
             return
         exact = os.environ.get('TTUP_EXACT_WINDOWS') == '1'
         if frames is None:
             n = min(2, x.shape[0])
-            hb, _ = m.forward(x[:n])
+            hb = m._heat(x[:n])
             twin = m._twin()
-            err = max(float(wasb.max_abs_diff(hb[k], twin.forward(x[k:k + 1])[0][0]).item()) for k in range(n))
+            err = max(float(wasb.max_abs_diff(hb[k], twin._heat(x[k:k + 1])[0]).item()) for k in range(n))
             m.set_certify(m.HEADROOM * err, exact_windows=exact)
             m.audit_state = dict(audited_frames=n, max_err_seen=err, widened=0)
         else:
             m.calibrate(frames, n=4, exact_windows=exact)
 
-    def _audit_picks(self, n_triples):
-        """One random triple per AUDIT_EVERY triples this detector has processed is re-run on the fp32 twin (eps audit)."""
-        if not self.model.certified or n_triples <= 0 or os.environ.get('TTUP_NO_AUDIT') == '1':
+    def _audit_picks(self, n_samples):
+        """One random sample per AUDIT_EVERY samples this detector has processed is re-run on the fp32 twin (eps audit)."""
+        if not self.model.certified or n_samples <= 0 or os.environ.get('TTUP_NO_AUDIT') == '1':
             return []
         rng = self.__dict__.setdefault('_audit_rng', np.random.default_rng(0))
-        self._since_audit = self.__dict__.get('_since_audit', 0) + n_triples
+        self._since_audit = self.__dict__.get('_since_audit', 0) + n_samples
         picks = []
         while self._since_audit >= self.AUDIT_EVERY:
             self._since_audit -= self.AUDIT_EVERY
-            picks.append(int(rng.integers(n_triples)))
+            picks.append(int(rng.integers(n_samples)))
         return picks
 
-    def _certified_peaks(self, fr):
-        """(idx, win) of the triples of the uint8 device clip `fr` (one forward call), certified under an audited eps."""
+    def _certified_forward(self, x):
+        """(heat, idx, win) of the float input x (the `self.model(x)` seam of `predict`): peaks from the certified argmax -- the fp32
+        index the reference's torch.argmax returns -- under an audited eps."""
         m = self.model
-        picks = self._audit_picks(fr.shape[0] - 2)
+        self._calibrate(x=x)
+        picks = self._audit_picks(x.shape[0])
+        while True:
+            heat, idx, win = wasb.WASBNet.forward(m, x, want_heatmap=True, want_peaks=True)
+            if not m.certified:
+                return heat, idx, win
+            status, info = m.certify_status(idx.shape[0]), m.certify_info()          # (masked status: the float entry re-runs the whole chunk on a widening)
+            err = m.note_error(m.decode_info(info.cpu().numpy())[1])
+            for t in picks:        # eps audit: the bf16 heatmaps of a random sample against the fp32 twin
+                err = max(err, m.note_error(float(wasb.max_abs_diff(heat[t], m._twin()._heat(x[t:t + 1])[0]).item()), 1))
+            picks = []
+            if m.eps_violated(err):
+                m.widen_eps(err)
+                continue
+            m.fix_uncertified(idx, win, x=x, status=status)
+            return heat, idx, win
+
+    def _certified_peaks(self, fr):
+        """(idx, win) of the samples of the uint8 device clip `fr` (one forward call), certified under an audited eps."""
+        m = self.model
+        picks = self._audit_picks(fr.shape[0] - (m.NF - 1))
         while True:
             audit = m.audit_async(fr, picks) if picks else None
             eps_used = m.eps if m.certified else None
@@ -179,6 +153,76 @@ class BallDetector:
                 st[todo] = 1
             m.fix_uncertified(idx, win, frames_u8=fr, status=st)
             return idx, win
+
+    def _settle_calls(self, calls, frames, audit=None):
+        """Host-side second half of certified forward calls that were only ENQUEUED (the overlapped clip path): `calls` = list of
+        dicts {f0, f1 (frame range of the call's input), idx, win, status (flags, host or device), info, eps}.  Folds the calls'
+        candidate errors and the audit into eps, re-certifies the heatmaps certified under a stale eps, repairs over-budget heatmaps
+        on the fp32 twin.  Returns the set of call positions whose idx / win changed (idx / win are updated in place, or replaced in
+        the dict when a whole call was run again)."""
+        m = self.model
+        changed = set()
+        if not m.certified or not calls:
+            return changed
+        err = m.note_error(max(m.decode_info(np.asarray(c['info'].cpu() if torch.is_tensor(c['info']) else c['info']))[1] for c in calls))
+        if audit is not None:
+            err = max(err, m.audit_result(audit))
+        if m.eps_violated(err):
+            m.widen_eps(err)
+        for k, c in enumerate(calls):
+            st = c['status'].cpu().numpy() if torch.is_tensor(c['status']) else np.array(c['status'])
+            fr = frames[c['f0']:c['f1']]
+            if c['eps'] < m.eps:
+                # an audit found eps too small: the heatmaps of this call whose guard band is not empty are run again under the
+                # widened eps; the whole call only when eps grew past the guard factor (audited, blocking; rare)
+                todo = m.recertify_subset(c['idx'], c['win'], st, c['eps'], fr)
+                if todo is None:
+                    c['idx'], c['win'] = self._certified_peaks(fr)
+                    changed.add(k)
+                    continue
+                if todo.size:
+                    st[todo] = 1
+                    changed.add(k)
+            if ((st & 3) == 2).any():
+                # rare: crop budget exceeded -> those samples on the full-frame fp32 path (with the call's own status)
+                m.fix_uncertified(c['idx'], c['win'], frames_u8=fr, status=st)
+                changed.add(k)
+        return changed
+
+
+class BallDetector(_CertifiedDetector):
+    def __init__(self, model_name='segformerpp_b2', max_batch=32, dtype='bf16', lanes=0):
+        if 'segformerpp' in model_name or model_name == 'vitpose':
+            raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference "
+                                      "(KieDani/SegformerPlusPlus / mmcv); only 'wasb' is built" % model_name)
+        _lib.require_gpu()
+        self.device = torch.device('cuda')
+        self.resolution = (WIDTH, HEIGHT)
+        sd, res, in_frames = _load_ball_checkpoint(model_name)
+        self.model = wasb.get_model(model_name, in_frames=in_frames, resolution=res, pretraining=False, state_dict=sd,
+                                    max_batch=max_batch, dtype=dtype, lanes=lanes)
+        self.model_resolution = res
+        self.max_batch = max_batch
+
+    def predict(self, images):
+        """images: list (length B) of [prev, curr, next] BGR uint8 HWC arrays.
+        Returns (pred_pos (B,3) float64 [x, y, confidence] in 1920x1080 px, preds (B,1,H,W) float32)."""
+        pred_pos, preds = [], []
+        w, h = self.model_resolution
+        for b0 in range(0, len(images), self.max_batch):
+            chunk = images[b0:b0 + self.max_batch]
+            xs = []
+            for imgs in chunk:
+                fr = torch.from_numpy(np.stack([np.asarray(i) for i in imgs])).to(self.device)   # (3,h,w,3) uint8
+                xs.append(wasb.preprocess_triples(fr, (w, h)))
+            # peaks from the certified argmax (the fp32 index the reference's torch.argmax returns), table-variant fit (interface.py:116)
+            heat, idx, win = self._certified_forward(torch.cat(xs))
+            pos = refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
+            pred_pos.append(pos.cpu().numpy())
+            preds.append(heat.cpu().numpy())
+        if not pred_pos:
+            return np.zeros((0, 3)), np.zeros((0, 1, h, w), np.float32)
+        return np.concatenate(pred_pos, axis=0), np.concatenate(preds, axis=0)
 
     def predict_clip(self, images):
         """Fast path for consecutive frames (what TableTennisPipeline.predict feeds the detector, interface.py:276-279):
@@ -209,10 +253,16 @@ def _load_table_checkpoint(model_name):
         sd, info = weights.load_checkpoint_state_dict(path)
         return sd, tuple(info.get('image_resolution', (1280, 704)))
     _synthetic_or_raise("TableDetector('%s')" % model_name, path if _weights_dir() else '')
-    return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')) + 1, planted=False, in_ch=3, head_out=13), (1280, 704)
+    # seeded stand-in: a planted path to every keypoint head, so the heatmaps are PEAKED like a trained detector's (one dominant
+    # maximum per keypoint map; on pure noise weights every map is a field of near-ties and the certified argmax degrades to the
+    # full-frame fp32 path -- TTUP_TABLE_NOISE_WEIGHTS=1 selects that regime)
+    noise = os.environ.get('TTUP_TABLE_NOISE_WEIGHTS') == '1'
+    return weights.random_wasb_state_dict(int(os.environ.get('TTUP_SEED', '0')) + 1, planted=not noise, in_ch=3, head_out=13, plant_all_heads=not noise), (1280, 704)
 
 
-class TableDetector:
+class TableDetector(_CertifiedDetector):
+    NO_CERTIFY_ENV = ('TTUP_NO_CERTIFY', 'TTUP_NO_TABLE_CERTIFY')
+
     def __init__(self, model_name='segformerpp_b2', max_batch=8, dtype='bf16', lanes=0):
         if 'segformerpp' in model_name or model_name == 'vitpose':
             raise NotImplementedError("detector '%s' depends on code that is not vendored in the reference; only 'hrnet' is built" % model_name)
@@ -233,8 +283,11 @@ class TableDetector:
         w, h = self.model_resolution
         for b0 in range(0, len(images), self.max_batch):
             fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[b0:b0 + self.max_batch]])).to(self.device)
-            heat = self.model(wasb.preprocess_frames(fr, (w, h)))
-            pred_pos.append(refine.extract_position_table(heat, self.resolution[0], self.resolution[1]))
+            # per-channel peaks from the certified argmax: the reference takes them from fp32 heatmaps (interface.py:148-172 ->
+            # tabledetection/helper_tabledetection.py:50-156)
+            heat, idx, win = self._certified_forward(wasb.preprocess_frames(fr, (w, h)))
+            pos = refine.refine_windows_device(idx, win, h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
+            pred_pos.append(pos.cpu().numpy().reshape(-1, 13, 3))
             preds.append(heat.cpu().numpy()[:, None])
         if not pred_pos:
             return np.zeros((0, 13, 3)), np.zeros((0, 1, 13, h, w), np.float32)
@@ -247,7 +300,8 @@ class TableDetector:
         out = []
         for b0 in range(0, len(images), self.max_batch):
             fr = torch.from_numpy(np.stack([np.asarray(i) for i in images[b0:b0 + self.max_batch]])).to(self.device)
-            _, idx, win = self.model.forward_frames(fr, want_heatmap=False)
+            self._calibrate(frames=fr)
+            idx, win = self._certified_peaks(fr)
             pos = refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), h, w, self.resolution[0], self.resolution[1], _lib.REFINE_TABLE)
             out.append(pos.cpu().numpy().reshape(-1, 13, 3))
         return np.concatenate(out, axis=0) if out else np.zeros((0, 13, 3))
@@ -362,7 +416,7 @@ class TableTennisPipeline:
         F0 = min(self.FIRST, C, n)
         bounds = [0, F0] + list(range(F0 + C, n, C)) + ([n] if n > F0 else [])
         bounds = sorted(set(bounds))
-        ball_out, table_out, ball_calls = [], [], []
+        ball_out, table_out, ball_calls, table_calls = [], [], [], []
         t_next = 0                        # first triple not yet submitted
         ev = None
         for ci, (c0, c1) in enumerate(zip(bounds[:-1], bounds[1:])):
@@ -377,10 +431,18 @@ class TableTennisPipeline:
             if ci == 0:
                 torch.cuda.current_stream(dev).wait_event(ev)
                 bd._calibrate(frames=frames[:c1]) if c1 >= 3 else None        # certified argmax: once per detector
+                if want_table:
+                    td._calibrate(frames=frames[:c1])
             if want_table:
                 with torch.cuda.stream(st['table']):
                     st['table'].wait_event(ev)
-                    _, idx, win = td.model.forward_frames(frames[c0:c1], want_heatmap=False)
+                    tm = td.model
+                    _, idx, win = tm.forward_frames(frames[c0:c1], want_heatmap=False)
+                    # status / info of THIS call, copied right behind it (per-call slot); the keypoints are refined at once from what
+                    # the call returned -- settled below, after the stream has drained, and refined again only where a repair changed them
+                    table_calls.append({'f0': c0, 'f1': c1, 'idx': idx, 'win': win, 'eps': tm.eps if tm.certified else None,
+                                        'status': tm.certify_status(idx.shape[0], raw=True) if tm.certified else None,
+                                        'info': tm.certify_info() if tm.certified else None})
                     table_out.append(refine.refine_windows_device(idx.reshape(-1), win.reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE))
             # triples t need frames t..t+2: everything up to c1-3 can go now
             while t_next < c1 - 2:
@@ -406,37 +468,43 @@ class TableTennisPipeline:
         if want_table:
             # the table detector (high-priority streams) finishes first: its keypoints come back and the host-side DBSCAN filter
             # runs while the ball detector is still busy on the GPU
+            t_audit = None
+            t_picks = td._audit_picks(n)
+            if t_picks:
+                cur.wait_event(uploaded[-1])
+                t_audit = td.model.audit_async(frames, t_picks)
+            cert = td.model.certified and bool(table_calls)
             with torch.cuda.stream(st['table']):
                 kp_dev = torch.cat(table_out).reshape(-1, 13, 3)
                 kp_host = torch.empty(kp_dev.shape, dtype=kp_dev.dtype, pin_memory=True)
                 kp_host.copy_(kp_dev, non_blocking=True)
+                if cert:          # the calls' status flags and crop / error info in one copy each
+                    st_dev = torch.cat([c['status'] for c in table_calls])
+                    in_dev = torch.stack([c['info'] for c in table_calls])
+                    st_host = torch.empty(st_dev.shape, dtype=st_dev.dtype, pin_memory=True); st_host.copy_(st_dev, non_blocking=True)
+                    in_host = torch.empty(in_dev.shape, dtype=in_dev.dtype, pin_memory=True); in_host.copy_(in_dev, non_blocking=True)
                 ev_t = torch.cuda.Event(); ev_t.record()
             ev_t.synchronize()
-            kp = table_consumer(kp_host.numpy()) if table_consumer is not None else kp_host.numpy().copy()
+            kp_np = kp_host.numpy()
+            if cert:
+                o = 0
+                for k, c in enumerate(table_calls):
+                    nmap = c['idx'].shape[0]
+                    c['status'], c['info'] = st_host.numpy()[o:o + nmap], in_host.numpy()[k]
+                    o += nmap
+                cur.wait_stream(st['table'])
+                for k in sorted(td._settle_calls(table_calls, frames, t_audit)):          # rare: re-certified / repaired calls are refined again
+                    c = table_calls[k]
+                    pos = refine.refine_windows_device(c['idx'].reshape(-1), c['win'].reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE)
+                    kp_np[c['f0']:c['f1']] = pos.cpu().numpy().reshape(-1, 13, 3)
+            kp = table_consumer(kp_np) if table_consumer is not None else kp_np.copy()
         for s in st.values():
             cur.wait_stream(s)
-        m = bd.model
-        if m.certified and ball_calls:
-            err = m.note_error(max(m.decode_info(c[5].cpu().numpy())[1] for c in ball_calls))
-            if audit is not None:
-                err = max(err, m.audit_result(audit))
-            if m.eps_violated(err):
-                m.widen_eps(err)
-        for (t0, nt, idx, win, status, info, eps_used) in ball_calls:
-            st = status.cpu().numpy() if status is not None else None
-            if st is not None and eps_used < m.eps:
-                # an audit found eps too small: the heatmaps of this call whose guard band is not empty are run again under the
-                # widened eps; the whole call only when eps grew past the guard factor (audited, blocking; rare)
-                todo = m.recertify_subset(idx, win, st, eps_used, frames[t0:t0 + nt + 2])
-                if todo is None:
-                    idx, win = bd._certified_peaks(frames[t0:t0 + nt + 2])
-                    st = None
-                else:
-                    st[todo] = 1
-            if st is not None and ((st & 3) == 2).any():
-                # rare: crop budget exceeded -> those frames on the full-frame fp32 path (with the call's own status)
-                m.fix_uncertified(idx, win, frames_u8=frames[t0:t0 + nt + 2], status=st)
-            ball_out.append(refine.refine_windows_device(idx, win, bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
+        calls = [{'f0': t0, 'f1': t0 + nt + 2, 'idx': idx, 'win': win, 'status': status, 'info': info, 'eps': eps_used}
+                 for (t0, nt, idx, win, status, info, eps_used) in ball_calls]
+        bd._settle_calls(calls, frames, audit)
+        for c in calls:
+            ball_out.append(refine.refine_windows_device(c['idx'], c['win'], bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
         pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
         return pos, kp
 

@@ -128,6 +128,9 @@ class StreamWorker:
         self.audit_every = int(audit_every)
         self._since_audit = 0
         self._rng = np.random.default_rng(audit_seed)
+        # measurement (bench.py `ambiguous_share`): when set to a list, every collected clip appends the fp32 top-2 margins of its
+        # heatmaps (`WASBNet.certify_margins`: +inf for single-candidate heatmaps)
+        self.margin_log = None
 
     def record_spec(self):
         """Capacities of the per-clip records (`gather_records(..., spec=...)`: one collective per step)."""
@@ -167,6 +170,7 @@ class StreamWorker:
         # handle's per-call slot
         status = self.net.certify_status(idx.shape[0], raw=True) if self.certify else None          # bit 2 = guard band not empty
         info = self.net.certify_info() if self.certify else None
+        self._last_margin = self.net.certify_margins(idx.shape[0]) if self.certify and self.margin_log is not None else None
         return xyv, idx, win, status, info
 
     def _pick_audits(self, n_triples):
@@ -313,11 +317,16 @@ class StreamWorker:
             st_host.copy_(status, non_blocking=True)
             info_host = self._pinned('info', info)
             info_host.copy_(info, non_blocking=True)
+        mg_host = None
+        if self._last_margin is not None:
+            mg_host = self._pinned('margin', self._last_margin)
+            mg_host.copy_(self._last_margin, non_blocking=True)
+            self._last_margin.record_stream(sub)
         done = torch.cuda.Event()
         done.record()
         for t in (xyv, idx, win, frames_u8) + ((status, info) if status is not None else ()):
             t.record_stream(sub)
-        return {'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host, 'info': info_host,
+        return {'margin': mg_host, 'xyv': xyv, 'host': host, 'done': done, 'frames': frames_u8, 'idx': idx, 'win': win, 'status': st_host, 'info': info_host,
                 'stream': sub, 'audit': audit, 'eps': eps_used}
 
     def collect(self, ticket, table_px, fps):
@@ -359,7 +368,9 @@ class StreamWorker:
         status_host = None if ticket.get('status') is None else (ticket['status'].numpy() & 3)          # 0 / 1 / 2 (guard bit dropped)
         if status_host is not None and rerun_status is not None:
             status_host = rerun_status
-        for k in ('host', 'status', 'info'):
+        if ticket.get('margin') is not None and self.margin_log is not None:
+            self.margin_log.append(ticket['margin'].numpy().copy())
+        for k in ('host', 'status', 'info', 'margin'):
             self._unpin('xyv' if k == 'host' else k, ticket.get(k))
             ticket[k] = None
         ticket['status_host'] = status_host

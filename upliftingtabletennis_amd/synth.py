@@ -57,6 +57,14 @@ def synth_frames(n, h=720, w=1280, seed=0, sigma=2.0, track=None):
     return frames, track
 
 
+def hard_clip(n, h=720, w=1280, seed=0, sigma=3.5, gain=1.5):
+    """A clip whose heatmaps have NEAR-TIES at the top: a wide blob (sigma 3-4 px) under a brightness gain of 1.3-1.6 saturates at
+    255 over dozens of pixels, so the detector's heatmap has a flat top (reference top-2 margins of 1e-4 .. 1e-2 on the planted
+    weights, against 0.2 on `synth_frames` defaults).  The content of tools/soak_audit.py and of tests/golden/wasb_hard.npz."""
+    frames, track = synth_frames(n, h, w, seed=seed, sigma=sigma)
+    return np.clip(np.rint(frames.astype(np.float32) * np.float32(gain)), 0, 255).astype(np.uint8), track
+
+
 def _random_camera(rng):
     """Pinhole camera looking at the table (ranges in the spirit of reference uplifting/data.py:60-64)."""
     dist = rng.uniform(6.0, 12.0)

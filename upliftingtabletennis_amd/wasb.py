@@ -123,18 +123,34 @@ class WASBNet:
             if getattr(self, 'exact_windows', False):
                 self.certify_budget(2 * self.max_batch)
 
+    def _make(self, resolution=None, max_batch=1, dtype='bf16'):
+        """Another handle of this detector type with the same weights."""
+        return type(self)(self._state_dict, resolution=resolution or (self.W, self.H), max_batch=max_batch, dtype=dtype, device=self.device)
+
     def _twin(self):
         if self._f32_twin is None:
-            self._f32_twin = type(self)(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='f32', device=self.device) \
-                if type(self) is not WASBNet else WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='f32', device=self.device)
+            self._f32_twin = self._make(dtype='f32')
         return self._f32_twin
+
+    @property
+    def NF(self):
+        """Frames per sample: 3 (ball detector, triples) or 1 (table detector)."""
+        return self.IN_CH // 3
+
+    def _pre(self, frames_u8):
+        """The network input of the samples of a uint8 clip: (N - NF + 1, IN_CH, H, W) float32."""
+        return (preprocess_triples if self.NF == 3 else preprocess_frames)(frames_u8, (self.W, self.H))
+
+    def _heat(self, x):
+        """(B, OUT_CH, H, W) heatmaps of a float input, whatever `forward` of the subclass returns."""
+        return WASBNet.forward(self, x, want_heatmap=True)[0]
 
     def _audit_twin(self):
         """A one-sample bf16 handle with the same weights: the audit re-computes the production path's heatmap of a frame on its own
         buffers (the kernels are per-tile deterministic: same values as the batched handle, asserted in the tests), so it never
         touches the production handle's lanes or its per-call certification state."""
         if getattr(self, '_bf16_twin', None) is None:
-            self._bf16_twin = WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='bf16', device=self.device)
+            self._bf16_twin = self._make(dtype='bf16')
         return self._bf16_twin
 
     SUBSET_MAX_SHARE = 0.25      # recertify_subset: above this share of guarded heatmaps the caller re-runs the whole call
@@ -146,27 +162,24 @@ class WASBNet:
         pre-processed triple is run through a bf16 and an fp32 handle of that size -- any sub-image is a fair sample of the
         bf16-vs-fp32 error on this kind of content, and a quarter-width strip costs a quarter of the fp32 time (the audit's
         price: 1.3 ms instead of 5.3 ms per audited frame at 1280x704)."""
-        fr = frames_u8[t:t + 3]
+        fr = frames_u8[t:t + self.NF]
         if x0 is None or self.W <= self.AUDIT_STRIP:
             hb, _, _ = self._audit_twin().forward_frames(fr, want_heatmap=True)
-            hf, _ = self._twin().forward(preprocess_triples(fr, (self.W, self.H)))
+            hf = self._twin()._heat(self._pre(fr))
             return max_abs_diff(hb[0], hf[0])
-        xs = preprocess_triples(fr, (self.W, self.H))[:, :, :, x0:x0 + self.AUDIT_STRIP].contiguous()
+        xs = self._pre(fr)[:, :, :, x0:x0 + self.AUDIT_STRIP].contiguous()
         tw = self.__dict__.get('_strip_twins')
         if tw is None:
             res = (self.AUDIT_STRIP, self.H)
-            tw = self._strip_twins = (WASBNet(self._state_dict, resolution=res, max_batch=1, dtype='bf16', device=self.device),
-                                      WASBNet(self._state_dict, resolution=res, max_batch=1, dtype='f32', device=self.device))
-        hb, _ = tw[0].forward(xs)
-        hf, _ = tw[1].forward(xs)
-        return max_abs_diff(hb[0], hf[0])
+            tw = self._strip_twins = (self._make(res, dtype='bf16'), self._make(res, dtype='f32'))
+        return max_abs_diff(tw[0]._heat(xs)[0], tw[1]._heat(xs)[0])
 
     def calibrate(self, frames_u8, n=8, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
         """First estimate of eps: HEADROOM * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
         (N,h,w,3) device tensor).  Enables the certified argmax and returns eps.  The estimate is then kept honest by the audits."""
         safety = self.HEADROOM if safety is None else safety
         frames_u8 = frames_u8.to(self.device)
-        nt = frames_u8.shape[0] - 2
+        nt = frames_u8.shape[0] - (self.NF - 1)
         n = max(1, min(n, nt))
         picks = sorted(set(int(round(k * (nt - 1) / max(1, n - 1))) for k in range(n))) if n > 1 else [0]
         err = max(float(self.heatmap_error(frames_u8, t).item()) for t in picks)
@@ -235,6 +248,13 @@ class WASBNet:
             _lib.check(fn(self._handle, batch, _lib.ptr(st), _lib.stream_ptr()))
         return st
 
+    def certify_margins(self, batch):
+        """fp32 top-2 margin among the candidates of each heatmap of the last forward (+inf: single candidate / not resolved)."""
+        m = torch.empty((batch,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ttup_wasb_certify_margins(self._handle, batch, _lib.ptr(m), _lib.stream_ptr()))
+        return m
+
     def certify_info(self):
         """(2,) int32 device tensor of the last forward, in stream order: [crops it asked for, bits of the largest |bf16 - fp32|
         seen at any candidate so far].  `decode_info` turns a host copy into (n_crops, max_candidate_err)."""
@@ -259,27 +279,31 @@ class WASBNet:
         """Heatmaps the certified argmax flagged 2 (candidate / crop budget exceeded) are re-run on the full-frame fp32 path, so that
         every returned index is the fp32 argmax.  Give the call's input -- the uint8 clip (`forward_frames`) or the float tensor
         (`forward`) -- and the call's OWN status (`certify_status` taken right after it, host or device); without it the handle's
-        last call is assumed.  Synchronises; returns the number of frames re-run."""
-        if idx.shape[0] > self.max_batch:
-            raise ValueError('fix_uncertified covers one forward call of at most max_batch=%d heatmaps' % self.max_batch)
+        last call is assumed.  idx / win / status hold OUT_CH entries per sample (13 keypoint heatmaps per frame for the table
+        detector).  Synchronises; returns the number of samples re-run."""
+        K = self.OUT_CH
+        if idx.shape[0] > self.max_batch * K:
+            raise ValueError('fix_uncertified covers one forward call of at most max_batch=%d samples' % self.max_batch)
         if status is None:
             status = self.certify_status(idx.shape[0])
         st = (status.cpu().numpy() if torch.is_tensor(status) else np.asarray(status)) & 3
         bad = np.nonzero(st == 2)[0]
-        if bad.size:
+        samples = np.unique(bad // K)
+        if samples.size:
             twin = self._twin()
-            for t in bad:
+            for t in samples:
                 t = int(t)
-                xt = x[t:t + 1] if x is not None else preprocess_triples(frames_u8[t:t + 3].to(self.device), (self.W, self.H))
-                _, i1, w1 = twin.forward(xt, want_heatmap=False, want_peaks=True)
-                idx[t] = i1[0]
-                win[t] = w1[0]
-        return int(bad.size)
+                xt = x[t:t + 1] if x is not None else self._pre(frames_u8[t:t + self.NF].to(self.device))
+                _, i1, w1 = WASBNet.forward(twin, xt, want_heatmap=False, want_peaks=True)
+                for m in bad[bad // K == t]:
+                    idx[int(m)] = i1[int(m) - t * K]
+                    win[int(m)] = w1[int(m) - t * K]
+        return int(samples.size)
 
     def recertify_subset(self, idx, win, status_raw, eps_used, frames_u8):
         """eps has been widened since the call that produced (idx, win, status_raw) from the uint8 clip `frames_u8`.  Heatmaps whose
         guard band was empty keep their certified result (same candidate set under any eps up to GUARD * eps_used); the others are
-        run again one triple at a time under the current eps and repaired on the fp32 handle if they overflow the budget.  Returns the indices re-run, or None when eps grew past the guard factor (the caller then re-runs the
+        run again one sample at a time under the current eps and repaired on the fp32 handle if they overflow the budget.  Returns the indices re-run, or None when eps grew past the guard factor (the caller then re-runs the
         whole call; also when more than SUBSET_MAX_SHARE of the heatmaps are guarded)."""
         if self.eps > eps_used * self.GUARD * (1 - 1e-6):
             return None
@@ -294,17 +318,19 @@ class WASBNet:
         # per-call certification slots, which a clip in flight may still be using
         h = self.__dict__.get('_recert')
         if h is None:
-            h = self._recert = WASBNet(self._state_dict, resolution=(self.W, self.H), max_batch=1, dtype='bf16', device=self.device)
+            h = self._recert = self._make(dtype='bf16')
             h._f32_twin = self._twin()
         if not h.certified or h.eps != self.eps or h.exact_windows != self.exact_windows:
             h.set_certify(self.eps, exact_windows=self.exact_windows)
-        for t in todo:
+        K = self.OUT_CH
+        for t in np.unique(todo // K):
             t = int(t)
-            fr = frames_u8[t:t + 3]
+            fr = frames_u8[t:t + self.NF]
             _, i1, w1 = h.forward_frames(fr, want_heatmap=False)
-            h.fix_uncertified(i1, w1, frames_u8=fr, status=h.certify_status(1))
-            idx[t] = i1[0]
-            win[t] = w1[0]
+            h.fix_uncertified(i1, w1, frames_u8=fr, status=h.certify_status(K))
+            for m in todo[todo // K == t]:
+                idx[int(m)] = i1[int(m) - t * K]
+                win[int(m)] = w1[int(m) - t * K]
         return todo
 
     def internal_streams(self):
