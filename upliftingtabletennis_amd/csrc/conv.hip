@@ -1123,9 +1123,11 @@ __device__ __forceinline__ unsigned long long bb_dpp_shl(unsigned long long x, i
 
 // element offset of 8-channel chunk c8 of the pixel at buffer column x (pix = row*stride + x); C=32 swizzles the chunk
 // with bits 1..2 of the column (conflict-free ds_read_b128, see lds_off).  C=16 (32 B per pixel) flips the two chunks with
-// bit 2 of the column: the ds_read_b128 fragments stay conflict-free (columns x and x+8 of a hardware lane group carry
-// different chunks either way) and the epilogue's 8-byte stores, 16 lanes at a 32-byte stride, drop from 4-way to 2-way
-// bank conflicts (PMC: conflicts were 22 % of this kernel's LDS cycles).
+// bit 2 of the column: the ds_read_b128 fragments of a band group stay conflict-free (columns x and x+8 of a hardware lane group
+// carry different chunks either way) and the epilogue's 8-byte stores, 16 lanes at a 32-byte stride, are 2-way instead of 4-way.
+// (History of SQ_LDS_BANK_CONFLICT per launch of the two-block chain: 22 % of its LDS cycles before this swizzle, 6.45e6 = 10 %
+// with it in round 2, 1.38e7 = 22 % again in round 3 when the ragged strips were packed row-major across aliasing rows, and back
+// down with odd row strides + column strip groups in round 4: profiles/r4_pmc_summary.txt.)
 template <int C> __device__ __forceinline__ int bb_off(int pix, int x, int c8) {
     if (C == 32) return pix * 32 + ((c8 ^ ((x >> 1) & 3)) << 3);
     return pix * C + ((c8 ^ ((x >> 2) & 1)) << 3);
@@ -1485,7 +1487,17 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
             }
         }
         if constexpr (STRIP) {
-            constexpr int RX = RWO - XLAST, NSP = RHO * RX, NSG = (NSP + 15) / 16;
+            // Strip groups are COLUMN groups when the input buffer's row stride is odd (the two-block chain's buffers): 16 consecutive
+            // rows of one strip column.  A pixel record is two 16-byte LDS slots and a ds_read_b128 is served in lane groups
+            // {0-3,12-15 of one chunk | 4-11 of the other}: with a row stride of 1 (mod 8) pixels the 16 rows land on the 16 slots
+            // exactly like the 16 consecutive pixels of a band group -- conflict-free for every tap, and the swizzle terms (a
+            // function of the column) become wave-uniform.  Round 3's row-major packing (16 pixels over 3-8 rows of a 6 / 4 / 2-pixel
+            // strip, row stride 40 = 0 mod 8: rows aliased on the same banks) doubled the kernel's SQ_LDS_BANK_CONFLICT
+            // (6.45e6 -> 1.38e7 per launch); it is kept for even strides (the one-block chain).
+            constexpr bool COLG = (RWI & 1) == 1 && (!SECOND || (RWR & 1) == 1);
+            constexpr int RX = RWO - XLAST, NSP = RHO * RX;
+            constexpr int CG = (RHO + 15) / 16;                          // column groups per strip column
+            constexpr int NSG = COLG ? RX * CG : (NSP + 15) / 16;
             constexpr int ROWS7 = RHO - 7 * RB < 0 ? 0 : (RHO - 7 * RB > RB ? RB : RHO - 7 * RB);      // band rows of the last wave
             // a strip group costs about two band groups (five fragment reads instead of three, one dependent MFMA chain, per-lane
             // addresses): the last wave takes as many as fit in HALF of its band's gap (in band-group units), the rest go round
@@ -1496,10 +1508,23 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #endif
             static_assert(NSG - K0 <= 16, "at most two strip groups per wave after the last wave's share");
             auto strip = [&](int j) __attribute__((always_inline)) {
-                const int p = 16 * j + n;
-                const bool valid = p < NSP;
-                const int pc = valid ? p : NSP - 1;                   // lanes past the strip recompute its last pixel and store nothing
-                const int row = pc / RX, col = XLAST + (pc - row * RX);
+                int row, col;
+                bool valid;
+                if constexpr (COLG) {
+                    const int cj = j / CG, rg = j - cj * CG;              // wave-uniform
+                    // rows dealt evenly over the column's groups (30 rows: 15 + 15, not 16 + 14)
+                    constexpr int RPG = (RHO + CG - 1) / CG;
+                    const int r0 = rg * RPG;
+                    valid = n < RPG && r0 + n < RHO;
+                    const int rn = r0 + (n < RPG ? n : RPG - 1);         // idle lanes re-read a neighbour's addresses (identical addresses
+                    row = rn < RHO ? rn : RHO - 1;                        // broadcast: no bank conflict) and store nothing
+                    col = XLAST + cj;
+                } else {
+                    const int p = 16 * j + n;
+                    valid = p < NSP;
+                    const int pc = valid ? p : NSP - 1;                   // lanes past the strip recompute its last pixel and store nothing
+                    row = pc / RX; col = XLAST + (pc - row * RX);
+                }
                 const bf16_t* b0 = s_in + ((row + IOFF) * RWI + IOFF + col) * C;
                 const int sw2 = (c8 ^ (((col + 2 + IOFF) >> 2) & 1)) << 3;
                 const bf16_t* a0 = b0 + h * C + ((c8 ^ (((col + h + IOFF) >> 2) & 1)) << 3);        // steps 0-2: rows row + dy, column col | col+1
@@ -1634,7 +1659,12 @@ template <int C, int TH, int TW, int MODE>
 __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int L = 4;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
-    constexpr int SZ_A = R0H * R0W * C;
+    // row strides (pixels) of the two LDS buffers: ODD, so that 16 consecutive rows of one column fall on 16 different 16-byte
+    // slots -- the strip groups of bb_conv are column groups (see there); 40 -> 41 and 38 -> 39 pixels cost 2 KB of LDS per workgroup
+    constexpr int SA = (R0W & 1) ? R0W : R0W + 1;
+    constexpr int SB = ((R0W - 2) & 1) ? R0W - 2 : R0W - 1;
+    constexpr int SZ_A = R0H * SA * C;
+    constexpr int SZ_B = (R0H - 2) * SB * C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* bufA = (bf16_t*)smem;
     bf16_t* bufB = bufA + SZ_A;
@@ -1678,23 +1708,23 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
             const u32x4 t = *(const u32x4*)(ok ? src + k * row_step : a.x);
             v[k] = u32x4{ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u};
         }
-        bf16_t* dst = bufA + bb_off<C>(rl * R0W + col, col, c8);
+        bf16_t* dst = bufA + bb_off<C>(rl * SA + col, col, c8);
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k)
-            if (rl < RL && rl + k * RL < R0H) *(u32x4*)(dst + k * RL * R0W * C) = v[k];
+            if (rl < RL && rl + k * RL < R0H) *(u32x4*)(dst + k * RL * SA * C) = v[k];
     }
     const bf16x8 idm = bb_identity_frag(lane);
     if (C == 16) bb_load_frag16(fr, a.w[0], a.bias[0], lane);          // first conv's fragments: in flight across the barrier
     __syncthreads();
     TTUP_STAMP(1);
     const BBFrag16* pre = C == 16 ? &fr : nullptr;
-    bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane,
+    bb_conv<C, SA, 0, R0H - 2, R0W - 2, false, 1, 0, false, SB, 0>(bufA, bufB, nullptr, a.w[0], a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr, pre);
     TTUP_STAMP(2);
     if (C == 16) bb_load_frag16(fr, a.w[1], a.bias[1], lane);          // next conv's fragments: requested BEFORE the barrier
     __syncthreads();
     TTUP_STAMP(3);
-    bb_conv<C, R0W - 2, 0, R0H - 4, R0W - 4, true, R0W, 2, false, R0W, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane,
+    bb_conv<C, SB, 0, R0H - 4, R0W - 4, true, SA, 2, false, SA, 2>(bufB, bufA, bufA, a.w[1], a.bias[1], nullptr, oy0 - 2, ox0 - 2, a.H, a.W, b, wave, lane,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr, pre, nullptr, idm);
     if (C == 16) bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
@@ -1703,7 +1733,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     // slices (12x16 + 6x8 + 3x4 pixels of 16 channels = 8 KB at most) are requested now, travel while conv3 runs, and are parked in
     // the tail of bufB that conv3's 26x34 output leaves free -- the epilogue then reads them from LDS instead of paying a memory
     // round trip per output row.
-    constexpr int T_FREE = ((TH + 6) * (TW + 6) - (TH + 2) * (TW + 2)) * C;       // elements of bufB behind conv3's output
+    constexpr int T_FREE = SZ_B - (TH + 2) * (TW + 2) * C;       // elements of bufB behind conv3's output
     static_assert(C != 16 || (TH % 8 == 0 && TW % 8 == 0), "term slices are aligned to the tile for 8-aligned tiles");
     bf16_t* s_terms = bufB + (TH + 2) * (TW + 2) * C;
     u32x4 treg = u32x4{0u, 0u, 0u, 0u};
@@ -1751,14 +1781,14 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
             }
         }
     }
-    bb_conv<C, R0W, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane,
+    bb_conv<C, SA, 2, R0H - 6, R0W - 6, false, 1, 0, false, R0W - 6, 0>(bufA, bufB, nullptr, a.w[2], a.bias[2], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr, pre);
     if (C == 16 && tunit >= 0) { static_assert(C != 16 || T_FREE * 2 >= ((TH >> 1) * (TW >> 1) + (TH >> 2) * (TW >> 2) + (TH >> 3) * (TW >> 3)) * 32, "bufB tail holds the term slices"); ((u32x4*)s_terms)[tunit] = treg; }
     if (C == 16) bb_load_frag16(fr, a.w[3], a.bias[3], lane);
     __syncthreads();
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
-    bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0, MODE>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
+    bb_conv<C, R0W - 6, 0, TH, TW, true, SA, 4, true, 1, 0, MODE>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
                                                                    nullptr, nullptr, nullptr, &a, &best, pre, &tlds, idm);
 #ifdef TTUP_TIMING_SPLIT
     TTUP_STAMP(6);
@@ -1772,7 +1802,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
         if (lane < 16 && best.i != 0x7fffffffffffffffLL) key = bb_key(best.v, (int)best.i);
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) { const unsigned long long o = bb_dpp_shl(key, off); key = o > key ? o : key; }
-        unsigned long long* slots = (unsigned long long*)(smem + (size_t)(SZ_A + (TH + 6) * (TW + 6) * C) * 2);
+        unsigned long long* slots = (unsigned long long*)(smem + (size_t)(SZ_A + SZ_B) * 2);
         if (lane == 0) slots[wave] = key;
         __syncthreads();
         if (wave == 0) {
@@ -1812,8 +1842,10 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
 
 template <int C, int TH, int TW, int MODE>
 static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
-    constexpr size_t SMEM = (size_t)((TH + 8) * (TW + 8) + (TH + 6) * (TW + 6)) * C * 2 + 64;       // + one argmax slot per wave
+    constexpr int SA = ((TW + 8) & 1) ? TW + 8 : TW + 9, SB = ((TW + 6) & 1) ? TW + 6 : TW + 7;       // odd row strides, as in the kernel
+    constexpr size_t SMEM = (size_t)((TH + 8) * SA + (TH + 6) * SB) * C * 2 + 64;       // + one argmax slot per wave
     static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(2 * SMEM <= 160 * 1024 || TH * TW > 24 * 32, "the 24x32 tile runs two workgroups per CU");
     if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW, MODE>, SMEM)) return rc;
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
