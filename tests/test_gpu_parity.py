@@ -267,6 +267,50 @@ def test_interface_surface():
     assert tuple(spin.shape) == (3,) and p3.shape == (20, 3)
 
 
+def test_split_bf16_fp32_path_against_the_exact_fp32_kernels(golden):
+    """The fp32 path runs its convolutions on the bf16 matrix pipe with operands split into three bf16 parts (csrc/conv_x3.hip: six
+    exact partial products per multiplication, fp32 accumulation).  Against the fp32-MFMA kernels (TTUP_F32_EXACT=1, exact fp32
+    products) and the reference's torch-CPU heatmap: the split path must be as close to the reference as the exact kernels are
+    (both differ from it only by summation order), on a small noise net and on the planted net; and a crop must reproduce the
+    full-frame pixels bit for bit (what the certified argmax relies on)."""
+    import subprocess, sys, json
+    g = golden('wasb_small.npz')
+    name = 'noise_96x160'
+    seed, planted, b, h, w = [int(v) for v in g[name + '/meta']]
+    sd = weights.random_wasb_state_dict(seed, planted=bool(planted))
+    x = torch.from_numpy(np.random.default_rng(seed).standard_normal((b, 9, h, w)).astype(np.float32)).cuda()
+    ref = g[name + '/heat']
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='f32')
+    heat = net(x)[0].cpu().numpy()
+    # the exact kernels in a child process (the choice is read once per process)
+    code = ('import sys, json, numpy as np, torch; sys.path.insert(0, %r); from upliftingtabletennis_amd import wasb, weights;'
+            'sd = weights.random_wasb_state_dict(%d, planted=%r);'
+            'x = torch.from_numpy(np.random.default_rng(%d).standard_normal((%d, 9, %d, %d)).astype(np.float32)).cuda();'
+            'net = wasb.WASBNet(sd, resolution=(%d, %d), max_batch=%d, dtype="f32"); h = net(x)[0].cpu().numpy();'
+            'np.save(sys.argv[1], h)' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), seed, bool(planted), seed, b, h, w, w, h, b))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'exact.npy')
+        e = dict(os.environ); e['TTUP_F32_EXACT'] = '1'
+        subprocess.run([sys.executable, '-c', code, out], check=True, env=e, timeout=600)
+        exact = np.load(out)
+    scale = float(ref.max() - ref.min())
+    d_split, d_exact, d_between = np.abs(heat - ref).max() / scale, np.abs(exact - ref).max() / scale, np.abs(heat - exact).max() / scale
+    print('\nfp32 path vs the reference heatmap (fraction of its range %.3g): split-bf16 kernels %.3g, exact fp32-MFMA kernels %.3g; split vs exact %.3g'
+          % (scale, d_split, d_exact, d_between))
+    assert d_split <= 2.0 * d_exact + 1e-7 and d_split <= 1e-5
+    assert np.array_equal(heat.reshape(b, -1).argmax(1), g[name + '/argmax'])
+    # tile-position independence: the same pixels from a shifted sub-image whose receptive fields lie inside both
+    big = wasb.WASBNet(sd, resolution=(320, 256), max_batch=1, dtype='f32')
+    small = wasb.WASBNet(sd, resolution=(192, 176), max_batch=1, dtype='f32')
+    xb = torch.from_numpy(np.random.default_rng(1).standard_normal((1, 9, 256, 320)).astype(np.float32)).cuda()
+    hb = big(xb)[0][0, 0]
+    y0, x0 = 40, 72                         # multiples of 8
+    hs = small(xb[:, :, y0:y0 + 176, x0:x0 + 192].contiguous())[0][0, 0]
+    R = 72
+    assert torch.equal(hs[R + 1:176 - R - 1, R + 1:192 - R - 1], hb[y0 + R + 1:y0 + 176 - R - 1, x0 + R + 1:x0 + 192 - R - 1])
+
+
 def test_fused_kernels_match_layerwise():
     """The fused kernels round every intermediate to bf16 exactly where the layer-by-layer path stores it, but two of them
     sum in a different fp32 order than the layer-wise kernels: the stem's 1x1 follower takes its K dimension in accumulator

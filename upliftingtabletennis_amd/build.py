@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libttup.so')
 STAMPS = os.path.join(CSRC, '.stamps.json')
-SOURCES = ['api.hip', 'conv.hip', 'conv_f32.hip', 'refine.hip', 'wasb_net.hip', 'certify.hip', 'uplift.hip', 'trajgen.hip', 'odefit.hip', 'calib.hip', 'peaks.hip']
+SOURCES = ['api.hip', 'conv.hip', 'conv_f32.hip', 'conv_x3.hip', 'refine.hip', 'wasb_net.hip', 'certify.hip', 'uplift.hip', 'trajgen.hip', 'odefit.hip', 'calib.hip', 'peaks.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fno-fast-math']

@@ -19,6 +19,8 @@ struct FoldedConv {
 struct PackedConv {
     int cout = 0, cin_total = 0, c0 = 0, k = 1, stride = 1, ck = 32;
     void*  w_dev = nullptr;     // bf16 MFMA fragments, or f32 [tap][cin][cout]
+    void*  w3_dev = nullptr;    // f32 handles: the weights split into three bf16 planes, per MFMA fragment (csrc/conv_x3.hip); null when the shape is not covered
+    int    mt3 = 0;             // couts per block of that packing / 16
     float* bias_dev = nullptr;  // [cout]
     size_t w_bytes = 0;
 };
@@ -47,9 +49,13 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b /*second source or null*/
 void free_conv(PackedConv* p);
 
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t stream);
-// fp32 matrix-pipe conv (csrc/conv_f32.hip)
+// fp32 matrix-pipe conv (csrc/conv_f32.hip): exact fp32 products on v_mfma_f32_16x16x4_f32 (cross-check path, TTUP_F32_EXACT=1)
 bool conv_f32_mfma_supported(const PackedConv& p);
 int launch_conv_f32_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t stream);
+// fp32 conv on the bf16 matrix pipe with operands split into three bf16 parts (csrc/conv_x3.hip): the fp32 path's kernel
+bool conv_x3_supported(const PackedConv& p);
+int launch_conv_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t stream);
+int pack_conv_x3(const std::vector<float>& w_tap_cin_cout, int cout, int cin_total, int c0, int k, int stride, PackedConv* out);
 
 // fused stem: conv1 + conv2 + Bottleneck conv1, bf16 only, persistent with all weights resident in LDS (csrc/conv.hip)
 // frames_per_sample = 0: x0 is the (B,H,W,16) input tensor; 1 / 3: x0 is the per-frame pre-processed clip (B+nf-1,H,W,4) and p1 is

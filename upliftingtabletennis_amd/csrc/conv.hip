@@ -1974,7 +1974,8 @@ __global__ void conv_direct_f32_kernel(ConvFArgs a) {
 void free_conv(PackedConv* p) {
     if (p->w_dev) (void)hipFree(p->w_dev);
     if (p->bias_dev) (void)hipFree(p->bias_dev);
-    p->w_dev = nullptr; p->bias_dev = nullptr;
+    if (p->w3_dev) (void)hipFree(p->w3_dev);
+    p->w_dev = nullptr; p->bias_dev = nullptr; p->w3_dev = nullptr;
 }
 
 int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, PackedConv* out) {
@@ -2002,7 +2003,7 @@ int pack_conv(const FoldedConv& a, const FoldedConv* b, int cin_pad, int dtype, 
         out->ck = 0;
         TTUP_HIP_CHECK(hipMalloc(&out->w_dev, out->w_bytes));
         TTUP_HIP_CHECK(hipMemcpy(out->w_dev, w.data(), out->w_bytes, hipMemcpyHostToDevice));
-        return TTUP_OK;
+        return pack_conv_x3(w, cout, cin_total, c0, k, a.stride, out);          // + the split-bf16 packing of the same weights (sets ck)
     }
     TTUP_REQUIRE(c0 % 16 == 0 && c1 % 32 == 0, TTUP_EINVAL, "channel counts %d+%d unsupported", c0, c1);
     int ck = (c0 % 32 == 0) ? 32 : 16;
@@ -2087,7 +2088,9 @@ static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t s
 int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t st) {
     if (dtype == TTUP_DTYPE_F32) {
         TTUP_REQUIRE(!l.res2 && !l.res3, TTUP_EINVAL, "conv: extra fuse-layer terms are a bf16-path fusion");
-        static const bool direct = getenv("TTUP_F32_DIRECT") != nullptr;         // cross-check of the matrix-pipe kernel
+        static const bool direct = getenv("TTUP_F32_DIRECT") != nullptr;         // cross-checks: one thread per output, plain fp32 fma chain
+        static const bool exact = getenv("TTUP_F32_EXACT") != nullptr;           // ... / exact fp32 products on the fp32 matrix pipe
+        if (!direct && !exact && conv_x3_supported(p)) return launch_conv_x3(p, l, st);
         if (!direct && conv_f32_mfma_supported(p)) return launch_conv_f32_mfma(p, l, st);
         TTUP_REQUIRE(!l.n_active, TTUP_EINVAL, "conv: a device-side batch needs the matrix-pipe fp32 kernel");
         ConvFArgs a;
