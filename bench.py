@@ -602,6 +602,26 @@ def main():
                     'gather_ms_max': [round(float(v) * 1e3, 3) for v in allr[:, 3]],
                     'note': 'ms_per_step = each rank\'s own K steps up to its last synchronize (before the closing barrier); gather = host wall clock of '
                             'gather_records (pack + all_gather_into_tensor + unpack on rank 0), which also absorbs the wait for the slowest rank of the step'}
+    # stream -> hardware-queue grouping of every rank's worker (after the timed region, one rank at a time: ranks that share a
+    # GPU in a dry run would disturb each other's probes): the single-GPU mapping is the best one seen and every
+    # rank should have it -- an N-GPU line then says so itself
+    queue_groups = None
+    if dist is not None or os.environ.get('TTUP_BENCH_QUEUE_PROBE') == '1':
+        mine_q = None
+        for r in range(world):
+            if r == rank:
+                try:
+                    mine_q = pipe.worker.queue_groups()
+                except Exception as e:
+                    mine_q = 'probe failed: %r' % (e,)
+            if dist is not None:
+                dist.barrier()
+        if dist is not None:
+            allq = [None] * world
+            dist.all_gather_object(allq, mine_q)
+        else:
+            allq = [mine_q]
+        queue_groups = {'per_rank': allq, 'all_equal': len(set(allq)) == 1}
     frames = TRIPLES * a.steps * world
     line = {'metric': 'frames/sec end-to-end (detect+uplift), 1280x720', 'value': round(frames / dt, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
@@ -627,6 +647,8 @@ def main():
     line['gather_ms_per_step'] = round(float(np.mean(gather_s)) * 1e3, 3)
     if per_rank is not None:
         line['per_rank'] = per_rank
+    if queue_groups is not None:
+        line['stream_queue_groups'] = queue_groups
     from upliftingtabletennis_amd import _lib as _l
     line['build_id'] = _l.build_id()          # hash of csrc/* + include/ttup.h compiled into libttup.so, checked against the tree at load
     if collective is not None:

@@ -63,6 +63,19 @@ def test_max_abs_diff_equals_the_torch_expression():
     assert float(wasb.max_abs_diff(a, b)) == float('inf')
     with pytest.raises(ValueError):
         wasb.max_abs_diff(a, b[:-1])
+    # column ranges (the strip audit leaves out the columns near an artificial border), running maximum, column slices
+    x = torch.randn((3, 5, 40, 64), device='cuda', generator=g)
+    y = x + 1e-2 * torch.randn(x.shape, device='cuda', generator=g)
+    for c0, c1 in ((0, 64), (9, 50), (0, 1), (63, 64), (17, 17)):
+        want = (x[..., c0:c1] - y[..., c0:c1]).abs().max() if c1 > c0 else torch.zeros((), device='cuda')
+        assert torch.equal(wasb.max_abs_diff(x, y, cols=(c0, c1)), want), (c0, c1)
+    run = torch.empty((1,), dtype=torch.float32, device='cuda')
+    wasb.max_abs_diff(x[0], y[0], out=run)
+    wasb.max_abs_diff(x[1], y[1], cols=(3, 60), out=run, accumulate=True)
+    assert torch.equal(run[0], torch.maximum((x[0] - y[0]).abs().max(), (x[1, ..., 3:60] - y[1, ..., 3:60]).abs().max()))
+    assert torch.equal(wasb.slice_columns(x, 8, 24), x[..., 8:32].contiguous())
+    with pytest.raises(ValueError):
+        wasb.slice_columns(x, 50, 24)
 
 
 def test_eps_audit_widens_on_brighter_frames_and_recertifies():

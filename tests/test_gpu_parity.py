@@ -737,7 +737,37 @@ def test_bench_eight_rank_dry_run_on_one_gpu():
     assert rec['config']['frames_per_step_per_gpu'] == 256
     assert abs(rec['value'] - 8 * 256 / (rec['ms_per_step'] / 1e3)) / rec['value'] < 1e-3
     assert 1 <= rec['host_threads_per_rank'] <= max(1, (os.cpu_count() or 8) // 8)
-    print('\n8 ranks on one GPU: %.0f frames/s aggregate, %.0f ms per step, %d host threads per rank' % (rec['value'], rec['ms_per_step'], rec['host_threads_per_rank']))
+    # every rank built its worker and streams before the process group: the same stream -> hardware-queue grouping everywhere
+    q = rec['stream_queue_groups']
+    assert len(q['per_rank']) == 8 and q['all_equal'], q
+    pr = rec['per_rank']
+    assert len(pr['ms_per_step']) == 8 and pr['ms_per_step_min'] <= pr['ms_per_step_max'] and len(pr['gather_ms_mean']) == 8
+    print('\n8 ranks on one GPU: %.0f frames/s aggregate, %.0f ms per step (per rank %.0f .. %.0f), %d host threads per rank; stream -> queue grouping on every rank: %s'
+          % (rec['value'], rec['ms_per_step'], pr['ms_per_step_min'], pr['ms_per_step_max'], rec['host_threads_per_rank'], q['per_rank'][0]))
+
+
+def test_gather_pack_and_unpack_on_device_buffers():
+    """The byte layout of the one collective (`pipeline._pack_records` / `_unpack_records`) on DEVICE buffers, as the nccl path
+    packs them: two ranks' records with different row counts, concatenated as all_gather_into_tensor would, come back per rank
+    with dtypes, shapes and values intact.  (A multi-rank RCCL run needs more than the one device of this box; round-3 advisor.)
+    With world > 1 the gathered records are HOST tensors on the destination rank (the payload is a few KB of results)."""
+    from upliftingtabletennis_amd import pipeline
+    spec = {'xyv': (8, (3,), torch.float64), 'spin': (4, (3,), torch.float32), 'pos3d': (4, (5, 3), torch.float32), 'n_valid': (4, (), torch.int64)}
+    g = torch.Generator(device='cuda').manual_seed(3)
+    ranks = []
+    for rows_xyv, rows_tr in ((8, 2), (5, 0)):
+        ranks.append({'xyv': torch.randn((rows_xyv, 3), device='cuda', generator=g, dtype=torch.float64),
+                      'spin': torch.randn((rows_tr, 3), device='cuda', generator=g), 'pos3d': torch.randn((rows_tr, 5, 3), device='cuda', generator=g),
+                      'n_valid': torch.arange(rows_tr, device='cuda', dtype=torch.int64)})
+    bufs = [pipeline._pack_records(r, spec, torch.device('cuda')) for r in ranks]
+    assert all(b[0].is_cuda and b[0].dtype == torch.uint8 and b[0].numel() == bufs[0][0].numel() for b in bufs)
+    flat = torch.cat([b[0] for b in bufs])
+    out = pipeline._unpack_records(flat.cpu(), 2, bufs[0][1], bufs[0][2], spec)
+    for k in spec:
+        for r in range(2):
+            assert out[k][r].dtype == spec[k][2] and torch.equal(out[k][r], ranks[r][k].cpu()), (k, r)
+    with pytest.raises(ValueError):
+        pipeline._pack_records({**ranks[0], 'xyv': torch.zeros((9, 3), dtype=torch.float64)}, spec, torch.device('cuda'))
 
 
 def test_rccl_gather_on_device_tensors():

@@ -34,6 +34,8 @@ SIGNATURES = {
     'ttup_wasb_set_certify': (_i, [_vp, _c.c_float, _i, _i]),
     'ttup_certify_scan': (_i, [_vp, _vp, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp, _vp]),
     'ttup_max_abs_diff': (_i, [_vp, _vp, _c.c_longlong, _vp, _vp]),
+    'ttup_max_abs_diff_cols': (_i, [_vp, _vp, _c.c_longlong, _c.c_longlong, _c.c_longlong, _c.c_longlong, _vp, _i, _vp]),
+    'ttup_slice_columns': (_i, [_vp, _c.c_longlong, _i, _i, _i, _vp, _vp]),
     'ttup_wasb_certify_budget': (_i, [_vp, _i]),
     'ttup_wasb_certify_exact_windows': (_i, [_vp, _i]),
     'ttup_wasb_certify_info': (_i, [_vp, _vp, _vp]),

@@ -452,15 +452,20 @@ extern "C" int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_de
     return TTUP_OK;
 }
 
-// The audit's error measure, max |a - b| over n floats, in one pass and without torch's element-wise kernels (the audits run on a
-// side stream beside the CNN: no packed fp32 here, common.h).  NaN anywhere gives NaN (its bit pattern orders above +inf).
+// The audit's error measure, max |a - b|, in one pass and without torch's element-wise kernels (the audits run on a side stream beside
+// the CNN: no packed fp32 here, common.h).  NaN anywhere gives NaN (its bit pattern orders above +inf).  The 2-D form compares the
+// columns [c0, c1) of `rows` rows of `width` floats (a strip audit leaves out the columns whose receptive field reaches the strip's
+// artificial zero padding) and can keep a running maximum in `out`.
 TTUP_NO_PACKED_FP32_BEGIN
 namespace ttup { namespace {
-__global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long rows, int width, int c0, int ncol,
+                                                           unsigned* __restrict__ out) {
     float m = 0.f;
     bool nan = false;
+    const long long n = rows * ncol;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float d = fabsf(a[i] - b[i]);
+        const long long e = ncol == width ? i : (i / ncol) * width + c0 + i % ncol;
+        const float d = fabsf(a[e] - b[e]);
         nan |= d != d;
         m = d > m ? d : m;
     }
@@ -469,16 +474,43 @@ __global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restri
     for (int k = 0; k < 6; ++k) { const unsigned o = __shfl_xor(bits, 32 >> k, 64); bits = o > bits ? o : bits; }
     if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
 }
+// dst[r][j] = src[r][x0 + j]: a column strip of (rows, width) floats (the audit's strip of the pre-processed input)
+__global__ __launch_bounds__(256) void slice_columns_kernel(const float* __restrict__ src, long long rows, int width, int x0, int w, float* __restrict__ dst) {
+    const long long n = rows * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[(i / w) * width + x0 + i % w];
+}
 } }
 TTUP_NO_PACKED_FP32_END
 
 extern "C" int ttup_max_abs_diff(const float* a_dev, const float* b_dev, long long n, float* out_dev, void* stream) {
-    TTUP_REQUIRE(a_dev && b_dev && out_dev && n >= 0, TTUP_EINVAL, "ttup_max_abs_diff: bad argument");
-    TTUP_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), (hipStream_t)stream));
+    return ttup_max_abs_diff_cols(a_dev, b_dev, 1, n, 0, n, out_dev, 0, stream);
+}
+
+extern "C" int ttup_max_abs_diff_cols(const float* a_dev, const float* b_dev, long long rows, long long width, long long c0, long long c1, float* out_dev,
+                                      int accumulate, void* stream) {
+    TTUP_REQUIRE(a_dev && b_dev && out_dev && rows >= 0 && width >= 0 && c0 >= 0 && c0 <= c1 && c1 <= width, TTUP_EINVAL, "ttup_max_abs_diff: bad argument");
+    TTUP_REQUIRE(rows <= 1 || width < (1ll << 31), TTUP_EINVAL, "ttup_max_abs_diff_cols: rows wider than 2^31 floats");
+    if (!accumulate) TTUP_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), (hipStream_t)stream));
+    const long long n = rows * (c1 - c0);
     if (n == 0) return TTUP_OK;
     long long nblk = (n + 256 * 16 - 1) / (256 * 16);
     nblk = nblk > 2048 ? 2048 : nblk;
-    hipLaunchKernelGGL(max_abs_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev, n, (unsigned*)out_dev);
+    if (rows == 1) {          // one row: a flat range (any length)
+        hipLaunchKernelGGL(max_abs_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a_dev + c0, b_dev + c0, c1 - c0, 1, 0, 1, (unsigned*)out_dev);
+    } else {
+        hipLaunchKernelGGL(max_abs_diff_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev, rows, (int)width, (int)c0, (int)(c1 - c0), (unsigned*)out_dev);
+    }
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
+extern "C" int ttup_slice_columns(const float* src_dev, long long rows, int width, int x0, int w, float* dst_dev, void* stream) {
+    TTUP_REQUIRE(src_dev && dst_dev && rows >= 0 && width > 0 && x0 >= 0 && w >= 0 && x0 + w <= width, TTUP_EINVAL, "ttup_slice_columns: bad argument");
+    const long long n = rows * w;
+    if (n == 0) return TTUP_OK;
+    long long nblk = (n + 256 * 8 - 1) / (256 * 8);
+    nblk = nblk > 4096 ? 4096 : nblk;
+    hipLaunchKernelGGL(slice_columns_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, src_dev, rows, width, x0, w, dst_dev);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }

@@ -34,6 +34,10 @@ struct ConvX3Args {
     const int* n_active;
 };
 
+// The operand split is fp32 vector arithmetic (v - hi parts) that the compiler would turn into packed fp32 instructions with neg
+// modifiers -- the forms measured to return wrong values beside another kernel's LDS-fed MFMAs (csrc/common.h), and the crop
+// passes run beside the bf16 CNN: built without packed fp32 (tests/test_cabi.py scans the ISA).
+TTUP_NO_PACKED_FP32_BEGIN
 namespace {
 
 // two fp32 -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32)
@@ -248,6 +252,7 @@ int launch_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
 }
 
 }  // namespace
+TTUP_NO_PACKED_FP32_END
 
 // couts per block (MT * 16) of a conv of this shape: as many as the LDS budget of its tile allows
 int conv_x3_block_mt(int cout, int k, int stride, int ck) {

@@ -74,7 +74,9 @@ def gather_records(records, dist=None, dst=0, spec=None):
     `spec` = {key: (max_rows, row_shape, dtype)} (StreamWorker.record_spec()) fixes every key's capacity, so a step is exactly ONE
     collective: all ranks contribute one equally sized byte buffer (row counts + rows) to an all_gather.  Without a spec the
     capacities are agreed first (one extra all_reduce of the row counts): two collectives.  nccl (= RCCL) gathers device buffers,
-    gloo (CPU tests, single-GPU dry runs) host buffers."""
+    gloo (CPU tests, single-GPU dry runs) host buffers.  With world > 1 the tensors returned on `dst` are HOST tensors (the
+    gathered payload is a few KB of results that the caller reads on the host); with one process the local records are returned as
+    they are."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return {k: [v] for k, v in records.items()}
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -377,3 +379,46 @@ class StreamWorker:
         return {'xyv': ticket['xyv'], 'spin': spin, 'pos3d': p3, 'n_valid': nvalid, 'status': status_host}
 
     RECORD_KEYS = ('xyv', 'spin', 'pos3d', 'n_valid')          # what a step hands to gather_records
+
+    def queue_groups(self, cycles=20_000_000):
+        """Which of the worker's streams share a hardware queue: HIP maps the streams of a process onto GPU_MAX_HW_QUEUES (4)
+        queues in the order in which they are first used, kernels of two streams on one queue do not overlap, and the pipeline's
+        throughput moves by up to 6 % with the grouping.  Pairwise probes with two spin kernels (co-resident when both
+        take the time of one).  Returns a canonical string, e.g. 'submit0+lane1 | submit1+crops | lane0 | audit+default'; every rank
+        of a multi-GPU run should report the same one (bench.py gathers them).  Takes a few hundred milliseconds; idle GPU assumed."""
+        dev = self.device
+        named = [('submit%d' % k, s) for k, s in enumerate(self.submit_streams()['streams'])]
+        ints = self.net.internal_streams()
+        n_lanes = len(ints) - (1 if self.net.certified else 0)
+        named += [('lane%d' % k, s) for k, s in enumerate(ints[:n_lanes])] + [('crops', s) for s in ints[n_lanes:]]
+        if getattr(self.net, '_audit_stream', None) is not None:
+            named.append(('audit', self.net._audit_stream))
+        if self.__dict__.get('_side') is not None:
+            named.append(('uplift', self._side))
+        named.append(('default', torch.cuda.default_stream(dev)))
+
+        def spin_ms(streams):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            cur = torch.cuda.current_stream(dev)
+            e0.record(cur)
+            for st in streams:
+                st.wait_event(e0)
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
+            e1.record(cur)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1)
+        one = spin_ms([named[0][1]])
+        groups = []
+        for name, st in named:
+            for g in groups:
+                if spin_ms([g[0][1], st]) > 1.6 * one:
+                    g.append((name, st))
+                    break
+            else:
+                groups.append([(name, st)])
+        return ' | '.join('+'.join(n for n, _ in g) for g in groups)

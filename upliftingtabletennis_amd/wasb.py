@@ -156,23 +156,30 @@ class WASBNet:
     SUBSET_MAX_SHARE = 0.25      # recertify_subset: above this share of guarded heatmaps the caller re-runs the whole call
     AUDIT_STRIP = 320      # columns of the image strip an audit re-computes (full height); calibration uses whole frames
 
-    def heatmap_error(self, frames_u8, t, x0=None):
-        """max |bf16 heatmap - fp32 heatmap| of triple t of the uint8 clip, on the current stream -> 0-dim device tensor.
+    AUDIT_MARGIN = 72      # = the receptive-field radius: columns this close to an artificial strip border are left out of the measure
+
+    def heatmap_error(self, frames_u8, t, x0=None, out=None, accumulate=False):
+        """max |bf16 heatmap - fp32 heatmap| of sample t of the uint8 clip, on the current stream -> 0-dim device tensor.
         x0=None: the whole frame (calibration).  x0 = a column (multiple of 8): only the strip [x0, x0 + AUDIT_STRIP) of the
-        pre-processed triple is run through a bf16 and an fp32 handle of that size -- any sub-image is a fair sample of the
-        bf16-vs-fp32 error on this kind of content, and a quarter-width strip costs a quarter of the fp32 time (the audit's
-        price: 1.3 ms instead of 5.3 ms per audited frame at 1280x704)."""
+        pre-processed sample is run through a bf16 and an fp32 handle of that size -- any sub-image is a fair sample of the
+        bf16-vs-fp32 error on this kind of content, and a quarter-width strip costs a quarter of the fp32 time.  The strip's own
+        zero padding is not the frame's: the columns within AUDIT_MARGIN (the receptive-field radius) of a strip border that is not
+        an image border are left out of the maximum (round-3 advisor).  `out`: a (1,) device tensor for the result; with
+        accumulate=True its current value is kept as a running maximum.  Library kernels only (no torch element-wise work beside the CNN, csrc/common.h)."""
         fr = frames_u8[t:t + self.NF]
         if x0 is None or self.W <= self.AUDIT_STRIP:
             hb, _, _ = self._audit_twin().forward_frames(fr, want_heatmap=True)
             hf = self._twin()._heat(self._pre(fr))
-            return max_abs_diff(hb[0], hf[0])
-        xs = self._pre(fr)[:, :, :, x0:x0 + self.AUDIT_STRIP].contiguous()
+            return max_abs_diff(hb[0], hf[0], out=out, accumulate=accumulate)
+        S = self.AUDIT_STRIP
+        xs = slice_columns(self._pre(fr), x0, S)
         tw = self.__dict__.get('_strip_twins')
         if tw is None:
-            res = (self.AUDIT_STRIP, self.H)
+            res = (S, self.H)
             tw = self._strip_twins = (self._make(res, dtype='bf16'), self._make(res, dtype='f32'))
-        return max_abs_diff(tw[0]._heat(xs)[0], tw[1]._heat(xs)[0])
+        c0 = 0 if x0 == 0 else self.AUDIT_MARGIN
+        c1 = S if x0 + S >= self.W else S - self.AUDIT_MARGIN
+        return max_abs_diff(tw[0]._heat(xs)[0], tw[1]._heat(xs)[0], cols=(c0, c1), out=out, accumulate=accumulate)
 
     def calibrate(self, frames_u8, n=8, safety=None, crop=0, max_crops_per_map=0, exact_windows=None):
         """First estimate of eps: HEADROOM * the largest bf16-vs-fp32 heatmap error on `n` triples spread over `frames_u8` (uint8
@@ -195,14 +202,13 @@ class WASBNet:
             st = self._audit_stream = torch.cuda.Stream(self.device)
         st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
-            err = None
             rng = self.__dict__.setdefault('_audit_rng', np.random.default_rng(12345))
-            for t in picks:
+            err = torch.empty((1,), dtype=torch.float32, device=self.device)
+            for k, t in enumerate(picks):          # the running maximum lives in `err` (the library's kernel folds each sample in)
                 x0 = 8 * int(rng.integers(0, max(1, (self.W - self.AUDIT_STRIP) // 8 + 1)))
-                e = self.heatmap_error(frames_u8, int(t), x0)
-                err = e if err is None else torch.maximum(err, e)
+                self.heatmap_error(frames_u8, int(t), x0, out=err, accumulate=k > 0)
             host = torch.empty((1,), dtype=torch.float32, pin_memory=True)
-            host.copy_(err.reshape(1), non_blocking=True)
+            host.copy_(err, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         frames_u8.record_stream(st)
@@ -412,20 +418,41 @@ def preprocess_triples(frames_u8, dst_wh):
     return out
 
 
-def max_abs_diff(a, b):
-    """max |a - b| of two float32 device tensors of equal size on the current stream -> 0-dim device tensor (ttup_max_abs_diff:
-    the audit's error measure without torch's element-wise kernels, which must not run beside the CNN -- csrc/common.h)."""
+def max_abs_diff(a, b, cols=None, out=None, accumulate=False):
+    """max |a - b| of two float32 device tensors of equal shape on the current stream -> 0-dim device tensor (ttup_max_abs_diff:
+    the audit's error measure without torch's element-wise kernels, which must not run beside the CNN -- csrc/common.h).
+    cols=(c0, c1): only the columns [c0, c1) of the last dimension.  out: a (1,) float32 device tensor for the result; with
+    accumulate=True its current value is kept as a running maximum."""
     _lib.require_gpu()
     lib = _lib.load()
     a, b = a.contiguous(), b.contiguous()
-    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() != b.numel():
-        raise ValueError('max_abs_diff: two float32 tensors of equal size expected')
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape:
+        raise ValueError('max_abs_diff: two float32 tensors of equal shape expected')
+    res = out if out is not None else torch.empty((1,), dtype=torch.float32, device=a.device)
+    acc = 1 if (accumulate and out is not None) else 0
     if a.numel() == 0:
-        return torch.zeros((), dtype=torch.float32, device=a.device)
-    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+        if not acc:
+            res.zero_()
+        return res[0]
     with torch.cuda.device(a.device):
-        _lib.check(lib.ttup_max_abs_diff(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.stream_ptr()))
-    return out[0]
+        if cols is None:
+            _lib.check(lib.ttup_max_abs_diff_cols(_lib.ptr(a), _lib.ptr(b), 1, a.numel(), 0, a.numel(), _lib.ptr(res), acc, _lib.stream_ptr()))
+        else:
+            width = a.shape[-1]
+            _lib.check(lib.ttup_max_abs_diff_cols(_lib.ptr(a), _lib.ptr(b), a.numel() // width, width, int(cols[0]), int(cols[1]), _lib.ptr(res),
+                                                  acc, _lib.stream_ptr()))
+    return res[0]
+
+
+def slice_columns(x, x0, w):
+    """x[..., x0:x0 + w] of a contiguous float32 device tensor as a new contiguous tensor, by the library's copy kernel."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape[:-1] + (w,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.ttup_slice_columns(_lib.ptr(x), x.numel() // x.shape[-1], x.shape[-1], int(x0), int(w), _lib.ptr(out), _lib.stream_ptr()))
+    return out
 
 
 _OP_KINDS = {0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem', 5: 'upsum_head'}
