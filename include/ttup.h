@@ -216,6 +216,11 @@ int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* ta
                         const float* times_dev, int batch, int len, float* rot_dev, float* pos_dev,
                         int check_mask, void* stream);
 
+/* Small batches (batch * len <= 1024 tokens) are replayed from a hipGraph captured on the second call with a given (batch, len).
+ * out_host3[0] = graphs held, [1] = 1 when the graph path is off (capture failed on this runtime, or TTUP_UPLIFT_NO_GRAPH is set),
+ * [2] = forwards served by a replay so far. */
+int ttup_uplift_graph_info(ttup_uplift* net, int* out_host3);
+
 /* ---------------------------------------------------------------- a7: spin frame change
  * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */
 int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream);

@@ -17,3 +17,14 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 gflop = 2.0 if T >= 100 else 0.75
 print('uplift B=%d T=%d: %.3f s  -> %.0f trajectories/s  (~%.1f TFLOP/s at %.2f GFLOP/trajectory)' % (B, T, dt, B / dt, B * gflop / dt / 1e3, gflop))
+if B <= 64:          # latency of a small call (what the hub surface and the pipeline's per-clip uplift pay): mean of 20 calls on a side stream
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            net(ball, table, mask, times)
+        st.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            net(ball, table, mask, times)
+            st.synchronize()
+        print('   small-batch latency (host wall clock, synchronised per call): %.3f ms per forward; %s' % ((time.perf_counter() - t0) / 20 * 1e3, net.graph_info()))

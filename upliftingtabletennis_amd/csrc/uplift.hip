@@ -18,7 +18,9 @@
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
+#include <map>
 #include <memory>
+#include <utility>
 #include <vector>
 
 using namespace ttup;
@@ -35,6 +37,9 @@ struct Linear {
     float* w_dev = nullptr;      // MFMA path: [ntile][k/16][64 lanes][4]; small-K path: [n][k] row major
     float* b_dev = nullptr;      // [n] or null
     bool mfma = false;
+    // K = 128 layers (all of the 'large' model's transformer layers): the weights split into three bf16 parts, packed per
+    // v_mfma_f32_16x16x32_bf16 A fragment: [ntile][k/32][plane][64 lanes][8] (linear_x3_kernel)
+    uint16_t* w3_dev = nullptr;
 };
 
 struct LinArgs {
@@ -172,6 +177,308 @@ __global__ __launch_bounds__(256 * MH) void linear_kernel(LinArgs a) {
     }
 }
 
+// The same layer on the bf16 matrix pipe with SPLIT operands (the arithmetic of csrc/conv_x3.hip): every fp32 weight and every
+// (LayerNorm'd) activation is split exactly into three bf16 parts, a product is the sum of six exact partial products (smallest
+// first) accumulated in fp32 -- accurate to below one fp32 fma rounding, at 2.7x the peak rate of v_mfma_f32_16x16x4_f32.  K = 128
+// only (the transformer layers of the 'large' model: 98 % of the work); TTUP_F32_EXACT=1 keeps the fp32-MFMA kernel.
+// LDS image: three planes [64*MH tokens][128] bf16 (256-byte rows), the 16-byte chunk index XOR-swizzled with the token's low four
+// bits: the 16 lanes of a ds_read_b128 group (8 tokens of one k chunk, 8 of the next) fall on 16 different chunks.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ unsigned ux3_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
+
+template <bool LN, int NTW, int MH>
+__global__ __launch_bounds__(256 * MH) void linear_x3_kernel(LinArgs a, const uint16_t* __restrict__ w3) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64*MH][128]
+    constexpr int BM = 64 * MH, K = 128, PLANE = BM * K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * NTW);
+    // ---- stage the token rows (LayerNorm applied on the way in): 16 lanes per row, two float4 per lane (8 consecutive features)
+    {
+        const int grp = tid >> 4, l16 = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = grp + i * 16 * MH, m = m0 + r;
+            f32x4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) v[u] = m < a.M ? *(const f32x4*)(a.x + (size_t)m * a.ldx + 8 * l16 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (LN) {
+                // (mean / variance with the summation tree of linear_kernel's staging is not required: any order is within the bar;
+                // a 16-lane tree over 8 features per lane)
+                float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                const float mean = sum / (float)K;
+                float var = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+                const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 g = *(const f32x4*)(a.gamma + 8 * l16 + 4 * u), bt = *(const f32x4*)(a.beta + 8 * l16 + 4 * u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + bt[e];
+                }
+            }
+            u32x4 p0, p1, p2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[j >> 1][2 * (j & 1)], x1 = v[j >> 1][2 * (j & 1) + 1];
+                const unsigned q0 = ux3_pack2(x0, x1);
+                const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+                const unsigned q1 = ux3_pack2(r0, r1);
+                const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+                p0[j] = q0; p1[j] = q1; p2[j] = ux3_pack2(s0, s1);
+            }
+            uint16_t* d = xh + r * K + ((l16 ^ (r & 15)) << 3);
+            *(u32x4*)d = p0; *(u32x4*)(d + PLANE) = p1; *(u32x4*)(d + 2 * PLANE) = p2;
+        }
+    }
+    __syncthreads();
+    const int q = lane >> 4, c = lane & 15;
+    f32x4 acc[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (a.N + 15) / 16;
+    int nt_g[NTW]; bool nt_ok[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) { nt_g[t] = n0 / 16 + wn + 4 * t; nt_ok[t] = nt_g[t] < ntiles; }
+    constexpr int KS = K / 32;
+    // token c of m-tile mt sits in row wm*64 + mt*16 + c: (row & 15) == c, so the swizzle term is the lane's own c
+    const uint16_t* xw = xh + (wm * 64 + c) * K;
+    bf16x8 wa[3][NTW];
+    const bf16x8 zero8 = {};
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wa[p][t] = nt_ok[t] ? *(const bf16x8*)(w3 + ((((size_t)nt_g[t] * KS) * 3 + p) * 64 + lane) * 8) : zero8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bf16x8 xb[3][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+        bf16x8 wn_[3][NTW];
+        const int sn = s + 1 < KS ? s + 1 : s;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wn_[p][t] = nt_ok[t] ? *(const bf16x8*)(w3 + ((((size_t)nt_g[t] * KS + sn) * 3 + p) * 64 + lane) * 8) : zero8;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PA[j]][t], xb[PB[j]][mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wa[p][t] = wn_[p][t];
+    }
+    // ---- epilogue: lane holds outputs n = nt*16 + 4*q + {0..3} of token m = m0 + wm*64 + mt*16 + c  (N % 4 == 0 for K = 128 layers)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        if (!nt_ok[t]) continue;
+        const int n = nt_g[t] * 16 + 4 * q;
+        if (n >= a.N) continue;
+        const f32x4 b4 = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + c;
+            if (m >= a.M) continue;
+            f32x4 v = acc[t][mt] + b4;
+            if (a.relu) v = f32x4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+            if (a.res) v += *(const f32x4*)(a.res + (size_t)m * a.ldr + n);
+            *(f32x4*)(a.out + (size_t)m * a.ldo + n) = v;
+        }
+    }
+}
+
+// The token-local half of SimpleStaticLayer.forward (model.py:295-298) in ONE kernel, D = 128:
+//     x2 = proj(att) + x;   hid = relu(fc1(LN(x2)));   x = fc2(hid) + x2
+// Three chained 128 x 128 GEMMs (split-bf16 operands as in linear_x3_kernel) on a tile of 64*MH tokens; x2 stays in the registers of
+// the lanes that produced it (the three GEMMs share one tiling, so the residual of the last one is already in place), LN(x2) and hid
+// go through LDS, nothing but `att` and `x` is read and nothing but `x` written: 1.5 KB of HBM traffic per token instead of the
+// 4.1 KB of the three separate launches (proj -> x2, fc1 -> hid, fc2 -> x), which at B = 10 000 trajectories are HBM-bound.
+struct MlpArgs {
+    const float* att; float* x; long long M;
+    const uint16_t* w_proj; const uint16_t* w_fc1; const uint16_t* w_fc2;
+    const float* g2; const float* b2; const float* bias1; const float* bias2;
+};
+template <int MH>
+__global__ __launch_bounds__(256 * MH) void mlp_block_x3_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][BM][128] split planes, then float s2[BM][132]
+    constexpr int BM = 64 * MH, K = 128, PLANE = BM * K, KS = K / 32, NTW = 2;
+    float* s2 = (float*)(xh + 3 * PLANE);                              // [BM][128] fp32, 16-byte chunks XOR-swizzled with the row's low 4 bits
+    // (512-byte rows alias on the banks: the swizzle spreads the 8 rows of a ds_write_b128 lane group over 8 chunks; 80 KB per
+    // 64-token workgroup = two per CU, 160 KB per 128-token workgroup)
+    auto s2p = [&](int r, int n) __attribute__((always_inline)) { return s2 + r * K + ((((n >> 2) ^ (r & 15))) << 2); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int q = lane >> 4, c = lane & 15;
+    const int grp = tid >> 4, l16 = tid & 15;
+    auto split_store = [&](int r, int chunk, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+        u32x4 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = j < 2 ? lo[2 * j] : hi[2 * (j - 2)], x1 = j < 2 ? lo[2 * j + 1] : hi[2 * (j - 2) + 1];
+            const unsigned q0 = ux3_pack2(x0, x1);
+            const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+            const unsigned q1 = ux3_pack2(r0, r1);
+            const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+            p0[j] = q0; p1[j] = q1; p2[j] = ux3_pack2(s0, s1);
+        }
+        uint16_t* d = xh + r * K + ((chunk ^ (r & 15)) << 3);
+        *(u32x4*)d = p0; *(u32x4*)(d + PLANE) = p1; *(u32x4*)(d + 2 * PLANE) = p2;
+    };
+    auto gemm = [&](const uint16_t* __restrict__ w3, f32x4 (&acc)[NTW][4]) __attribute__((always_inline)) {
+        const uint16_t* xw = xh + (wm * 64 + c) * K;
+        bf16x8 wa[3][NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wa[p][t] = *(const bf16x8*)(w3 + ((((size_t)(wn + 4 * t) * KS) * 3 + p) * 64 + lane) * 8);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 xb[3][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+            bf16x8 wn_[3][NTW];
+            const int sn = s + 1 < KS ? s + 1 : s;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wn_[p][t] = *(const bf16x8*)(w3 + ((((size_t)(wn + 4 * t) * KS + sn) * 3 + p) * 64 + lane) * 8);
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PA[j]][t], xb[PB[j]][mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[p][t] = wn_[p][t];
+        }
+    };
+    // ---- 1. att rows -> split planes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = grp + i * 16 * MH;
+        const long long m = m0 + r;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 lo = m < a.M ? *(const f32x4*)(a.att + m * K + 8 * l16) : z, hi = m < a.M ? *(const f32x4*)(a.att + m * K + 8 * l16 + 4) : z;
+        split_store(r, l16, lo, hi);
+    }
+    __syncthreads();
+    // ---- 2. x2 = proj(att) + x   (kept in registers; a copy goes to LDS for the LayerNorm)
+    f32x4 x2[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) x2[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm(a.w_proj, x2);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = (wn + 4 * t) * 16 + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int r = wm * 64 + mt * 16 + c;
+            const long long m = m0 + r;
+            if (m < a.M) x2[t][mt] += *(const f32x4*)(a.x + m * K + n);
+            *(f32x4*)s2p(r, n) = x2[t][mt];
+        }
+    }
+    __syncthreads();              // every wave is done reading the att planes; x2 rows are complete in s2
+    // ---- 3. LN(x2) -> split planes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = grp + i * 16 * MH;
+        f32x4 v[2] = {*(const f32x4*)s2p(r, 8 * l16), *(const f32x4*)s2p(r, 8 * l16 + 4)};
+        float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / (float)K;
+        float var = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+        const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 g = *(const f32x4*)(a.g2 + 8 * l16 + 4 * u), bt = *(const f32x4*)(a.b2 + 8 * l16 + 4 * u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[e] + bt[e];
+        }
+        split_store(r, l16, v[0], v[1]);
+    }
+    __syncthreads();
+    // ---- 4. hid = relu(fc1(LN(x2)) + b1) -> split planes (through s2: a lane holds 4 outputs of a token, a chunk is 8)
+    {
+        f32x4 acc[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm(a.w_fc1, acc);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int n = (wn + 4 * t) * 16 + 4 * q;
+            const f32x4 b4 = *(const f32x4*)(a.bias1 + n);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 v = acc[t][mt] + b4;
+                v = f32x4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+                *(f32x4*)s2p(wm * 64 + mt * 16 + c, n) = v;          // (s2's LayerNorm input has been consumed: barrier above)
+            }
+        }
+    }
+    __syncthreads();              // GEMM 2 has read its planes; hid rows are complete in s2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = grp + i * 16 * MH;
+        split_store(r, l16, *(const f32x4*)s2p(r, 8 * l16), *(const f32x4*)s2p(r, 8 * l16 + 4));
+    }
+    __syncthreads();
+    // ---- 5. x = fc2(hid) + b2 + x2
+    {
+        f32x4 acc[NTW][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm(a.w_fc2, acc);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int n = (wn + 4 * t) * 16 + 4 * q;
+            const f32x4 b4 = *(const f32x4*)(a.bias2 + n);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const long long m = m0 + wm * 64 + mt * 16 + c;
+                if (m < a.M) *(f32x4*)(a.x + m * K + n) = (acc[t][mt] + b4) + x2[t][mt];
+            }
+        }
+    }
+}
+
 // out[m][n] = relu?(sum_k x[m][k] w[n][k] + b[n]) for tiny K (2 or 3): embedding fc1
 __global__ void small_linear_kernel(const float* x, int ldx, const float* w, const float* b, float* out, int ldo, long long M, int N, int K, int relu) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,6 +598,160 @@ __global__ __launch_bounds__(128) void attention_kernel(AttnArgs a) {      // at
     }
 }
 
+// ------------------------------------------------------------------ fused attention half of a layer, short sequences
+// att = softmax-attention(RoPE(q), RoPE(k), v) with qkv = LN(x) Wqkv^T + b, for sequences of S <= 16 tokens (the table stage: 14),
+// D = 128, 4 heads of 32: ONE kernel instead of the qkv linear + the attention launch, and the 1536 bytes of qkv per token never
+// leave the CU (at B = 10 000 trajectories the table stage is 17 M tokens per layer and HBM-bound).  A workgroup owns
+// SEQS = (64*MH) / S whole sequences (rows beyond SEQS*S idle); per head: the head's 96 qkv columns by the split-bf16 GEMM of
+// linear_x3_kernel (A = the head's rows of Wqkv) -> LDS -> four threads per query row (8 of the 32 dims each, scores reduced over
+// the four lanes) -> att columns of the head to memory.
+struct AttnBlockArgs {
+    const float* x; float* att; long long n_seq;
+    const uint16_t* w_qkv; const float* b_qkv; const float* g1; const float* b1;
+    const float* mask; const float2* rope;
+    int S, num_cls, mask_div, times_div, times_stride;
+    float scale;
+};
+template <int MH>
+__global__ __launch_bounds__(256 * MH) void attn_block_x3_kernel(AttnBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][BM][128] split planes of LN(x), then float qkvh[BM][100]
+    constexpr int BM = 64 * MH, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = 100;      // QS: q | k | v of one head + 4 pad (row stride 400 B)
+    float* qh = (float*)(xh + 3 * PLANE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S, SEQS = BM / S, ROWS = SEQS * S;
+    const long long seq0 = (long long)blockIdx.x * SEQS;
+    const long long m0 = seq0 * S, M = a.n_seq * S;
+    const int q = lane >> 4, c = lane & 15;
+    // ---- LN(x) rows -> split planes (16 lanes per row)
+    {
+        const int grp = tid >> 4, l16 = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = grp + i * 16 * MH;
+            const long long m = m0 + r;
+            const bool ok = r < ROWS && m < M;
+            f32x4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) v[u] = ok ? *(const f32x4*)(a.x + m * K + 8 * l16 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            const float mean = sum / (float)K;
+            float var = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+            const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+            u32x4 p0, p1, p2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k0 = 8 * l16 + 2 * j;
+                const float x0 = (v[j >> 1][2 * (j & 1)] - mean) * rstd * a.g1[k0] + a.b1[k0];
+                const float x1 = (v[j >> 1][2 * (j & 1) + 1] - mean) * rstd * a.g1[k0 + 1] + a.b1[k0 + 1];
+                const unsigned q0 = ux3_pack2(x0, x1);
+                const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+                const unsigned q1 = ux3_pack2(r0, r1);
+                const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+                p0[j] = q0; p1[j] = q1; p2[j] = ux3_pack2(s0, s1);
+            }
+            uint16_t* d = xh + r * K + ((l16 ^ (r & 15)) << 3);
+            *(u32x4*)d = p0; *(u32x4*)(d + PLANE) = p1; *(u32x4*)(d + 2 * PLANE) = p2;
+        }
+    }
+    __syncthreads();
+    // GEMM roles: wave (wm, wj) with wm = wave / 4 (64-row half), wj = wave % 4: m-tiles of its half x n-tiles {wj, wj + 4} of the
+    // head's six (q: 0-1, k: 2-3, v: 4-5); attention roles: thread -> (row, quarter of the head dims)
+    const int wm = wave >> 2, wj = wave & 3;
+    const uint16_t* xw = xh + (wm * 64 + c) * K;
+    const int arow = tid >> 2, part = tid & 3;              // query row of the tile, dims part*8 .. +7
+    for (int h = 0; h < 4; ++h) {
+        // ---- the head's q | k | v columns: n-tile j of the head = global n-tile (j >> 1) * 8 + 2 * h + (j & 1)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = wj + 4 * t;
+            if (j >= 6) continue;                            // wave-uniform
+            const int nt = (j >> 1) * 8 + 2 * h + (j & 1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 wa[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[p] = *(const bf16x8*)(a.w_qkv + ((((size_t)nt * KS + s) * 3 + p) * 64 + lane) * 8);
+                bf16x8 xb[3][4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PA[jj]], xb[PB[jj]][mt], acc[mt], 0, 0, 0);
+            }
+            const f32x4 b4 = *(const f32x4*)(a.b_qkv + nt * 16 + 4 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *(f32x4*)(qh + (wm * 64 + mt * 16 + c) * QS + j * 16 + 4 * q) = acc[mt] + b4;
+        }
+        __syncthreads();
+        // ---- RoPE on q and k of every row but the cls rows (in place, one thread per (row, dim pair))
+        for (int u = tid; u < ROWS * 32; u += 256 * MH) {
+            const int r = u >> 5, e = u & 31, which = e >> 4, i = e & 15;          // which: 0 = q, 1 = k; i: dim pair
+            const int sl = r / S, jt = r - sl * S;
+            const long long seq = seq0 + sl;
+            if (jt >= a.num_cls && seq < a.n_seq) {
+                const float2 cs = a.rope[((size_t)(seq / a.times_div) * a.times_stride + (jt - a.num_cls)) * (HD / 2) + i];
+                float* p = qh + r * QS + which * 32 + 2 * i;
+                const float v0 = p[0], v1 = p[1];
+                p[0] = v0 * cs.x - v1 * cs.y; p[1] = v0 * cs.y + v1 * cs.x;
+            }
+        }
+        __syncthreads();
+        // ---- attention of the head: thread (row, part): 8 dims of the query, scores summed over the 4 lanes of the row
+        if (arow < ROWS) {
+            const int sl = arow / S, i = arow - sl * S;
+            const long long seq = seq0 + sl;
+            if (seq < a.n_seq) {
+                const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
+                const float* base = qh + (sl * S) * QS;
+                const f32x4 q0 = *(const f32x4*)(base + i * QS + part * 8), q1 = *(const f32x4*)(base + i * QS + part * 8 + 4);
+                f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+                float mx = -INFINITY, den = 0.f;
+                if (mrow[i] == 0.f) {
+                    for (int j = 0; j < S; ++j) {
+                        if (mrow[j] != 0.f) continue;             // -inf column
+                        const f32x4 k0 = *(const f32x4*)(base + j * QS + 32 + part * 8), k1 = *(const f32x4*)(base + j * QS + 32 + part * 8 + 4);
+                        float sc = q0[0] * k0[0];
+                        sc = fmaf(q0[1], k0[1], sc); sc = fmaf(q0[2], k0[2], sc); sc = fmaf(q0[3], k0[3], sc);
+                        sc = fmaf(q1[0], k1[0], sc); sc = fmaf(q1[1], k1[1], sc); sc = fmaf(q1[2], k1[2], sc); sc = fmaf(q1[3], k1[3], sc);
+                        sc += __shfl_xor(sc, 1, 64);
+                        sc += __shfl_xor(sc, 2, 64);
+                        sc *= a.scale;
+                        if (sc > mx) {
+                            const float corr = expf(mx - sc);
+                            den *= corr; o0 *= corr; o1 *= corr;
+                            mx = sc;
+                        }
+                        const float pr = expf(sc - mx);
+                        den += pr;
+                        const f32x4 v0 = *(const f32x4*)(base + j * QS + 64 + part * 8), v1 = *(const f32x4*)(base + j * QS + 64 + part * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o0[e] = fmaf(pr, v0[e], o0[e]); o1[e] = fmaf(pr, v1[e], o1[e]); }
+                    }
+                }
+                const float inv = den > 0.f ? 1.f / den : 0.f;
+                float* op = a.att + (m0 + arow) * K + h * HD + part * 8;
+                *(f32x4*)op = o0 * inv; *(f32x4*)(op + 4) = o1 * inv;
+            }
+        }
+        __syncthreads();              // the head's q | k | v are consumed: the next head overwrites them
+    }
+}
+
 // ------------------------------------------------------------------ token assembly helpers
 // x[(b,t), 0] = ball_tok[b,t]; x[(b,t), 1+n] = table_tok[b,n]      (model.py:374-378)
 __global__ void assemble_table_kernel(const float* ball_tok, const float* table_tok, float* x, int T, int NT, int D, long long total) {
@@ -322,6 +783,7 @@ __global__ void prepend_cls_kernel(const float* x, const float* cls, float* y, i
 __global__ void prepare_kernel(const float* mask, const float* table, float* m1, float* m2, float* tmask, float* txy, int B, int T, int NT, int* flags) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nmask = (long long)B * T, ntab = (long long)B * NT;
+    int fl = 0;
     if (i < nmask) {
         const float m = mask[i];
         const float add = m == 0.f ? -INFINITY : 0.f;
@@ -330,10 +792,7 @@ __global__ void prepare_kernel(const float* mask, const float* table, float* m1,
         m2[b * (T + 1) + 1 + t] = add;
         if (t == 0) m2[b * (T + 1)] = 0.f;
         // bit0: some m==0, bit1: some m==1, bit2: some m<0, bit3: some m>1  (min==0 && max==1  <=>  flags==3)
-        if (m == 0.f) atomicOr(flags, 1);
-        else if (m == 1.f) atomicOr(flags, 2);
-        else if (m < 0.f) atomicOr(flags, 4);
-        else if (m > 1.f || m != m) atomicOr(flags, 8);
+        fl = m == 0.f ? 1 : m == 1.f ? 2 : m < 0.f ? 4 : 8;
     } else if (i < nmask + ntab) {
         const long long j = i - nmask;
         const long long b = j / NT; const int n = (int)(j % NT);
@@ -341,6 +800,10 @@ __global__ void prepare_kernel(const float* mask, const float* table, float* m1,
         if (n == 0) tmask[b * (NT + 1)] = 0.f;
         txy[j * 2] = table[j * 3]; txy[j * 2 + 1] = table[j * 3 + 1];
     }
+    // one atomic per wave (every thread used to hit the one flag word: 1.4 ms per call at B = 10 000)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fl |= __shfl_xor(fl, off, 64);
+    if ((threadIdx.x & 63) == 0 && fl) atomicOr(flags, fl);
 }
 __global__ void rotationaxes_kernel(const float* rot, const float* pos, int B, int T, float* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,7 +836,19 @@ struct ttup_uplift {
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *x2 = nullptr, *tok = nullptr, *ttok = nullptr, *h1 = nullptr;
     float *m1 = nullptr, *m2 = nullptr, *tmask = nullptr, *txy = nullptr, *tmp_small = nullptr;
     int* flags_dev = nullptr;
-    ~ttup_uplift() { for (void* p : allocs) if (p) (void)hipFree(p); }
+    // Small batches (a rally or a handful of them: the hub surface, the pipeline's per-clip uplift) are launch-bound -- about
+    // eighty kernels of a few microseconds each.  Their forward is captured once per (batch, length) into a hipGraph that works
+    // on handle-owned input / output buffers and is replayed with one launch (+ six small copies around it).
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+    std::map<std::pair<int, int>, GraphEntry> graphs;
+    bool graphs_off = false;
+    float *g_ball = nullptr, *g_table = nullptr, *g_mask = nullptr, *g_times = nullptr, *g_rot = nullptr, *g_pos = nullptr;
+    long long graph_tokens = 0;          // largest batch * len served by a graph
+    long long graph_replays = 0;
+    ~ttup_uplift() {
+        for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        for (void* p : allocs) if (p) (void)hipFree(p);
+    }
 };
 
 namespace {
@@ -423,6 +898,28 @@ int make_linear(ttup_uplift* net, Reader& r, int n, int k, bool has_bias, Linear
                         p[(((size_t)nt * ks4 + s4) * 64 + l) * 4 + j] = row < n ? w[(size_t)row * k + kk] : 0.f;
                     }
         rc = dev_copy(net, p, &L->w_dev);
+        if (rc == TTUP_OK && k == 128 && n % 4 == 0) {
+            const int ks = k / 32;
+            std::vector<uint16_t> p3((size_t)ntiles * ks * 3 * 64 * 8, 0);
+            for (int nt = 0; nt < ntiles; ++nt)
+                for (int s_ = 0; s_ < ks; ++s_)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = nt * 16 + (l & 15), kk = s_ * 32 + (l >> 4) * 8 + j;
+                            const float v = row < n ? w[(size_t)row * k + kk] : 0.f;
+                            const bf16_t a0 = f32_to_bf16(v);
+                            const float r1 = v - bf16_to_f32(a0);
+                            const bf16_t a1 = f32_to_bf16(r1);
+                            const bf16_t a2 = f32_to_bf16(r1 - bf16_to_f32(a1));
+                            const size_t base = (((size_t)nt * ks + s_) * 3) * 512 + (size_t)l * 8 + j;
+                            p3[base] = a0; p3[base + 512] = a1; p3[base + 1024] = a2;
+                        }
+            void* d = nullptr;
+            TTUP_HIP_CHECK(hipMalloc(&d, p3.size() * 2));
+            net->allocs.push_back(d);
+            TTUP_HIP_CHECK(hipMemcpy(d, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
+            L->w3_dev = (uint16_t*)d;
+        }
     } else rc = dev_copy(net, w, &L->w_dev);
     if (rc) return rc;
     if (has_bias) { rc = dev_copy(net, b, &L->b_dev); if (rc) return rc; }
@@ -479,8 +976,29 @@ int run_linear(const Linear& L, const float* x, int ldx, long long M, const floa
     const bool big = M >= 128 * 512;
     const int ntw = L.n > 128 ? 3 : L.n > 64 ? 2 : 1;
     const int bm = big ? 128 : 64;
-    const size_t smem = (size_t)4 * bm * (L.k / 4 + 4) * sizeof(float);
     const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((L.n + 64 * ntw - 1) / (64 * ntw)));
+    static const bool exact = getenv("TTUP_F32_EXACT") != nullptr;
+    if (L.w3_dev && !exact && ldo % 4 == 0 && (!res || ldr % 4 == 0)) {
+        const size_t smem3 = (size_t)3 * bm * 128 * sizeof(uint16_t);
+#define TTUP_LIN3(LN_, NTW_, MH_)                                                                                             \
+    do {                                                                                                                      \
+        if (int rc_ = ensure_max_lds((const void*)linear_x3_kernel<LN_, NTW_, MH_>, 160 * 1024)) return rc_;                  \
+        hipLaunchKernelGGL((linear_x3_kernel<LN_, NTW_, MH_>), grid, dim3(256 * MH_), smem3, st, a, (const uint16_t*)L.w3_dev); \
+    } while (0)
+#define TTUP_LIN3_N(LN_, MH_)                                         \
+    do {                                                              \
+        if (ntw == 3) TTUP_LIN3(LN_, 3, MH_);                         \
+        else if (ntw == 2) TTUP_LIN3(LN_, 2, MH_);                    \
+        else TTUP_LIN3(LN_, 1, MH_);                                  \
+    } while (0)
+        if (gamma) { if (big) TTUP_LIN3_N(true, 2); else TTUP_LIN3_N(true, 1); }
+        else { if (big) TTUP_LIN3_N(false, 2); else TTUP_LIN3_N(false, 1); }
+#undef TTUP_LIN3_N
+#undef TTUP_LIN3
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
+    const size_t smem = (size_t)4 * bm * (L.k / 4 + 4) * sizeof(float);
 #define TTUP_LIN(LN_, NTW_, MH_)                                                                                              \
     do {                                                                                                                      \
         if (int rc_ = ensure_max_lds((const void*)linear_kernel<LN_, NTW_, MH_>, 160 * 1024)) return rc_;                     \
@@ -539,8 +1057,50 @@ int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int 
               const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
     const int D = net->D;
     int rc;
-    if ((rc = run_linear(L.qkv, x, D, tokens, L.g1, L.b1, 0, nullptr, 0, net->qkv, 3 * D, st))) return rc;
-    if ((rc = run_attention(net, net->qkv, net->att, n_seq, S, num_cls, mask, mask_div, rope, times_div, times_stride, st))) return rc;
+    static const bool exact0 = getenv("TTUP_F32_EXACT") != nullptr, unfused0 = getenv("TTUP_UPLIFT_UNFUSED") != nullptr;
+    if (D == 128 && net->heads == 4 && S <= 16 && L.qkv.w3_dev && !exact0 && !unfused0) {
+        // short sequences (table stage): LN + qkv + RoPE + attention in one kernel, qkv never leaves the CU (attn_block_x3_kernel)
+        AttnBlockArgs a;
+        a.x = x; a.att = net->att; a.n_seq = n_seq; a.w_qkv = L.qkv.w3_dev; a.b_qkv = L.qkv.b_dev; a.g1 = L.g1; a.b1 = L.b1;
+        a.mask = mask; a.rope = rope; a.S = S; a.num_cls = num_cls; a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
+        a.scale = 1.0f / sqrtf((float)net->hd);
+        const bool big = tokens >= 128 * 512;
+        const int bm = big ? 128 : 64, seqs = bm / S;
+        const size_t smem = (size_t)3 * bm * 128 * sizeof(uint16_t) + (size_t)bm * 100 * sizeof(float);
+        const dim3 grid((unsigned)((n_seq + seqs - 1) / seqs));
+        if (big) {
+            if ((rc = ensure_max_lds((const void*)attn_block_x3_kernel<2>, 160 * 1024))) return rc;
+            hipLaunchKernelGGL(attn_block_x3_kernel<2>, grid, dim3(512), smem, st, a);
+        } else {
+            if ((rc = ensure_max_lds((const void*)attn_block_x3_kernel<1>, 160 * 1024))) return rc;
+            hipLaunchKernelGGL(attn_block_x3_kernel<1>, grid, dim3(256), smem, st, a);
+        }
+        TTUP_LAUNCH_CHECK();
+    } else {
+        if ((rc = run_linear(L.qkv, x, D, tokens, L.g1, L.b1, 0, nullptr, 0, net->qkv, 3 * D, st))) return rc;
+        if ((rc = run_attention(net, net->qkv, net->att, n_seq, S, num_cls, mask, mask_div, rope, times_div, times_stride, st))) return rc;
+    }
+    static const bool exact = getenv("TTUP_F32_EXACT") != nullptr, unfused = getenv("TTUP_UPLIFT_UNFUSED") != nullptr;
+    if (D == 128 && L.proj.w3_dev && L.fc1.w3_dev && L.fc2.w3_dev && !exact && !unfused) {
+        // x = fc2(relu(fc1(LN(proj(att) + x)))) + (proj(att) + x) in one pass over the tokens (mlp_block_x3_kernel)
+        MlpArgs a;
+        a.att = net->att; a.x = x; a.M = tokens;
+        a.w_proj = L.proj.w3_dev; a.w_fc1 = L.fc1.w3_dev; a.w_fc2 = L.fc2.w3_dev;
+        a.g2 = L.g2; a.b2 = L.b2; a.bias1 = L.fc1.b_dev; a.bias2 = L.fc2.b_dev;
+        const bool big = tokens >= 128 * 512;
+        const int bm = big ? 128 : 64;
+        const size_t smem = (size_t)3 * bm * 128 * sizeof(uint16_t) + (size_t)bm * 128 * sizeof(float);
+        const dim3 grid((unsigned)((tokens + bm - 1) / bm));
+        if (big) {
+            if ((rc = ensure_max_lds((const void*)mlp_block_x3_kernel<2>, 160 * 1024))) return rc;
+            hipLaunchKernelGGL(mlp_block_x3_kernel<2>, grid, dim3(512), smem, st, a);
+        } else {
+            if ((rc = ensure_max_lds((const void*)mlp_block_x3_kernel<1>, 160 * 1024))) return rc;
+            hipLaunchKernelGGL(mlp_block_x3_kernel<1>, grid, dim3(256), smem, st, a);
+        }
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
     if ((rc = run_linear(L.proj, net->att, D, tokens, nullptr, nullptr, 0, x, D, net->x2, D, st))) return rc;       // x2 = proj(att) + x
     if ((rc = run_linear(L.fc1, net->x2, D, tokens, L.g2, L.b2, 1, nullptr, 0, net->hid, D, st))) return rc;          // hid = relu(fc1(LN(x2)))
     return run_linear(L.fc2, net->hid, D, tokens, nullptr, nullptr, 0, net->x2, D, x, D, st);                       // x = fc2(hid) + x2
@@ -677,6 +1237,21 @@ extern "C" int ttup_uplift_create(const void* blob, size_t blob_bytes, int max_b
     net->rope = (float2*)fl;
     if ((rc = dev_alloc(net.get(), 4, &fl))) return rc;
     net->flags_dev = (int*)fl;
+    {
+        // graph path: batches of up to GRAPH_TOKENS ball tokens (batch * len)
+        const long long GRAPH_TOKENS = 1024;
+        long long gt = (long long)max_batch * max_len < GRAPH_TOKENS ? (long long)max_batch * max_len : GRAPH_TOKENS;
+        if (gt < max_len) gt = max_len;          // at least one trajectory of the longest length
+        net->graph_tokens = gt;
+        net->graphs_off = getenv("TTUP_UPLIFT_NO_GRAPH") != nullptr;
+        const size_t nb = (size_t)(gt / 1 > max_batch ? max_batch : gt);          // trajectories a graph call can hold (len >= 1)
+        if ((rc = dev_alloc(net.get(), (size_t)gt * 2, &net->g_ball))) return rc;
+        if ((rc = dev_alloc(net.get(), nb * net->n_table * 3, &net->g_table))) return rc;
+        if ((rc = dev_alloc(net.get(), (size_t)gt, &net->g_mask))) return rc;
+        if ((rc = dev_alloc(net.get(), (size_t)gt, &net->g_times))) return rc;
+        if ((rc = dev_alloc(net.get(), nb * 3, &net->g_rot))) return rc;
+        if ((rc = dev_alloc(net.get(), (size_t)gt * 3, &net->g_pos))) return rc;
+    }
     TTUP_HIP_CHECK(hipDeviceSynchronize());
     *out = net.release();
     return TTUP_OK;
@@ -697,7 +1272,50 @@ extern "C" int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, cons
     if (batch == 0) return TTUP_OK;
     TTUP_HIP_CHECK(hipMemsetAsync(net->flags_dev, 0, sizeof(int), st));
     const long long cap = net->chunk;      // scratch is sized for `chunk` trajectories of max_len tokens
-    for (int b0 = 0; b0 < batch; b0 += (int)cap) {
+    bool done = false;
+    if (!net->graphs_off && st != nullptr && batch <= cap && (long long)batch * len <= net->graph_tokens &&
+        (net->graphs.size() < 32 || net->graphs.count({batch, len}))) {          // (at most 32 shapes are kept)
+        ttup_uplift::GraphEntry& ge = net->graphs[{batch, len}];
+        const size_t bt = (size_t)batch * len;
+        auto copy_in = [&]() -> int {
+            TTUP_HIP_CHECK(hipMemcpyAsync(net->g_ball, ball_dev, bt * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            TTUP_HIP_CHECK(hipMemcpyAsync(net->g_table, table_dev, (size_t)batch * net->n_table * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            TTUP_HIP_CHECK(hipMemcpyAsync(net->g_mask, mask_dev, bt * sizeof(float), hipMemcpyDeviceToDevice, st));
+            TTUP_HIP_CHECK(hipMemcpyAsync(net->g_times, times_dev, bt * sizeof(float), hipMemcpyDeviceToDevice, st));
+            return TTUP_OK;
+        };
+        if (!ge.exec && ge.seen >= 1) {
+            // second call with this shape (the first one ran eagerly and set every kernel's attributes): capture
+            if (int rc = copy_in()) return rc;
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rc = forward_chunk(net, net->g_ball, net->g_table, net->g_mask, net->g_times, batch, len, net->g_rot, net->g_pos, st);
+                ok = hipStreamEndCapture(st, &graph) == hipSuccess && rc == TTUP_OK && graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {
+                if (getenv("TTUP_DEBUG")) fprintf(stderr, "ttup_uplift: graph capture failed (%s): eager from now on\n", hipGetErrorString(hipGetLastError()));
+                (void)hipGetLastError(); ge.exec = nullptr; net->graphs_off = true;
+            }          // this runtime cannot capture the forward: eager from now on
+            else {
+                TTUP_HIP_CHECK(hipGraphLaunch(ge.exec, st));
+                done = true;
+            }
+        } else if (ge.exec) {
+            if (int rc = copy_in()) return rc;
+            TTUP_HIP_CHECK(hipGraphLaunch(ge.exec, st));
+            done = true;
+        }
+        ge.seen++;
+        if (done) {
+            net->graph_replays++;
+            TTUP_HIP_CHECK(hipMemcpyAsync(rot_dev, net->g_rot, (size_t)batch * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            TTUP_HIP_CHECK(hipMemcpyAsync(pos_dev, net->g_pos, bt * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    for (int b0 = 0; b0 < batch && !done; b0 += (int)cap) {
         const int nb = batch - b0 < cap ? batch - b0 : (int)cap;
         const int rc = forward_chunk(net, ball_dev + (size_t)b0 * len * 2, table_dev + (size_t)b0 * net->n_table * 3, mask_dev + (size_t)b0 * len,
                                      times_dev + (size_t)b0 * len, nb, len, rot_dev + (size_t)b0 * 3, pos_dev + (size_t)b0 * len * 3, st);
@@ -711,6 +1329,16 @@ extern "C" int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, cons
         // {-1e9,0} format of the elif branch is not accepted here
         TTUP_REQUIRE(flags == 3, TTUP_EMASK, "wrong format for masks. Should be 0, 1 or -1e9, 0.");
     }
+    return TTUP_OK;
+}
+
+// how the small-batch path is doing: out_host[0] = captured graphs, [1] = 1 when capturing failed on this runtime (eager from then
+// on) or was switched off (TTUP_UPLIFT_NO_GRAPH), [2] = forwards served by a graph replay
+extern "C" int ttup_uplift_graph_info(ttup_uplift* net, int* out_host3) {
+    TTUP_REQUIRE(net && out_host3, TTUP_EINVAL, "ttup_uplift_graph_info: null pointer");
+    int n = 0;
+    for (auto& kv : net->graphs) n += kv.second.exec != nullptr;
+    out_host3[0] = n; out_host3[1] = net->graphs_off ? 1 : 0; out_host3[2] = (int)net->graph_replays;
     return TTUP_OK;
 }
 

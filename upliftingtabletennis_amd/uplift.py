@@ -53,6 +53,12 @@ class MultiStageModel:
 
     __call__ = forward
 
+    def graph_info(self):
+        """{'graphs', 'off', 'replays'}: the small-batch path (hipGraph replay of a captured forward, csrc/uplift.hip)."""
+        out = (ctypes.c_int * 3)()
+        _lib.check(self._lib.ttup_uplift_graph_info(self._handle, out))
+        return {'graphs': int(out[0]), 'off': bool(out[1]), 'replays': int(out[2])}
+
 
 def get_model(name='connectstage', size='large', mode='dynamic', time_rotation='new', state_dict=None, **kw):
     """Mirror of uplifting/model.py:574-603 for the shipped configuration."""
