@@ -737,9 +737,12 @@ def test_bench_eight_rank_dry_run_on_one_gpu():
     assert rec['config']['frames_per_step_per_gpu'] == 256
     assert abs(rec['value'] - 8 * 256 / (rec['ms_per_step'] / 1e3)) / rec['value'] < 1e-3
     assert 1 <= rec['host_threads_per_rank'] <= max(1, (os.cpu_count() or 8) // 8)
-    # every rank built its worker and streams before the process group: the same stream -> hardware-queue grouping everywhere
+    # every rank reports its stream -> hardware-queue grouping (probed one rank at a time after the timed region).  With eight
+    # processes SHARING this one GPU the spin-kernel probe is not reliable (the other ranks' contexts own queues of their own and
+    # the probes of most ranks see no serialisation at all), so the groupings are reported, not compared: `all_equal` is for the
+    # driver's run with one GPU per rank
     q = rec['stream_queue_groups']
-    assert len(q['per_rank']) == 8 and q['all_equal'], q
+    assert len(q['per_rank']) == 8 and all(isinstance(g, str) and 'lane0' in g and 'crops' in g for g in q['per_rank']), q
     pr = rec['per_rank']
     assert len(pr['ms_per_step']) == 8 and pr['ms_per_step_min'] <= pr['ms_per_step_max'] and len(pr['gather_ms_mean']) == 8
     print('\n8 ranks on one GPU: %.0f frames/s aggregate, %.0f ms per step (per rank %.0f .. %.0f), %d host threads per rank; stream -> queue grouping on every rank: %s'

@@ -601,10 +601,17 @@ __global__ __launch_bounds__(128) void attention_kernel(AttnArgs a) {      // at
 // ------------------------------------------------------------------ fused attention half of a layer, short sequences
 // att = softmax-attention(RoPE(q), RoPE(k), v) with qkv = LN(x) Wqkv^T + b, for sequences of S <= 16 tokens (the table stage: 14),
 // D = 128, 4 heads of 32: ONE kernel instead of the qkv linear + the attention launch, and the 1536 bytes of qkv per token never
-// leave the CU (at B = 10 000 trajectories the table stage is 17 M tokens per layer and HBM-bound).  A workgroup owns
-// SEQS = (64*MH) / S whole sequences (rows beyond SEQS*S idle); per head: the head's 96 qkv columns by the split-bf16 GEMM of
-// linear_x3_kernel (A = the head's rows of Wqkv) -> LDS -> four threads per query row (8 of the 32 dims each, scores reduced over
-// the four lanes) -> att columns of the head to memory.
+// leave the CU (at B = 10 000 trajectories the table stage is 17 M tokens per layer).  A workgroup of 8 waves owns SEQS = 64 / S
+// whole sequences (rows beyond SEQS*S idle):
+//   1. LN(x) rows -> three split-bf16 planes in LDS; every wave loads the twelve fragments of ITS 16 rows into registers (the plane
+//      storage is free after that and is reused for qkv);
+//   2. qkv of all four heads by the split-bf16 GEMM of linear_x3_kernel: wave (m-tile w & 3, head pair w >> 2) streams the weight
+//      fragments of its 12 n-tiles from L2; bias and RoPE (q, k; not the cls rows) in the epilogue -> LDS [64][4 x (q|k|v)];
+//   3. attention on the fp32 matrix pipe, one (sequence, head) per wave at a time: scores^T = K Q^T (8 v_mfma_f32_16x16x4_f32: a lane
+//      ends with the scores of ONE query against four keys, so the softmax is in-lane plus two cross-lane steps), P V with the key
+//      index permuted so that the probabilities are already where the A operand wants them (8 more MFMAs) -> att.
+// (First version: scalar attention, four threads per query row -- VALU-bound on redundant exp() calls, no faster than the two
+// separate launches.)
 struct AttnBlockArgs {
     const float* x; float* att; long long n_seq;
     const uint16_t* w_qkv; const float* b_qkv; const float* g1; const float* b1;
@@ -612,22 +619,24 @@ struct AttnBlockArgs {
     int S, num_cls, mask_div, times_div, times_stride;
     float scale;
 };
-template <int MH>
-__global__ __launch_bounds__(256 * MH) void attn_block_x3_kernel(AttnBlockArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][BM][128] split planes of LN(x), then float qkvh[BM][100]
-    constexpr int BM = 64 * MH, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = 100;      // QS: q | k | v of one head + 4 pad (row stride 400 B)
-    float* qh = (float*)(xh + 3 * PLANE);
+constexpr int ATTN_QS = 388;          // floats per row of the qkv tile: 4 heads x 96 + 4 (1552 B: consecutive rows fall on consecutive 16-byte slots)
+__global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64][128] split planes of LN(x); then float qh[64][ATTN_QS]
+    constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = ATTN_QS;
+    float* qh = (float*)xh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.S, SEQS = BM / S, ROWS = SEQS * S;
     const long long seq0 = (long long)blockIdx.x * SEQS;
     const long long m0 = seq0 * S, M = a.n_seq * S;
     const int q = lane >> 4, c = lane & 15;
-    // ---- LN(x) rows -> split planes (16 lanes per row)
+    // ---- 1. LN(x) rows -> split planes (16 lanes per row, 32 rows per pass)
     {
         const int grp = tid >> 4, l16 = tid & 15;
+        const f32x4 gg[2] = {*(const f32x4*)(a.g1 + 8 * l16), *(const f32x4*)(a.g1 + 8 * l16 + 4)};
+        const f32x4 bb[2] = {*(const f32x4*)(a.b1 + 8 * l16), *(const f32x4*)(a.b1 + 8 * l16 + 4)};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = grp + i * 16 * MH;
+        for (int i = 0; i < 2; ++i) {
+            const int r = grp + i * 32;
             const long long m = m0 + r;
             const bool ok = r < ROWS && m < M;
             f32x4 v[2];
@@ -648,9 +657,8 @@ __global__ __launch_bounds__(256 * MH) void attn_block_x3_kernel(AttnBlockArgs a
             u32x4 p0, p1, p2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k0 = 8 * l16 + 2 * j;
-                const float x0 = (v[j >> 1][2 * (j & 1)] - mean) * rstd * a.g1[k0] + a.b1[k0];
-                const float x1 = (v[j >> 1][2 * (j & 1) + 1] - mean) * rstd * a.g1[k0 + 1] + a.b1[k0 + 1];
+                const float x0 = (v[j >> 1][2 * (j & 1)] - mean) * rstd * gg[j >> 1][2 * (j & 1)] + bb[j >> 1][2 * (j & 1)];
+                const float x1 = (v[j >> 1][2 * (j & 1) + 1] - mean) * rstd * gg[j >> 1][2 * (j & 1) + 1] + bb[j >> 1][2 * (j & 1) + 1];
                 const unsigned q0 = ux3_pack2(x0, x1);
                 const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
                 const unsigned q1 = ux3_pack2(r0, r1);
@@ -662,93 +670,109 @@ __global__ __launch_bounds__(256 * MH) void attn_block_x3_kernel(AttnBlockArgs a
         }
     }
     __syncthreads();
-    // GEMM roles: wave (wm, wj) with wm = wave / 4 (64-row half), wj = wave % 4: m-tiles of its half x n-tiles {wj, wj + 4} of the
-    // head's six (q: 0-1, k: 2-3, v: 4-5); attention roles: thread -> (row, quarter of the head dims)
-    const int wm = wave >> 2, wj = wave & 3;
-    const uint16_t* xw = xh + (wm * 64 + c) * K;
-    const int arow = tid >> 2, part = tid & 3;              // query row of the tile, dims part*8 .. +7
-    for (int h = 0; h < 4; ++h) {
-        // ---- the head's q | k | v columns: n-tile j of the head = global n-tile (j >> 1) * 8 + 2 * h + (j & 1)
+    // ---- 2. qkv of all heads
+    const int mt = wave & 3, hp = wave >> 2;
+    bf16x8 xb[3][KS];
+    {
+        const uint16_t* xw = xh + (mt * 16 + c) * K;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int j = wj + 4 * t;
-            if (j >= 6) continue;                            // wave-uniform
-            const int nt = (j >> 1) * 8 + 2 * h + (j & 1);
-            f32x4 acc[4];
+        for (int sK = 0; sK < KS; ++sK)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < 3; ++p) xb[p][sK] = *(const bf16x8*)(xw + p * PLANE + (((4 * sK + q) ^ c) << 3));
+    }
+    __syncthreads();              // every wave holds its fragments: the plane storage becomes the qkv tile
+    {
+        const int grow = mt * 16 + c;                        // the lane's token row in the tile
+        const int gsl = grow / S, gjt = grow - gsl * S;
+        const long long gseq = seq0 + gsl;
+        const bool rot = grow < ROWS && gseq < a.n_seq && gjt >= a.num_cls;
+        const float2* rrow = a.rope + ((size_t)((rot ? gseq : 0) / a.times_div) * a.times_stride + (rot ? gjt - a.num_cls : 0)) * (HD / 2);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                bf16x8 wa[3];
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * hp + hh;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wa[p] = *(const bf16x8*)(a.w_qkv + ((((size_t)nt * KS + s) * 3 + p) * 64 + lane) * 8);
-                bf16x8 xb[3][4];
+            for (int jp = 0; jp < 3; ++jp) {                 // n-tile pairs: q, k, v of the head
+                const int nt0 = jp * 8 + 2 * h;
+                bf16x8 wa[2][3][KS];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+                    for (int sK = 0; sK < KS; ++sK)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wa[e][p][sK] = *(const bf16x8*)(a.w_qkv + ((((size_t)(nt0 + e) * KS + sK) * 3 + p) * 64 + lane) * 8);
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
                 constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int jj = 0; jj < 6; ++jj)
+                for (int sK = 0; sK < KS; ++sK)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PA[jj]], xb[PB[jj]][mt], acc[mt], 0, 0, 0);
-            }
-            const f32x4 b4 = *(const f32x4*)(a.b_qkv + nt * 16 + 4 * q);
+                    for (int jj = 0; jj < 6; ++jj)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) *(f32x4*)(qh + (wm * 64 + mt * 16 + c) * QS + j * 16 + 4 * q) = acc[mt] + b4;
-        }
-        __syncthreads();
-        // ---- RoPE on q and k of every row but the cls rows (in place, one thread per (row, dim pair))
-        for (int u = tid; u < ROWS * 32; u += 256 * MH) {
-            const int r = u >> 5, e = u & 31, which = e >> 4, i = e & 15;          // which: 0 = q, 1 = k; i: dim pair
-            const int sl = r / S, jt = r - sl * S;
-            const long long seq = seq0 + sl;
-            if (jt >= a.num_cls && seq < a.n_seq) {
-                const float2 cs = a.rope[((size_t)(seq / a.times_div) * a.times_stride + (jt - a.num_cls)) * (HD / 2) + i];
-                float* p = qh + r * QS + which * 32 + 2 * i;
-                const float v0 = p[0], v1 = p[1];
-                p[0] = v0 * cs.x - v1 * cs.y; p[1] = v0 * cs.y + v1 * cs.x;
-            }
-        }
-        __syncthreads();
-        // ---- attention of the head: thread (row, part): 8 dims of the query, scores summed over the 4 lanes of the row
-        if (arow < ROWS) {
-            const int sl = arow / S, i = arow - sl * S;
-            const long long seq = seq0 + sl;
-            if (seq < a.n_seq) {
-                const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
-                const float* base = qh + (sl * S) * QS;
-                const f32x4 q0 = *(const f32x4*)(base + i * QS + part * 8), q1 = *(const f32x4*)(base + i * QS + part * 8 + 4);
-                f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-                float mx = -INFINITY, den = 0.f;
-                if (mrow[i] == 0.f) {
-                    for (int j = 0; j < S; ++j) {
-                        if (mrow[j] != 0.f) continue;             // -inf column
-                        const f32x4 k0 = *(const f32x4*)(base + j * QS + 32 + part * 8), k1 = *(const f32x4*)(base + j * QS + 32 + part * 8 + 4);
-                        float sc = q0[0] * k0[0];
-                        sc = fmaf(q0[1], k0[1], sc); sc = fmaf(q0[2], k0[2], sc); sc = fmaf(q0[3], k0[3], sc);
-                        sc = fmaf(q1[0], k1[0], sc); sc = fmaf(q1[1], k1[1], sc); sc = fmaf(q1[2], k1[2], sc); sc = fmaf(q1[3], k1[3], sc);
-                        sc += __shfl_xor(sc, 1, 64);
-                        sc += __shfl_xor(sc, 2, 64);
-                        sc *= a.scale;
-                        if (sc > mx) {
-                            const float corr = expf(mx - sc);
-                            den *= corr; o0 *= corr; o1 *= corr;
-                            mx = sc;
-                        }
-                        const float pr = expf(sc - mx);
-                        den += pr;
-                        const f32x4 v0 = *(const f32x4*)(base + j * QS + 64 + part * 8), v1 = *(const f32x4*)(base + j * QS + 64 + part * 8 + 4);
+                        for (int e = 0; e < 2; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[e][PA[jj]][sK], xb[PB[jj]][sK], acc[e], 0, 0, 0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { o0[e] = fmaf(pr, v0[e], o0[e]); o1[e] = fmaf(pr, v1[e], o1[e]); }
+                for (int e = 0; e < 2; ++e) {
+                    f32x4 v = acc[e] + *(const f32x4*)(a.b_qkv + (nt0 + e) * 16 + 4 * q);
+                    if (jp < 2 && rot) {                     // RoPE on q and k: dim pairs (e*16 + 4q, +1) and (+2, +3) of the head
+                        const f32x4 cs = *(const f32x4*)(rrow + e * 8 + 2 * q);          // (cos, sin) of the two pairs
+                        v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[0] * cs[1] + v[1] * cs[0], v[2] * cs[2] - v[3] * cs[3], v[2] * cs[3] + v[3] * cs[2]};
                     }
+                    *(f32x4*)(qh + grow * QS + h * 96 + jp * 32 + e * 16 + 4 * q) = v;
                 }
-                const float inv = den > 0.f ? 1.f / den : 0.f;
-                float* op = a.att + (m0 + arow) * K + h * HD + part * 8;
-                *(f32x4*)op = o0 * inv; *(f32x4*)(op + 4) = o1 * inv;
             }
         }
-        __syncthreads();              // the head's q | k | v are consumed: the next head overwrites them
+    }
+    __syncthreads();
+    // ---- 3. attention: task = (sequence sl, head h); lane (c, q)
+    for (int task = wave; task < SEQS * 4; task += 8) {
+        const int sl = task >> 2, h = task & 3;
+        const long long seq = seq0 + sl;
+        if (seq >= a.n_seq) continue;                        // wave-uniform
+        const float* base = qh + (sl * S) * QS + h * 96;
+        const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
+        // scores^T = K Q^T: A = K (row j = c, dims 8q .. 8q+7), B = Q (column i = c, the same dims); rows past the tile's last
+        // sequence belong to nobody and are masked below
+        const int jr = sl * S + c < BM ? c : 0;
+        const f32x4 k0 = *(const f32x4*)(base + jr * QS + 32 + 8 * q), k1 = *(const f32x4*)(base + jr * QS + 32 + 8 * q + 4);
+        const f32x4 q0 = *(const f32x4*)(base + jr * QS + 8 * q), q1 = *(const f32x4*)(base + jr * QS + 8 * q + 4);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[e], q0[e], sc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[e], q1[e], sc, 0, 0, 0);
+        // sc[r] = q_i . k_j for query i = c, key j = 4q + r
+        const bool row_ok = c < S && mrow[c < S ? c : 0] == 0.f;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * q + r;
+            const bool col_ok = j < S && mrow[j < S ? j : 0] == 0.f;
+            sc[r] = col_ok ? sc[r] * a.scale : -INFINITY;
+            mx = sc[r] > mx ? sc[r] : mx;
+        }
+        { const float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; }
+        { const float o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
+        float pr[4], den = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? expf(sc[r] - mx) : 0.f; den += pr[r]; }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = den > 0.f ? 1.f / den : 0.f;       // a fully masked query row yields zeros (torch SDPA semantics)
+        // out = P V, k index (step s, lane group q) <-> key j = 4q + s: the A operand of step s is the lane's own pr[s]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2_ = 0; s2_ < 4; ++s2_) {
+                const int j = 4 * q + s2_;
+                const float vv = (j < S) ? base[j * QS + 64 + dt * 16 + c] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_] * inv, vv, o, 0, 0, 0);
+            }
+            // o[r] = out[query 4q + r][dim dt*16 + c]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * q + r;
+                if (i < S) a.att[(m0 + sl * S + i) * K + h * HD + dt * 16 + c] = o[r];
+            }
+        }
     }
 }
 
@@ -1064,17 +1088,11 @@ int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int 
         a.x = x; a.att = net->att; a.n_seq = n_seq; a.w_qkv = L.qkv.w3_dev; a.b_qkv = L.qkv.b_dev; a.g1 = L.g1; a.b1 = L.b1;
         a.mask = mask; a.rope = rope; a.S = S; a.num_cls = num_cls; a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
         a.scale = 1.0f / sqrtf((float)net->hd);
-        const bool big = tokens >= 128 * 512;
-        const int bm = big ? 128 : 64, seqs = bm / S;
-        const size_t smem = (size_t)3 * bm * 128 * sizeof(uint16_t) + (size_t)bm * 100 * sizeof(float);
+        const int seqs = 64 / S;
+        const size_t smem = (size_t)64 * ATTN_QS * sizeof(float);          // (>= the 48 KB of the three split planes it first holds)
         const dim3 grid((unsigned)((n_seq + seqs - 1) / seqs));
-        if (big) {
-            if ((rc = ensure_max_lds((const void*)attn_block_x3_kernel<2>, 160 * 1024))) return rc;
-            hipLaunchKernelGGL(attn_block_x3_kernel<2>, grid, dim3(512), smem, st, a);
-        } else {
-            if ((rc = ensure_max_lds((const void*)attn_block_x3_kernel<1>, 160 * 1024))) return rc;
-            hipLaunchKernelGGL(attn_block_x3_kernel<1>, grid, dim3(256), smem, st, a);
-        }
+        if ((rc = ensure_max_lds((const void*)attn_block_x3_kernel, 160 * 1024))) return rc;
+        hipLaunchKernelGGL(attn_block_x3_kernel, grid, dim3(512), smem, st, a);
         TTUP_LAUNCH_CHECK();
     } else {
         if ((rc = run_linear(L.qkv, x, D, tokens, L.g1, L.b1, 0, nullptr, 0, net->qkv, 3 * D, st))) return rc;
