@@ -70,6 +70,7 @@ struct ConvKArgs {
     const bf16_t* wl32; const float* bl32; bf16_t* dl32;
     // conv_s2_pair_kernel: the second conv on the same input (16 -> 16), its own ReLU flag
     const bf16_t* wpack_b; const float* bias_b; bf16_t* dst_b; int relu_b;
+    int xcd;           // conv_mfma_kernel: walk the tiles in the XCD-aware order of xcd_tile (stride-2 convs; see launch_mfma)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 
     u32x4 pin[IN_PT], pw[W_PT];
     auto issue = [&](int item) {
-        const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
+        const int tl0 = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
+        const int tl = a.xcd ? xcd_tile(tl0, a.total_tiles) : tl0;
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
         const int gy0 = (t / a.tiles_x) * TH * S - PAD, gx0 = (t % a.tiles_x) * TW * S - PAD;
         const bool first = chunk < a.nchunk0;
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 #endif
         if (chunk != nchunk - 1) continue;
         // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
-        const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
+        const int tl0 = blockIdx.x + (item / nchunk) * gridDim.x;
+        const int tl = a.xcd ? xcd_tile(tl0, a.total_tiles) : tl0;
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
 #pragma unroll
@@ -2054,6 +2057,9 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     }
     a.tiles_per_img = a.tiles_x * cdiv(a.OH, TH);
     a.total_tiles = a.tiles_per_img * l.batch;
+    // XCD-aware tile order for the stride-2 convs (env TTUP_S2_XCD=0/1 overrides; the stride-1 full-resolution conv is 5-10 % slower with it)
+    static const int s2_xcd = getenv("TTUP_S2_XCD") ? atoi(getenv("TTUP_S2_XCD")) : 0;
+    a.xcd = (S == 2) ? s2_xcd : 0;
     // persistent grid: as many workgroups as can be resident (LDS-limited), each walks its share of the tiles
     const int per_cu = (int)((160 * 1024) / SMEM) > 4 ? 4 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
     const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;

@@ -359,14 +359,15 @@ class TableTennisPipeline:
         self.device = torch.device('cuda')
         self.CHUNK = int(os.environ.get('TTUP_HUB_CHUNK', self.CHUNK))
         self.FIRST = int(os.environ.get('TTUP_HUB_FIRST', self.FIRST))
+        self.CHUNK_LONG = max(self.CHUNK, int(os.environ.get('TTUP_HUB_CHUNK_LONG', self.CHUNK_LONG)))
         # one lane per detector: the two handles already run side by side on their own streams; with two lanes each, four CNN streams
         # (plus copy, audit and refine work) collide on the runtime's four hardware queues, and a high-priority table kernel queued
         # behind a ball kernel is no longer ahead of it (measured on a 48-frame clip: 748-757 -> 804-820 frames/s; table lanes alone:
         # 808-811; GPU_MAX_HW_QUEUES=8 with one lane each: 843)
         lanes = int(os.environ.get('TTUP_HUB_LANES', '1'))
-        self.ball_detector = BallDetector(model_name='wasb', max_batch=max(max_batch, self.CHUNK), lanes=lanes)
+        self.ball_detector = BallDetector(model_name='wasb', max_batch=max(max_batch, self.CHUNK_LONG), lanes=lanes)
         self.ball_detector_aux = self.ball_detector       # the primary SegFormer++ detector is not available offline
-        self.table_detector = TableDetector(model_name='hrnet', max_batch=max(16, self.CHUNK), lanes=lanes)
+        self.table_detector = TableDetector(model_name='hrnet', max_batch=max(16, self.CHUNK_LONG), lanes=lanes)
         self.table_detector_aux = self.table_detector
         # the overlapped clip path runs both detectors side by side: the table detector goes first on the GPU, so that its
         # host-side consumer (the DBSCAN keypoint filter) overlaps with the rest of the ball detector
@@ -385,6 +386,7 @@ class TableTennisPipeline:
         return self._predict(images, fps, table_keypoints)
 
     CHUNK = 24          # frames per upload / detector call of the overlapped clip path (measured: 16 -> 68 ms, 24 -> 60 ms, 48 -> 63 ms per 48-frame clip)
+    CHUNK_LONG = 64     # ... of clips of at least four chunks, after their first chunk: a detector call drains at its end, so long clips take fewer, larger calls (256 frames: 868 -> see DESIGN.md 11)
     FIRST = 24          # frames of the first chunk (a short first chunk -- 8 frames -- was measured 5 ms SLOWER per clip: its one-micro-batch calls run at half the batched rate)
 
     def _clip_detections(self, images, want_table, table_consumer=None):
@@ -392,7 +394,9 @@ class TableTennisPipeline:
         pinned memory and uploaded ONCE in chunks on a copy stream; while chunk k+1 is staged and copied, the table detector
         runs on chunk k on its own stream and the ball detector on the triples whose three frames are already resident on a
         third; the host blocks only at the end.  Same values as `predict_clip` / `predict_keypoints` (same kernels per frame)."""
-        n, dev, C = len(images), self.device, self.CHUNK
+        n, dev = len(images), self.device
+        C = self.CHUNK if n < 4 * self.CHUNK else self.CHUNK_LONG
+        CP = self.CHUNK_LONG                       # rows of the pinned staging buffers
         h0, w0 = np.asarray(images[0]).shape[:2]
         bd, td = self.ball_detector, self.table_detector
         bw, bh = bd.model_resolution
@@ -402,10 +406,10 @@ class TableTennisPipeline:
         if st is None:
             st = self._streams = {k: torch.cuda.Stream(dev) for k in ('ball', 'table')}
             st['copy'] = st['table']          # uploads ride on the table stream (chunk k+1 behind the table pass of chunk k): one stream fewer
-            self._pinned = [torch.empty((C, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._pinned = [torch.empty((CP, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
             self._pin_free = [None, None]
         if self._pinned[0].shape[1:] != (h0, w0, 3):
-            self._pinned = [torch.empty((C, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._pinned = [torch.empty((CP, h0, w0, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
             self._pin_free = [None, None]
         cur = torch.cuda.current_stream(dev)
         for s in st.values():
@@ -528,7 +532,7 @@ class TableTennisPipeline:
 
     def _predict(self, images, fps, table_keypoints):
         overlapped = (self.ball_detector_aux is self.ball_detector and self.table_detector_aux is self.table_detector and len(images) >= 3
-                      and self.table_detector.max_batch >= self.CHUNK and self.ball_detector.max_batch >= self.CHUNK
+                      and self.table_detector.max_batch >= self.CHUNK_LONG and self.ball_detector.max_batch >= self.CHUNK_LONG
                       and os.environ.get('TTUP_HUB_SERIAL') != '1')
         if overlapped:
             ball_positions, kp = self._clip_detections(images, want_table=table_keypoints is None,
