@@ -594,6 +594,39 @@ def test_single_lane_handle_equals_the_two_lane_handle():
         wasb.WASBNet(sd, resolution=(1280, 704), max_batch=24, dtype='bf16', lanes=5)
 
 
+def test_hub_table_detector_keypoint_indices_equal_the_fp32_path_on_a_64_frame_soak():
+    """VERDICT r3 #6 done-criterion: the hub surface's table keypoints come from the certified argmax.  `TableDetector('hrnet')`
+    (seeded stand-in weights with a planted path to every head) on 64 frames of changing content, through the path
+    `predict_keypoints` takes (`_calibrate` + `_certified_peaks`, audits on): all 64 x 13 argmax indices equal the full-frame fp32
+    path's, and the keypoints `predict_keypoints` returns are the table-variant fit of those peaks."""
+    from upliftingtabletennis_amd.interface import TableDetector
+    det = TableDetector('hrnet', max_batch=16)
+    det.AUDIT_EVERY = 16
+    clips = [synth.hard_clip(16, 720, 1280, seed=500 + c, sigma=sg, gain=gn)[0] for c, (sg, gn) in enumerate(((2.0, 1.0), (3.0, 1.3), (1.3, 0.7), (4.0, 1.6)))]
+    frames = np.concatenate(clips)
+    m = det.model
+    f32 = m._make(dtype='f32')
+    kp = det.predict_keypoints(list(frames))
+    assert kp.shape == (64, 13, 3) and m.certified
+    w, h = det.model_resolution
+    n_diff_raw = 0
+    raw = wasb.get_table_model('hrnet', resolution=(w, h), state_dict=m._state_dict, max_batch=16, dtype='bf16')
+    for b0 in range(0, 64, 16):
+        fr = torch.from_numpy(frames[b0:b0 + 16]).cuda()
+        idx, win = det._certified_peaks(fr)
+        x = wasb.preprocess_frames(fr, (w, h))
+        ref = torch.cat([wasb.WASBNet.forward(f32, x[t:t + 1], want_heatmap=False, want_peaks=True)[1] for t in range(16)])
+        assert torch.equal(idx, ref), b0
+        n_diff_raw += int((raw.forward_frames(fr)[1] != ref).sum())
+        pos = refine.refine_windows_device(idx, win, h, w, 1920, 1080, _lib.REFINE_TABLE).cpu().numpy().reshape(-1, 13, 3)
+        # (a second pass may resolve a heatmap on an fp32 crop that the first pass settled from its bf16 window -- the audits of the
+        # passes in between widen eps: same index, a window that differs in the last bf16 bits)
+        assert np.abs(pos - kp[b0:b0 + 16]).max() < 0.05
+    a = m.audit_state
+    print('\nhub table detector, 64 frames: 832 certified indices equal the fp32 path (the raw bf16 argmax differs on %d); eps %.4g, %d audited frames, %d widenings'
+          % (n_diff_raw, m.eps, a['audited_frames'], a['widened']))
+
+
 def test_table_detector_and_full_pipeline_surface():
     from upliftingtabletennis_amd.interface import TableDetector, TableTennisPipeline
     frames, track = synth.synth_frames(8, 720, 1280, seed=4)
