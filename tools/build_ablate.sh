@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../upliftingtabletennis_amd"
 mkdir -p _ablate
 for f in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -DTTUP_$f -c csrc/conv.hip -o _ablate/conv_$f.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _ablate/libttup_$f.so csrc/api.o _ablate/conv_$f.o csrc/conv_f32.o csrc/refine.o csrc/wasb_net.o csrc/certify.o csrc/uplift.o csrc/trajgen.o csrc/odefit.o csrc/calib.o csrc/peaks.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _ablate/libttup_$f.so csrc/api.o _ablate/conv_$f.o csrc/conv_f32.o csrc/conv_x3.o csrc/refine.o csrc/wasb_net.o csrc/certify.o csrc/uplift.o csrc/trajgen.o csrc/odefit.o csrc/calib.o csrc/peaks.o
   rm _ablate/conv_$f.o
 done
 ls -la _ablate
