@@ -395,6 +395,10 @@ class TableTennisPipeline:
         runs on chunk k on its own stream and the ball detector on the triples whose three frames are already resident on a
         third; the host blocks only at the end.  Same values as `predict_clip` / `predict_keypoints` (same kernels per frame)."""
         n, dev = len(images), self.device
+        import time as _time
+        tr = self.__dict__.get('_trace')          # tools/hub_trace.py: host time stamps (ms since the call) of the clip path's stages
+        t00 = _time.perf_counter()
+        mark = (lambda name: tr.append((name, (_time.perf_counter() - t00) * 1e3))) if tr is not None else (lambda name: None)
         C = self.CHUNK if n < 4 * self.CHUNK else self.CHUNK_LONG
         CP = self.CHUNK_LONG                       # rows of the pinned staging buffers
         h0, w0 = np.asarray(images[0]).shape[:2]
@@ -428,6 +432,7 @@ class TableTennisPipeline:
             if self._pin_free[ci % 2] is not None:
                 self._pin_free[ci % 2].synchronize()          # the copy that last read this staging buffer is done
             self._stage(images, c0, c1, pin)
+            mark('staged chunk %d' % ci)
             with torch.cuda.stream(st['copy']):
                 frames[c0:c1].copy_(pin[:c1 - c0], non_blocking=True)
                 ev = torch.cuda.Event(); ev.record()
@@ -461,6 +466,7 @@ class TableTennisPipeline:
                     ball_calls.append((t_next, nt, idx, win, status, info, bd.model.eps if bd.model.certified else None))
                 t_next += nt
         uploaded = [ev]
+        mark('all calls enqueued')
         frames.record_stream(st['ball']); frames.record_stream(st['table'])
         # eps audit of the certified argmax: a random triple of the clip on the fp32 twin, on its own stream next to the detectors
         audit = None
@@ -489,6 +495,7 @@ class TableTennisPipeline:
                     in_host = torch.empty(in_dev.shape, dtype=in_dev.dtype, pin_memory=True); in_host.copy_(in_dev, non_blocking=True)
                 ev_t = torch.cuda.Event(); ev_t.record()
             ev_t.synchronize()
+            mark('table stream drained')
             kp_np = kp_host.numpy()
             if cert:
                 o = 0
@@ -501,7 +508,9 @@ class TableTennisPipeline:
                     c = table_calls[k]
                     pos = refine.refine_windows_device(c['idx'].reshape(-1), c['win'].reshape(-1, 9), th, tw, td.resolution[0], td.resolution[1], _lib.REFINE_TABLE)
                     kp_np[c['f0']:c['f1']] = pos.cpu().numpy().reshape(-1, 13, 3)
+            mark('table calls settled')
             kp = table_consumer(kp_np) if table_consumer is not None else kp_np.copy()
+            mark('keypoint filter done')
         for s in st.values():
             cur.wait_stream(s)
         calls = [{'f0': t0, 'f1': t0 + nt + 2, 'idx': idx, 'win': win, 'status': status, 'info': info, 'eps': eps_used}
@@ -510,6 +519,7 @@ class TableTennisPipeline:
         for c in calls:
             ball_out.append(refine.refine_windows_device(c['idx'], c['win'], bh, bw, bd.resolution[0], bd.resolution[1], _lib.REFINE_TABLE))
         pos = torch.cat(ball_out).cpu().numpy() if ball_out else np.zeros((0, 3))
+        mark('ball calls settled, positions on the host')
         return pos, kp
 
     STAGE_THREADS = 4
