@@ -598,6 +598,122 @@ __global__ __launch_bounds__(128) void attention_kernel(AttnArgs a) {      // at
     }
 }
 
+// ------------------------------------------------------------------ attention on the fp32 matrix pipe, long sequences
+// The temporal / spin stages (sequences of T or T+1 tokens, head dim 32).  attention_kernel walks the keys with one thread per query
+// row -- 121 dependent exp / fma rounds: 60-70 us for a single rally, 15 % of the time at B = 10 000.  Here a wave owns 16 queries
+// of one (sequence, head): K (RoPE applied) and V of the whole sequence are staged in LDS once per workgroup (4 waves = 64 queries);
+// per 16-key tile  scores^T = K Q^T  (8 v_mfma_f32_16x16x4_f32: a lane ends with the scores of ONE query against four keys, so the
+// row maximum and the denominator are in-lane sums plus two cross-lane steps at the end) in a first pass for the maxima, and again in
+// a second pass for p = exp(s - max) and  out += P V  (8 more MFMAs, key index permuted so that p is already the A operand).  The
+// normalisation 1 / den goes through 16 floats of LDS (out rows are indexed by 4q + r, den by the lane's own query).
+struct AttnMArgs {
+    const float* qkv; float* out; const float* mask; const float2* rope;
+    int n_seq, S, num_cls, mask_div, times_div, times_stride;
+    float scale;
+};
+constexpr int ATTM_KS = 36;          // floats per K / V row in LDS (144 B: 16 consecutive rows fall on 16 different 16-byte slots)
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // K [SP][36] | V [SP][36] | inv [4 waves][16]
+    constexpr int HD = 32, D = 128, D3 = 384, KS = ATTM_KS;
+    const int S = a.S, KT = (S + 15) / 16, SP = KT * 16;
+    float* sk = sm;
+    float* sv = sm + SP * KS;
+    float* sinv = sv + SP * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, seq = blockIdx.z;
+    const float* base = a.qkv + (size_t)seq * S * D3 + h * HD;
+    const float2* rbase = a.rope + (size_t)(seq / a.times_div) * a.times_stride * (HD / 2);
+    const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
+    // ---- stage K (rotated) and V: 8 threads per row, one float4 each; rows past S are zero
+    for (int u = tid; u < SP * 8; u += 256) {
+        const int j = u >> 3, part = u & 7;
+        f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+        if (j < S) {
+            k = *(const f32x4*)(base + (size_t)j * D3 + D + part * 4);
+            v = *(const f32x4*)(base + (size_t)j * D3 + 2 * D + part * 4);
+            if (j >= a.num_cls) {
+                const f32x4 cs = *(const f32x4*)(rbase + (size_t)(j - a.num_cls) * (HD / 2) + part * 2);
+                k = f32x4{k[0] * cs[0] - k[1] * cs[1], k[0] * cs[1] + k[1] * cs[0], k[2] * cs[2] - k[3] * cs[3], k[2] * cs[3] + k[3] * cs[2]};
+            }
+        }
+        *(f32x4*)(sk + j * KS + part * 4) = k;
+        *(f32x4*)(sv + j * KS + part * 4) = v;
+    }
+    __syncthreads();
+    const int qt = blockIdx.x * 4 + wave;                   // this wave's tile of 16 queries
+    if (qt * 16 >= S) return;                                // (no barrier below: waves are independent from here on)
+    const int i = qt * 16 + c;                               // the lane's query
+    const bool row_ok = i < S && mrow[i < S ? i : 0] == 0.f;
+    // B operand of scores^T: Q[i][8q .. 8q+7], rotated
+    f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+    if (i < S) {
+        q0 = *(const f32x4*)(base + (size_t)i * D3 + 8 * q);
+        q1 = *(const f32x4*)(base + (size_t)i * D3 + 8 * q + 4);
+        if (i >= a.num_cls) {
+            const float2* rp = rbase + (size_t)(i - a.num_cls) * (HD / 2) + 4 * q;
+            const f32x4 c0 = *(const f32x4*)rp, c1 = *(const f32x4*)(rp + 2);
+            q0 = f32x4{q0[0] * c0[0] - q0[1] * c0[1], q0[0] * c0[1] + q0[1] * c0[0], q0[2] * c0[2] - q0[3] * c0[3], q0[2] * c0[3] + q0[3] * c0[2]};
+            q1 = f32x4{q1[0] * c1[0] - q1[1] * c1[1], q1[0] * c1[1] + q1[1] * c1[0], q1[2] * c1[2] - q1[3] * c1[3], q1[2] * c1[3] + q1[3] * c1[2]};
+        }
+    }
+    auto scores = [&](int kt) __attribute__((always_inline)) {
+        // A operand: K[kt*16 + c][8q .. 8q+7]; result sc[r] = q_i . k_j for j = kt*16 + 4q + r, masked keys -> -inf
+        const float* kp = sk + (kt * 16 + c) * KS + 8 * q;
+        const f32x4 k0 = *(const f32x4*)kp, k1 = *(const f32x4*)(kp + 4);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[e], q0[e], sc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[e], q1[e], sc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = kt * 16 + 4 * q + r;
+            const bool col_ok = j < S && mrow[j < S ? j : 0] == 0.f;
+            sc[r] = col_ok ? sc[r] * a.scale : -INFINITY;
+        }
+        return sc;
+    };
+    float mx = -INFINITY;
+    for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 sc = scores(kt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = sc[r] > mx ? sc[r] : mx;
+    }
+    { const float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; }
+    { const float o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 sc = scores(kt);
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? expf(sc[r] - mx) : 0.f; den += pr[r]; }
+        // out += P V with k index (step s, lane group q) <-> key kt*16 + 4q + s: the A operand of step s is the lane's own pr[s]
+        const float* vp = sv + (kt * 16 + 4 * q) * KS + c;
+#pragma unroll
+        for (int s2_ = 0; s2_ < 4; ++s2_) {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[s2_ * KS], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[s2_ * KS + 16], o1, 0, 0, 0);
+        }
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    // o[r] = out[query qt*16 + 4q + r][dim c (o0) / 16 + c (o1)]: the row's 1 / den comes from the lane that owns that query
+    if (q == 0) sinv[wave * 16 + c] = den > 0.f ? 1.f / den : 0.f;          // a fully masked query row yields zeros (torch SDPA semantics)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int io = qt * 16 + 4 * q + r;
+        if (io >= S) continue;
+        const float inv = sinv[wave * 16 + 4 * q + r];
+        float* op = a.out + ((size_t)seq * S + io) * D + h * HD;
+        op[c] = o0[r] * inv;
+        op[16 + c] = o1[r] * inv;
+    }
+}
+
 // ------------------------------------------------------------------ fused attention half of a layer, short sequences
 // att = softmax-attention(RoPE(q), RoPE(k), v) with qkv = LN(x) Wqkv^T + b, for sequences of S <= 16 tokens (the table stage: 14),
 // D = 128, 4 heads of 32: ONE kernel instead of the qkv linear + the attention launch, and the 1536 bytes of qkv per token never
@@ -1064,6 +1180,18 @@ int run_attention(ttup_uplift* net, const float* qkv, float* out, int n_seq, int
     a.n_seq = n_seq; a.S = S; a.D = net->D; a.heads = net->heads; a.hd = net->hd; a.num_cls = num_cls;
     a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
     a.scale = 1.0f / sqrtf((float)net->hd);
+    static const bool scalar_attn = getenv("TTUP_UPLIFT_SCALAR_ATTENTION") != nullptr || getenv("TTUP_F32_EXACT") != nullptr;
+    if (net->hd == 32 && net->D == 128 && S > 16 && S <= 512 && !scalar_attn) {
+        AttnMArgs m;
+        m.qkv = qkv; m.out = out; m.mask = mask; m.rope = rope; m.n_seq = n_seq; m.S = S; m.num_cls = num_cls;
+        m.mask_div = mask_div; m.times_div = times_div; m.times_stride = times_stride; m.scale = a.scale;
+        const int KT = (S + 15) / 16;
+        const size_t smem = ((size_t)2 * KT * 16 * ATTM_KS + 64) * sizeof(float);
+        if (int rc = ensure_max_lds((const void*)attention_mfma_kernel, 160 * 1024)) return rc;
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3((KT + 3) / 4, net->heads, n_seq), dim3(256), smem, st, m);
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
     TTUP_REQUIRE(((size_t)2 * S * net->hd + 16 + S) * sizeof(float) <= 64 * 1024, TTUP_EINVAL, "attention: sequence length %d too long", S);
     switch (net->hd) {
         case 8: launch_attention<8>(a, st); break;
