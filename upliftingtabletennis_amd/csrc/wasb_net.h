@@ -42,7 +42,7 @@ struct CertState {
     static constexpr float GUARD = 1.25f;   // a heatmap with an empty guard band stays certified when eps is widened by up to this factor
     int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
     int K = 256;                         // candidates kept per heatmap (<= CERT_MAX_K, csrc/certify.hip): the flat top of a saturated blob fits
-    int maxc = 4;                        // new crops a heatmap may add
+    int maxc = 8;                        // new crops a heatmap may add
     int maxf = 4;                        // crops per frame (the channels of a frame share them: min(16, maxc * channels))
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
