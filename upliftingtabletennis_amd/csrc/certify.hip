@@ -186,13 +186,22 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     }
 }
 
-__global__ void cert_active_kernel(const int* n_crops, int* n_active, int CH, int nchunks, int max_crops) {
+__global__ void cert_active_kernel(const int* n_crops, int* n_active, int CH, int nchunks, int max_crops, const int* crop_rec, int* roi_flag,
+                                   int H, int W, int Hc, int Wc) {
     const int c = threadIdx.x;
     if (c >= nchunks) return;
     int n = *n_crops;
     n = n > max_crops ? max_crops : n;
     int v = n - c * CH;
-    n_active[c] = v < 0 ? 0 : (v > CH ? CH : v);
+    v = v < 0 ? 0 : (v > CH ? CH : v);
+    n_active[c] = v;
+    // cone pruning applies to INTERIOR crops: a crop on an image border has a core that reaches that border (its zero padding IS the
+    // frame's), i.e. a wider cone: those are computed in full (one flag per crop; the kernels skip the tiles / pixels outside an op's
+    // region for the flagged samples only)
+    for (int j = 0; j < v; ++j) {
+        const int* rec = crop_rec + 4 * (c * CH + j);
+        roi_flag[c * CH + j] = (rec[1] <= 0 || rec[2] <= 0 || rec[1] + Hc >= H || rec[2] + Wc >= W) ? 0 : 1;
+    }
 }
 
 // crop windows of a caller-supplied fp32 NCHW input (the `forward(x)` entry): -> fp32 NHWC16
@@ -267,7 +276,7 @@ void cert_free(ttup_wasb* net) {
     CertState& c = net->cert;
     if (c.cropnet) { ttup_wasb_destroy(c.cropnet); c.cropnet = nullptr; }
     for (auto& sl : c.slot) {
-        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt, sl.margin};
+        void* ptrs[] = {sl.cand_idx, sl.cand_cnt, sl.cand_crop, sl.cand_val, sl.cand_win, sl.cand_bf, sl.crop_rec, sl.n_crops, sl.n_active, sl.status, sl.guard_cnt, sl.margin, sl.roi_flag};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.read_status) (void)hipEventDestroy(sl.read_status);
@@ -327,7 +336,8 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
     hipStream_t st = c.stream;
     TTUP_HIP_CHECK(hipEventRecord(c.lanes_done, caller));
     TTUP_HIP_CHECK(hipStreamWaitEvent(st, c.lanes_done, 0));
-    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, sl.n_crops, sl.n_active, c.CH, c.nchunks, c.budget);
+    hipLaunchKernelGGL(cert_active_kernel, dim3(1), dim3(64), 0, st, sl.n_crops, sl.n_active, c.CH, c.nchunks, c.budget, (const int*)sl.crop_rec, sl.roi_flag,
+                       net->H, net->W, c.Hc, c.Wc);
     TTUP_LAUNCH_CHECK();
     // fp32 passes that can hold crops of THIS call: at most maxc per heatmap, at most the caller's budget
     const int C = net->n_out;
@@ -348,9 +358,11 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
             TTUP_LAUNCH_CHECK();
         }
         cn->n_active = na;
+        cn->roi_flag = cn->op_roi.empty() ? nullptr : sl.roi_flag + crop0;
+        Roi hr = cn->out_roi; hr.flag = cn->roi_flag;
         int rc = run_ops(cn, c.CH, st);
-        if (rc == TTUP_OK) rc = launch_head(cn->tensors[cn->t_out].ptr, cn->head_w_dev, cn->head_b_dev, C, c.crop_heat, c.CH, c.Hc, c.Wc, 16, TTUP_DTYPE_F32, st, na);
-        cn->n_active = nullptr;
+        if (rc == TTUP_OK) rc = launch_head(cn->tensors[cn->t_out].ptr, cn->head_w_dev, cn->head_b_dev, C, c.crop_heat, c.CH, c.Hc, c.Wc, 16, TTUP_DTYPE_F32, st, na, &hr);
+        cn->n_active = nullptr; cn->roi_flag = nullptr;
         if (rc) return rc;
         const int nthr = batch * C * c.K;
         hipLaunchKernelGGL(cert_lookup_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.cand_crop,
@@ -415,6 +427,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.crop_rec, (size_t)c.max_crops * 4 * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_crops, sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.n_active, (size_t)c.nchunks * sizeof(int)));
+        TTUP_HIP_CHECK(hipMalloc((void**)&sl.roi_flag, (size_t)c.max_crops * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.status, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.margin, nb * sizeof(float)));
         TTUP_HIP_CHECK(hipMemset(sl.margin, 0x7f, nb * sizeof(float)));
@@ -430,6 +443,13 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * net->n_out * c.Hc * c.Wc * sizeof(float)));
     const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
     if (rc) { cert_free(net); return rc; }
+    // cone pruning of the crop net: an interior crop's candidates lie R + 1 pixels inside it, their 3x3 windows one more: only the
+    // heatmap rows / columns [R, side - R) are ever read (lookup kernel), and every layer only has to produce what those depend on
+    static const bool no_cone = getenv("TTUP_NO_CONE") != nullptr || getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_F32_DIRECT") != nullptr;
+    if (!no_cone && c.Hc == c.Wc && c.Hc > 2 * c.R + 2 && c.Hc < net->H && c.Wc < net->W) {
+        const int rc2 = compute_roi(c.cropnet, c.R, c.Hc - c.R);
+        if (rc2) { cert_free(net); return rc2; }
+    }
     c.enabled = true;
     return TTUP_OK;
 }

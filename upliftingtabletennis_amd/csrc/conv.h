@@ -25,6 +25,11 @@ struct PackedConv {
     size_t w_bytes = 0;
 };
 
+// Part of a tensor that an op has to produce: rows [y0, y1), columns [x0, x1) of sample b, applied only where flag[b] != 0 (device
+// memory, one int per sample of the pass).  The fp32 crop net of the certified argmax is pruned to the cone of its 24-pixel core (csrc/wasb_net.hip compute_roi): a
+// kernel may compute any superset of the region -- what lies outside is never read by an op that matters.  flag == nullptr: no pruning.
+struct Roi { int y0 = 0, y1 = 0, x0 = 0, x1 = 0; const int* flag = nullptr; };
+
 struct ConvLaunch {
     const void* src0 = nullptr;   // NHWC, c0 channels
     const void* src1 = nullptr;   // NHWC, cin_total-c0 channels (two-source 1x1 only) or null
@@ -37,6 +42,7 @@ struct ConvLaunch {
     const void* res2 = nullptr;           // bf16 stride-2 convs: further fuse-layer terms added before the ReLU (same resolution /
     const void* res3 = nullptr; int sh3 = 0;   // 1/2^sh3 resolution, nearest-neighbour upsampled), wasb.py:236-243
     const int* n_active = nullptr;        // f32 only: device-side batch (<= batch) decided by an earlier kernel (csrc/certify.hip)
+    Roi roi;                              // f32 split-bf16 kernels only: output region to produce (cone pruning of the crop net)
     // bf16 64 -> 64 3x3 only: linear 1x1 followers (fuse-layer convs 64 -> 16 / 64 -> 32, no ReLU) applied to dst
     const PackedConv* lin16 = nullptr; void* lin16_dst = nullptr;
     const PackedConv* lin32 = nullptr; void* lin32_dst = nullptr;
@@ -83,7 +89,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
 
 // y = relu(base + sum_k nearest_upsample(t_k, 2^shift_k)); all NHWC with c channels; base at (h,w).
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
-                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active = nullptr);
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active = nullptr, const Roi* roi = nullptr);
 
 // float32 NCHW (B,cin,H,W) -> NHWC with cpad channels (zero filled)
 int launch_nchw_to_nhwc(const float* src, void* dst, int batch, int cin, int cpad, int h, int w, int dtype, hipStream_t stream);
@@ -92,7 +98,7 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, in
 
 // head: 1x1 conv cin -> n_out output channels (+bias), float32 (B,n_out,H,W) out; w_dev [n_out][cin], bias_dev [n_out]
 int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin,
-                int dtype, hipStream_t stream, const int* n_active = nullptr);
+                int dtype, hipStream_t stream, const int* n_active = nullptr, const Roi* roi = nullptr);
 
 // uint8 frames -> normalised triples: see ttup_preprocess_triples.  out NCHW f32 or NHWC16 (dtype of the net)
 int launch_preprocess(const uint8_t* frames, int n_frames, int src_h, int src_w, int dst_h, int dst_w,

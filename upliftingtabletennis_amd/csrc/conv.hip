@@ -2152,17 +2152,21 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-struct UpsumArgs { const void* base; const void* t[3]; int shift[3]; int n; void* dst; int H, W, C; long long total; const int* n_active; long long per_sample; };
+struct UpsumArgs { const void* base; const void* t[3]; int shift[3]; int n; void* dst; int H, W, C; long long total; const int* n_active; long long per_sample; Roi roi; int batch; };
 
 template <typename T>
 __global__ void upsum_kernel(UpsumArgs a) {
-    const long long total = a.n_active ? (a.per_sample * *a.n_active < a.total ? a.per_sample * *a.n_active : a.total) : a.total;
+    // every sample's whole tensor is walked; samples whose pruning flag is set produce only the op's cone region
+    int nb = a.batch;
+    if (a.n_active) nb = *a.n_active < nb ? *a.n_active : nb;
+    const long long total = (long long)nb * a.H * a.W * a.C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % a.C);
         long long p = i / a.C;
         const int x = (int)(p % a.W); p /= a.W;
         const int y = (int)(p % a.H);
         const int b = (int)(p / a.H);
+        if (a.roi.flag && a.roi.flag[b] != 0 && (y < a.roi.y0 || y >= a.roi.y1 || x < a.roi.x0 || x >= a.roi.x1)) continue;
         float v = ld((const T*)a.base + i);
         for (int k = 0; k < a.n; ++k) {
             const int sh = a.shift[k], hh = a.H >> sh, ww = a.W >> sh;
@@ -2203,9 +2207,11 @@ __global__ __launch_bounds__(256) void upsum_bf16x8_kernel(UpsumArgs a) {
 }
 
 int launch_upsum(const void* base, const void* const* terms, const int* shifts, int n_terms, void* dst,
-                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active) {
+                 int batch, int h, int w, int c, int dtype, hipStream_t stream, const int* n_active, const Roi* roi) {
     UpsumArgs a;
-    a.base = base; a.n = n_terms; a.dst = dst; a.H = h; a.W = w; a.C = c;
+    a.base = base; a.n = n_terms; a.dst = dst; a.H = h; a.W = w; a.C = c; a.batch = batch;
+    if (roi) a.roi = *roi;
+    TTUP_REQUIRE(!a.roi.flag || dtype == TTUP_DTYPE_F32, TTUP_EINVAL, "upsum: output regions are an fp32-path feature");
     for (int k = 0; k < 3; ++k) { a.t[k] = k < n_terms ? terms[k] : nullptr; a.shift[k] = k < n_terms ? shifts[k] : 0; }
     a.total = (long long)batch * h * w * c;
     a.n_active = n_active; a.per_sample = (long long)h * w * c;
@@ -2262,9 +2268,16 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int batch, int c, int h, in
 
 // head: 1x1 conv 16 -> n_out selected output channels (+bias), fp32 NCHW (B, n_out, H, W) out
 template <typename T, int CIN>
-__global__ void head_kernel(const T* src, const float* w, const float* bias, int n_out, float* heat, long long hw, long long npix_max, const int* n_active) {
-    const long long npix = n_active ? (hw * *n_active < npix_max ? hw * *n_active : npix_max) : npix_max;
+__global__ void head_kernel(const T* src, const float* w, const float* bias, int n_out, float* heat, long long hw, long long npix_max, const int* n_active, Roi roi, int W) {
+    long long nb = npix_max / hw;
+    if (n_active) nb = *n_active < nb ? *n_active : nb;
+    const long long npix = nb * hw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        if (roi.flag) {
+            const long long bq = i / hw, rem = i - bq * hw;
+            const int y = (int)(rem / W), xq = (int)(rem % W);
+            if (roi.flag[bq] != 0 && (y < roi.y0 || y >= roi.y1 || xq < roi.x0 || xq >= roi.x1)) continue;
+        }
         float x[CIN];
 #pragma unroll
         for (int c = 0; c < CIN; ++c) x[c] = ld(src + i * CIN + c);
@@ -2279,14 +2292,15 @@ __global__ void head_kernel(const T* src, const float* w, const float* bias, int
 }
 
 int launch_head(const void* src, const float* w_dev, const float* bias_dev, int n_out, float* heat, int batch, int h, int w, int cin, int dtype,
-                hipStream_t stream, const int* n_active) {
+                hipStream_t stream, const int* n_active, const Roi* roi) {
+    const Roi r = roi ? *roi : Roi();
     TTUP_REQUIRE(cin == 16, TTUP_EINVAL, "head expects 16 input channels, got %d", cin);
     const long long hw = (long long)h * w, npix = (long long)batch * hw;
     if (npix == 0) return TTUP_OK;
     long long blocks = (npix + 255) / 256;
     if (n_active && blocks > 8192) blocks = 8192;
-    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active);
-    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active);
+    if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL((head_kernel<float, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active, r, w);
+    else hipLaunchKernelGGL((head_kernel<bf16_t, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)src, w_dev, bias_dev, n_out, heat, hw, npix, n_active, r, w);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }

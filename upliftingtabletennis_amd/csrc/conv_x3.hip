@@ -32,13 +32,21 @@ struct ConvX3Args {
     int c0, c1, nchunk0, nchunk, cout;
     int H, W, OH, OW, tiles_x, tiles_per_img, relu, batch;
     const int* n_active;
+    // cone pruning (conv.h Roi): of a sample b with roi_flag[b] != 0 only the tiles [r_ty0, r_ty0 + r_nty) x [r_tx0, r_tx0 + r_ntx) are produced
+    const int* roi_flag; int r_ty0, r_tx0, r_nty, r_ntx;
 };
 
-// The operand split is fp32 vector arithmetic (v - hi parts) that the compiler would turn into packed fp32 instructions with neg
-// modifiers -- the forms measured to return wrong values beside another kernel's LDS-fed MFMAs (csrc/common.h), and the crop
-// passes run beside the bf16 CNN: built without packed fp32 (tests/test_cabi.py scans the ISA).
-TTUP_NO_PACKED_FP32_BEGIN
+// The operand split is fp32 vector arithmetic (v - hi parts) that the compiler turns into `v_pk_add_f32 ... neg_lo neg_hi` -- packed
+// fp32 with operand modifiers, the forms measured to return wrong values beside another kernel's LDS-fed MFMAs (csrc/common.h), and
+// the crop passes run beside the bf16 CNN.  The subtractions are therefore issued as plain v_sub_f32 through inline asm (x3_sub);
+// the rest of the unit keeps packed fp32 (element-wise forms without modifiers, measured safe: building the whole unit without
+// packed fp32 cost 22 % of a crop pass).  tests/test_cabi.py scans the library's ISA for swizzled packed forms.
 namespace {
+__device__ __forceinline__ float x3_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // two fp32 -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned x3_pack2(float a, float b) {
@@ -57,9 +65,9 @@ __device__ __forceinline__ void x3_split8(const f32x4& lo, const f32x4& hi, u32x
     for (int i = 0; i < 4; ++i) {
         const float a = v[2 * i], b = v[2 * i + 1];
         const unsigned q0 = x3_pack2(a, b);
-        const float ra = a - __uint_as_float(q0 << 16), rb = b - __uint_as_float(q0 & 0xffff0000u);
+        const float ra = x3_sub(a, __uint_as_float(q0 << 16)), rb = x3_sub(b, __uint_as_float(q0 & 0xffff0000u));
         const unsigned q1 = x3_pack2(ra, rb);
-        const float sa = ra - __uint_as_float(q1 << 16), sb = rb - __uint_as_float(q1 & 0xffff0000u);
+        const float sa = x3_sub(ra, __uint_as_float(q1 << 16)), sb = x3_sub(rb, __uint_as_float(q1 & 0xffff0000u));
         p0[i] = q0; p1[i] = q1; p2[i] = x3_pack2(sa, sb);
     }
 }
@@ -90,16 +98,32 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
     const bf16_t* wblk = a.wpack + (size_t)blockIdx.y * nchunk * 3 * W_ELEMS;
     int batch = a.batch;
     if (a.n_active) { const int na = *a.n_active; batch = na < batch ? na : batch; }
-    const int total_tiles = a.tiles_per_img * batch;
+    const int tiles_x = a.tiles_x, tiles_per_img = a.tiles_per_img;
+    constexpr int ty_off = 0, tx_off = 0;
+    const int total_tiles = tiles_per_img * batch;
     const int my_tiles = total_tiles > (int)blockIdx.x ? (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int n_items = my_tiles * nchunk;
+    // a tile of a pruned sample outside the op's region is skipped (wave-uniform: scalar loads of the sample's flag)
+    auto skipped = [&](int item) {
+        if (!a.roi_flag) return false;
+        const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
+        const int b = tl / tiles_per_img, t = tl % tiles_per_img;
+        if (a.roi_flag[b] == 0) return false;
+        const int ty = t / tiles_x, tx = t % tiles_x;
+        return ty < a.r_ty0 || ty >= a.r_ty0 + a.r_nty || tx < a.r_tx0 || tx >= a.r_tx0 + a.r_ntx;
+    };
+    auto next_item = [&](int item) {          // first item >= `item` that is not skipped (all chunks of a tile share the decision)
+        while (item < n_items && item % nchunk == 0 && skipped(item)) item += nchunk;
+        return item;
+    };
 
     f32x4 pin[IN_PT][2];
     u32x4 pw[W_PT];
+    bool w_loaded = false, w_stored = false;          // single-chunk convs: the weights are staged with the first item the workgroup runs
     auto issue = [&](int item) {
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
-        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
-        const int gy0 = (t / a.tiles_x) * TH * S - PAD, gx0 = (t % a.tiles_x) * TW * S - PAD;
+        const int b = tl / tiles_per_img, t = tl % tiles_per_img;
+        const int gy0 = (ty_off + t / tiles_x) * TH * S - PAD, gx0 = (tx_off + t % tiles_x) * TW * S - PAD;
         const bool first = chunk < a.nchunk0;
         const float* src = first ? a.src0 : a.src1;
         const int csrc = first ? a.c0 : a.c1;
@@ -116,10 +140,11 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             pin[k][0] = ok ? lo : z; pin[k][1] = ok ? hi : z;
         }
-        if (nchunk > 1 || item == 0) {
+        if (nchunk > 1 || !w_loaded) {
             const u32x4* wsrc = (const u32x4*)(wblk + (size_t)chunk * 3 * W_ELEMS);
 #pragma unroll
             for (int k = 0; k < W_PT; ++k) { const int u = tid + k * NTHR; pw[k] = wsrc[u < W_UNITS ? u : 0]; }
+            w_loaded = true;
         }
     };
     auto commit = [&](int item) {
@@ -134,9 +159,10 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
                 *(u32x4*)d = p0; *(u32x4*)(d + IN_ELEMS) = p1; *(u32x4*)(d + 2 * IN_ELEMS) = p2;
             }
         }
-        if (nchunk > 1 || item == 0) {
+        if (nchunk > 1 || !w_stored) {
 #pragma unroll
             for (int k = 0; k < W_PT; ++k) { const int u = tid + k * NTHR; if (u < W_UNITS) ((u32x4*)s_w)[u] = pw[k]; }
+            w_stored = true;
         }
     };
 
@@ -159,13 +185,17 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
     }
 
     f32x4 acc[MT][NT];
-    if (n_items > 0) issue(0);
-    for (int item = 0; item < n_items; ++item) {
+    int item = next_item(0);
+    if (item < n_items) issue(item);
+    bool first = true;
+    for (; item < n_items;) {
+        const int nxt = next_item(item + 1);
         const int chunk = item % nchunk;
-        if (item > 0) __syncthreads();          // every wave finished reading the previous item's LDS image
+        if (!first) __syncthreads();            // every wave finished reading the previous item's LDS image
+        first = false;
         commit(item);
         __syncthreads();
-        if (item + 1 < n_items) issue(item + 1);
+        if (nxt < n_items) issue(nxt);
         if (chunk == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -198,11 +228,11 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[q]][m], bfr[PB[q]][t], acc[m][t], 0, 0, 0);
         }
-        if (chunk != nchunk - 1) continue;
+        if (chunk != nchunk - 1) { item = nxt; continue; }
         // ---- epilogue: lane holds couts co_base + [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
-        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-        const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+        const int b = tl / tiles_per_img, tt = tl % tiles_per_img;
+        const int oy0 = (ty_off + tt / tiles_x) * TH, ox0 = (tx_off + tt % tiles_x) * TW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int nt = wave * NT + t;
@@ -220,6 +250,7 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
                 *(f32x4*)(a.dst + o + m * 4) = v;
             }
         }
+        item = nxt;
     }
 }
 
@@ -236,6 +267,13 @@ int launch_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     a.H = l.h; a.W = l.w; a.OH = (l.h + S - 1) / S; a.OW = (l.w + S - 1) / S;
     a.tiles_x = cdiv(a.OW, TW); a.tiles_per_img = a.tiles_x * cdiv(a.OH, TH);
     a.relu = l.relu; a.batch = l.batch; a.n_active = l.n_active;
+    a.roi_flag = l.roi.flag; a.r_ty0 = a.r_tx0 = 0; a.r_nty = cdiv(a.OH, TH); a.r_ntx = a.tiles_x;
+    if (l.roi.flag) {
+        TTUP_REQUIRE(l.roi.y0 >= 0 && l.roi.x0 >= 0 && l.roi.y1 > l.roi.y0 && l.roi.x1 > l.roi.x0 && l.roi.y1 <= a.OH && l.roi.x1 <= a.OW, TTUP_EINVAL,
+                     "conv x3: output region [%d,%d)x[%d,%d) outside %dx%d", l.roi.y0, l.roi.y1, l.roi.x0, l.roi.x1, a.OH, a.OW);
+        a.r_ty0 = l.roi.y0 / TH; a.r_nty = cdiv(l.roi.y1, TH) - a.r_ty0;
+        a.r_tx0 = l.roi.x0 / TW; a.r_ntx = cdiv(l.roi.x1, TW) - a.r_tx0;
+    }
     TTUP_REQUIRE(p.cout % (MT * 16) == 0 && p.mt3 == MT, TTUP_EINVAL, "conv x3: cout %d packed in blocks of %d, launched with %d", p.cout, p.mt3 * 16, MT * 16);
     const int blocks = p.cout / (MT * 16);
     const long long total = (long long)a.tiles_per_img * l.batch;
@@ -252,7 +290,6 @@ int launch_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
 }
 
 }  // namespace
-TTUP_NO_PACKED_FP32_END
 
 // couts per block (MT * 16) of a conv of this shape: as many as the LDS budget of its tile allows
 int conv_x3_block_mt(int cout, int k, int stride, int ck) {

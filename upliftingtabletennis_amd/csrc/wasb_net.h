@@ -55,6 +55,7 @@ struct CertState {
         float* cand_bf = nullptr;           // the bf16 path's value of every candidate (audit: |bf16 - fp32| at the candidates is free)
         int* guard_cnt = nullptr;           // pixels per heatmap in the guard band below the candidate band
         int* crop_rec = nullptr; int* n_crops = nullptr; int* n_active = nullptr; int* status = nullptr;
+        int* roi_flag = nullptr;            // per crop: 1 = interior crop (the pruned op regions of the crop net apply to it)
         float* margin = nullptr;            // fp32 top-2 margin among the candidates of a resolved heatmap (+inf: one candidate / not resolved)
         hipEvent_t done = nullptr;          // fp32 passes of the call that last used the slot have finished
         // the caller's copies of this slot's status / crop count (ttup_wasb_certify_status / _flags / _info, on whatever stream the
@@ -88,6 +89,10 @@ struct ttup_wasb {
     int last_batch = 0;
     bool fused_head = false;      // last op computes the heatmap and the argmax partials itself (bf16 path)
     const int* n_active = nullptr;      // fp32 crop net of the certified argmax: device-side batch of the current pass
+    // ... and its cone pruning: op_roi[k] = the region of op k's output that the crop's core depends on (compute_roi), out_roi = the
+    // region of the heatmap itself; applied to the samples b with roi_flag[b] != 0 (interior crops; a crop that touches an image border has a core
+    // that reaches that border and is computed in full).  Empty op_roi = no pruning (every other handle).
+    std::vector<ttup::Roi> op_roi; ttup::Roi out_roi; const int* roi_flag = nullptr;
     std::vector<char> blob;             // the weight blob the handle was created from (the certified argmax builds its fp32 twin from it)
     ttup::CertState cert;
     // Lanes: independent micro-batches alternate between `lanes.size()` internal streams, each with its own activation
@@ -116,6 +121,8 @@ struct ttup_wasb {
 
 namespace ttup {
 int run_ops(ttup_wasb* net, int mb, hipStream_t st);
+// regions of every op's output that the heatmap rows / columns [lo, hi) depend on (fp32 layer-by-layer graphs only)
+int compute_roi(ttup_wasb* net, int lo, int hi);
 // certified argmax (csrc/certify.hip)
 void cert_free(ttup_wasb* net);
 int cert_begin(ttup_wasb* net, int batch, hipStream_t caller);                                   // reset per-call state

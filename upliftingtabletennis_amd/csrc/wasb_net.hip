@@ -410,6 +410,7 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             l.src0 = s.ptr; l.src1 = op.src1 >= 0 ? net->tensors[op.src1].ptr : nullptr;
             l.residual = op.residual >= 0 ? net->tensors[op.residual].ptr : nullptr;
             l.dst = net->tensors[op.dst].ptr; l.batch = mb; l.h = s.h; l.w = s.w; l.relu = op.relu; l.n_active = net->n_active;
+            if (!net->op_roi.empty() && net->roi_flag) { l.roi = net->op_roi[&op - net->ops.data()]; l.roi.flag = net->roi_flag; }
             if (op.conv2 >= 0) { l.follow = &net->convs[op.conv2]; l.dst2 = net->tensors[op.dst2].ptr; }
             if (op.lin16 >= 0) { l.lin16 = &net->convs[op.lin16]; l.lin16_dst = net->tensors[op.lin16_dst].ptr; }
             if (op.lin32 >= 0) { l.lin32 = &net->convs[op.lin32]; l.lin32_dst = net->tensors[op.lin32_dst].ptr; }
@@ -452,7 +453,9 @@ int run_op(ttup_wasb* net, const Op& op, int mb, hipStream_t st) {
             const Tensor& d = net->tensors[op.dst];
             const void* terms[3] = {nullptr, nullptr, nullptr};
             for (int k = 0; k < op.n_terms; ++k) terms[k] = net->tensors[op.terms[k]].ptr;
-            const int rc = launch_upsum(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, d.ptr, mb, d.h, d.w, d.c, net->dtype, st, net->n_active);
+            Roi roi;
+            if (!net->op_roi.empty() && net->roi_flag) { roi = net->op_roi[&op - net->ops.data()]; roi.flag = net->roi_flag; }
+            const int rc = launch_upsum(net->tensors[op.src0].ptr, terms, op.shifts, op.n_terms, d.ptr, mb, d.h, d.w, d.c, net->dtype, st, net->n_active, &roi);
             if (rc) return rc;
         }
     }
@@ -575,6 +578,62 @@ int forward_impl(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, 
 
 namespace ttup {
 int run_ops(ttup_wasb* net, int mb, hipStream_t st) { return run_graph(net, mb, st); }
+
+// Cone pruning of a layer-by-layer fp32 graph: walk the ops backwards from the heatmap region [lo, hi) x [lo, hi) and record, for
+// every tensor, the union of what its consumers read.  A 3x3 conv reads one pixel around its outputs (times the stride), a fuse sum
+// reads the same pixels of its base and pixel >> shift of every upsampled term.  The recorded regions are SUPERSETS by construction
+// (kernels round them out to whole tiles): every value an op reads inside its own region has been produced.
+int compute_roi(ttup_wasb* net, int lo, int hi) {
+    TTUP_REQUIRE(net && net->dtype == TTUP_DTYPE_F32 && net->t_out >= 0, TTUP_EINVAL, "compute_roi: an fp32 handle is expected");
+    const size_t nt = net->tensors.size();
+    struct R { int y0, y1, x0, x1; bool any; };
+    std::vector<R> need(nt, R{0, 0, 0, 0, false});
+    auto add = [&](int t, int y0, int y1, int x0, int x1) {
+        const Tensor& tn = net->tensors[t];
+        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > tn.h ? tn.h : y1; x1 = x1 > tn.w ? tn.w : x1;
+        if (y1 <= y0 || x1 <= x0) return;
+        R& r = need[t];
+        if (!r.any) r = R{y0, y1, x0, x1, true};
+        else { r.y0 = y0 < r.y0 ? y0 : r.y0; r.y1 = y1 > r.y1 ? y1 : r.y1; r.x0 = x0 < r.x0 ? x0 : r.x0; r.x1 = x1 > r.x1 ? x1 : r.x1; }
+    };
+    add(net->t_out, lo, hi, lo, hi);
+    net->op_roi.assign(net->ops.size(), Roi());
+    for (int k = (int)net->ops.size() - 1; k >= 0; --k) {
+        const Op& op = net->ops[k];
+        TTUP_REQUIRE(op.kind == Op::CONV || op.kind == Op::UPSUM, TTUP_EINVAL, "compute_roi: fused op in an fp32 graph");
+        TTUP_REQUIRE(op.conv2 < 0 && op.lin16 < 0 && op.lin32 < 0 && op.pair < 0 && op.res2 < 0 && op.res3 < 0, TTUP_EINVAL, "compute_roi: fused epilogue in an fp32 graph");
+        const R d = need[op.dst];
+        Roi& o = net->op_roi[k];
+        if (!d.any) { o.y0 = 0; o.y1 = 1; o.x0 = 0; o.x1 = 1; continue; }          // nothing in the cone reads this op: one pixel
+        o.y0 = d.y0; o.y1 = d.y1; o.x0 = d.x0; o.x1 = d.x1;
+        if (op.kind == Op::CONV) {
+            const PackedConv& p = net->convs[op.conv];
+            const int s_ = p.stride, pad = p.k / 2;
+            add(op.src0, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
+            if (op.src1 >= 0) add(op.src1, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
+            if (op.residual >= 0) add(op.residual, d.y0, d.y1, d.x0, d.x1);
+        } else {
+            add(op.src0, d.y0, d.y1, d.x0, d.x1);
+            for (int j = 0; j < op.n_terms; ++j) { const int sh = op.shifts[j]; add(op.terms[j], d.y0 >> sh, ((d.y1 - 1) >> sh) + 1, d.x0 >> sh, ((d.x1 - 1) >> sh) + 1); }
+        }
+    }
+    if (getenv("TTUP_DEBUG_ROI")) {
+        double full = 0, kept = 0;
+        for (size_t k = 0; k < net->ops.size(); ++k) {
+            const Op& op = net->ops[k];
+            const Tensor& d = net->tensors[op.dst];
+            const Roi& o = net->op_roi[k];
+            double w = (double)d.h * d.w;
+            if (op.kind == Op::CONV) { const PackedConv& p = net->convs[op.conv]; w *= (double)p.cout * p.cin_total * p.k * p.k; } else w *= d.c;
+            full += w; kept += w * ((double)(o.y1 - o.y0) * (o.x1 - o.x0)) / ((double)d.h * d.w);
+            fprintf(stderr, "roi op %2zu %s dst %3dx%3dx%3d -> [%d,%d)x[%d,%d)\n", k, op.kind == Op::CONV ? "conv " : "upsum", d.h, d.w, d.c, o.y0, o.y1, o.x0, o.x1);
+        }
+        fprintf(stderr, "roi: %.1f %% of the graph's multiply-adds kept\n", 100.0 * kept / full);
+    }
+    net->out_roi = Roi();
+    net->out_roi.y0 = lo; net->out_roi.y1 = hi; net->out_roi.x0 = lo; net->out_roi.x1 = hi;
+    return TTUP_OK;
+}
 }
 
 // micro_override / lanes_override > 0 fix the micro-batch and the lane count (the certified argmax's fp32 crop net runs its
