@@ -205,3 +205,36 @@ def test_hard_fixture_premises_and_oracle(golden):
     assert np.array_equal(heat[g[key + '/top_idx'][t]], g[key + '/top_val'][t])
     print('hard fixture: %d triples, margins min %.1e median %.1e; %d below 0.09, %d below 1e-3; oracle == reference on %s t%d (margin %.1e)'
           % (margins.size, margins.min(), np.median(margins), (margins < 0.09).sum(), (margins < 1e-3).sum(), key, t, m0))
+
+
+def test_hard_table_fixture_premises_and_oracle(golden):
+    """tests/golden/table_hard.npz: the reference MyHRNet (13 keypoint heatmaps) at 704x1280 on near-tie content -- 8 frames, 104
+    heatmaps, every reference top-2 margin below 0.09.  The clips regenerate bit for bit; the CPU oracle reproduces the reference on
+    the frame that holds the smallest margin: same 13 argmax indices, same top-8 values."""
+    from e2e_common import hard_frames
+    from oracle import glue_ref
+    g = golden('table_hard.npz')
+    margins, best = [], None
+    for ci in range(int(g['n_clips'][0])):
+        key = 'clip%d' % ci
+        tv = g[key + '/top_val']
+        assert np.array_equal(g[key + '/top_idx'][..., 0], g[key + '/argmax']) and (np.diff(tv, axis=-1) <= 0).all()
+        m = tv[..., 0] - tv[..., 1]
+        margins += m.reshape(-1).tolist()
+        t = int(np.unravel_index(m.argmin(), m.shape)[0])
+        if best is None or m.min() < best[0]:
+            best = (float(m.min()), key, t)
+    margins = np.array(margins)
+    assert margins.size == 104 and (margins < 0.09).all() and (margins < 1e-3).sum() >= 10
+    m0, key, t = best
+    wseed, cseed, nf, h, w = [int(v) for v in g[key + '/meta']]
+    weps, sigma, gain = [float(v) for v in g[key + '/params']]
+    frames = hard_frames(g, key, cseed, sigma, gain, nf, h, w)
+    x = glue_ref.normalize_image(frames[t]).transpose(2, 0, 1).astype(np.float32)[None]
+    sd = weights.random_wasb_state_dict(wseed, planted=True, in_ch=3, head_out=13, eps=weps, plant_all_heads=True)
+    with torch.no_grad():
+        heat = wasb_ref.hrnet_forward(torch.from_numpy(np.ascontiguousarray(x)), sd)[0].numpy()[0].reshape(13, -1)
+    assert np.array_equal(heat.argmax(1), g[key + '/argmax'][t])
+    for c in range(13):
+        assert np.array_equal(heat[c][g[key + '/top_idx'][t, c]], g[key + '/top_val'][t, c])
+    print('hard table fixture: 104 heatmaps, margins min %.1e median %.1e; oracle == reference on %s frame %d' % (margins.min(), np.median(margins), key, t))

@@ -388,6 +388,58 @@ def gen_hard():
           % (n_tr, (time.time() - t0) / n_tr, m.min(), np.median(m), m.max(), (m < 0.09).sum(), (m < 1e-3).sum()))
 
 
+HARD_TABLE = (81, 0.2, [(2100, 3.5, 1.5), (2101, 4.0, 1.3)])          # table weights seed / noise, clips (seed, sigma, gain); 4 frames each
+
+
+def gen_hard_table():
+    """The near-tie fixture for the TABLE detector (13 keypoint heatmaps per frame): the reference `MyHRNet`
+    (tabledetection/models/hrnet.py:510-589) at 704x1280, batch 1 per frame like interface.py:160-165, on the hard content of
+    gen_hard with seeded weights that carry a planted path to every head (flat-topped maps on all 13 channels).  Per (frame, channel):
+    argmax, the 8 largest values with their indices, the zero-padded 3x3 window and a 16x16 crop around the argmax."""
+    from upliftingtabletennis_amd import weights, synth
+    from oracle import glue_ref
+    h, w = 704, 1280
+    wseed, weps, clips = HARD_TABLE
+    sd = weights.random_wasb_state_dict(wseed, planted=True, in_ch=3, head_out=13, eps=weps, plant_all_heads=True)
+    model = ref_table_hrnet(sd, (w, h))
+    out, t0, margins = {}, time.time(), []
+    nf = 4
+    for ci, (cseed, sigma, gain) in enumerate(clips):
+        frames, _ = synth.hard_clip(nf, h, w, seed=cseed, sigma=sigma, gain=gain)
+        key = 'clip%d' % ci
+        rec = dict(argmax=np.zeros((nf, 13), np.int64), top_idx=np.zeros((nf, 13, 8), np.int64), top_val=np.zeros((nf, 13, 8), np.float32),
+                   win=np.zeros((nf, 13, 9), np.float32), crop16=np.zeros((nf, 13, 16, 16), np.float32), crop16_origin=np.zeros((nf, 13, 2), np.int64))
+        for t in range(nf):
+            # frames are generated AT the network resolution (the resize is the identity); normalisation as interface.py:160-165
+            # (oracle/glue_ref.normalize_image is pinned equal to the reference's NormalizeImage by glue.npz)
+            x = glue_ref.normalize_image(frames[t]).transpose(2, 0, 1).astype(np.float32)[None]
+            with torch.no_grad():
+                heat = model(torch.from_numpy(np.ascontiguousarray(x)))
+            hm = heat.numpy()[0]
+            for c in range(13):
+                flat = hm[c].reshape(-1)
+                order = np.argsort(-flat, kind='stable')[:8]
+                idx = int(order[0])
+                assert idx == int(torch.argmax(heat[0, c].reshape(-1)))
+                rec['argmax'][t, c] = idx
+                rec['top_idx'][t, c], rec['top_val'][t, c] = order, flat[order]
+                y, xq = idx // w, idx % w
+                rec['win'][t, c] = np.pad(hm[c], 1)[y:y + 3, xq:xq + 3].reshape(-1)
+                y0, x0 = int(np.clip(y - 8, 0, h - 16)), int(np.clip(xq - 8, 0, w - 16))
+                rec['crop16'][t, c], rec['crop16_origin'][t, c] = hm[c, y0:y0 + 16, x0:x0 + 16], (y0, x0)
+                margins.append(float(flat[order[0]] - flat[order[1]]))
+            print('hard table %s t%d: margins %s  [%.0f s]' % (key, t, ' '.join('%.1e' % m for m in margins[-13:]), time.time() - t0), flush=True)
+        for k, v in rec.items():
+            out['%s/%s' % (key, k)] = v
+        out[key + '/meta'] = np.array([wseed, cseed, nf, h, w], np.int64)
+        out[key + '/params'] = np.array([weps, sigma, gain], np.float64)
+        out[key + '/frames_sha256'] = np.array(hashlib.sha256(frames.tobytes()).hexdigest())
+    out['n_clips'] = np.array([len(clips)])
+    np.savez_compressed(os.path.join(OUT, 'table_hard.npz'), **out)
+    m = np.array(margins)
+    print('hard table: %d heatmaps; reference top-2 margins: min %.2e median %.2e max %.2e; %d below 0.09' % (m.size, m.min(), np.median(m), m.max(), (m < 0.09).sum()))
+
+
 def install_mujoco_standin(history):
     """`mujoco` is not importable here.  The reference's generator only needs containers (MjModel/MjData), the
     fixed camera pose and `mj_step`.  This stand-in provides the containers and REPLAYS states that oracle/trajgen_ref.py
@@ -680,6 +732,6 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib', 'e2e', 'hard']
+    which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib', 'e2e', 'hard', 'hard_table']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'e2e': gen_e2e, 'hard': gen_hard}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'e2e': gen_e2e, 'hard': gen_hard, 'hard_table': gen_hard_table}[w_]()
