@@ -97,6 +97,15 @@ def test_argument_validation_without_gpu(lib):
     n = ctypes.c_int(0)
     assert lib.ttup_wasb_streams(None, None, 0, ctypes.byref(n)) == _lib.EINVAL
     assert lib.ttup_max_abs_diff(None, None, 4, None, None) == _lib.EINVAL
+    # round-4 entry points: null handles / pointers are refused before anything touches a device
+    assert lib.ttup_max_abs_diff_cols(None, None, 2, 8, 0, 8, None, 0, None) == _lib.EINVAL
+    assert lib.ttup_slice_columns(None, 2, 8, 0, 4, None, None) == _lib.EINVAL
+    for fn in (lib.ttup_wasb_certify_status, lib.ttup_wasb_certify_flags, lib.ttup_wasb_certify_margins):
+        assert fn(None, 1, None, None) == _lib.EINVAL
+    out3 = (ctypes.c_int * 3)()
+    assert lib.ttup_uplift_graph_info(None, out3) == _lib.EINVAL
+    assert lib.ttup_wasb_set_certify(None, 0.1, 0, 0) == _lib.EINVAL
+    assert len(lib.ttup_build_id()) == 16 and lib.ttup_version() == 101
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     assert lib.ttup_refine_workspace_bytes(4, 704, 1280) >= 4 * 44
