@@ -17,6 +17,7 @@
 // The k order per output pixel (chunk, k-step, the MFMA's own order) does not depend on the tile or on the image size: a pixel
 // computed on a crop equals the pixel computed on the whole frame bit for bit (what the certified argmax relies on).
 #include "conv.h"
+#include <stdlib.h>
 #include <vector>
 
 namespace ttup {
@@ -307,6 +308,16 @@ bool conv_x3_supported(const PackedConv& p) {
 int launch_conv_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     const int mt = p.mt3;
 #define X3_CASE(CK, MT, KS, S, TH, TW, NW) if (p.ck == CK && mt == MT) return launch_x3<CK, MT, KS, S, TH, TW, NW>(p, l, st)
+    // pruned launches (the crop net): 16-pixel-wide tiles follow an op's region more closely than 8x32 ones (certification per varied
+    // step 18.2 -> 16.7 ms on one box with the first four; TTUP_X3_WIDE=1 keeps the 32-wide tiles)
+    static const bool wide = getenv("TTUP_X3_WIDE") != nullptr;
+    if (!wide && l.roi.flag && p.k == 3 && p.stride == 1) {
+        X3_CASE(32, 1, 3, 1, 16, 16, 8); X3_CASE(32, 2, 3, 1, 16, 16, 8); X3_CASE(32, 4, 3, 1, 8, 16, 8);
+        X3_CASE(16, 1, 3, 1, 16, 16, 8); X3_CASE(16, 2, 3, 1, 16, 16, 8); X3_CASE(16, 4, 3, 1, 16, 16, 8);
+    }
+    if (!wide && l.roi.flag && p.k == 1 && p.stride == 1) {
+        X3_CASE(32, 1, 1, 1, 16, 16, 8); X3_CASE(32, 2, 1, 1, 16, 16, 8); X3_CASE(32, 4, 1, 1, 16, 16, 8);
+    }
     if (p.k == 3 && p.stride == 1) {
         X3_CASE(32, 1, 3, 1, 8, 32, 8); X3_CASE(32, 2, 3, 1, 8, 32, 8); X3_CASE(32, 4, 3, 1, 4, 32, 8);
         X3_CASE(16, 1, 3, 1, 8, 32, 8); X3_CASE(16, 2, 3, 1, 8, 32, 8); X3_CASE(16, 4, 3, 1, 8, 32, 8);
