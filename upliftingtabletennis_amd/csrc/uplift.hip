@@ -735,9 +735,10 @@ struct AttnBlockArgs {
     int S, num_cls, mask_div, times_div, times_stride;
     float scale;
 };
-constexpr int ATTN_QS = 388;          // floats per row of the qkv tile: 4 heads x 96 + 4 (1552 B: consecutive rows fall on consecutive 16-byte slots)
+constexpr int ATTN_QS = 196;          // floats per row of the qkv tile: 2 heads x 96 + 4 (784 B = 49 slots of 16 B: consecutive rows fall on consecutive slots)
 __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64][128] split planes of LN(x); then float qh[64][ATTN_QS]
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64][128] split planes of LN(x); then float qh[64][ATTN_QS], two heads at a time
+    // (50 KB: two workgroups per CU; with all four heads in LDS -- 99 KB, one workgroup per CU -- the kernel was latency-bound)
     constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = ATTN_QS;
     float* qh = (float*)xh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -797,15 +798,14 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
             for (int p = 0; p < 3; ++p) xb[p][sK] = *(const bf16x8*)(xw + p * PLANE + (((4 * sK + q) ^ c) << 3));
     }
     __syncthreads();              // every wave holds its fragments: the plane storage becomes the qkv tile
-    {
-        const int grow = mt * 16 + c;                        // the lane's token row in the tile
-        const int gsl = grow / S, gjt = grow - gsl * S;
-        const long long gseq = seq0 + gsl;
-        const bool rot = grow < ROWS && gseq < a.n_seq && gjt >= a.num_cls;
-        const float2* rrow = a.rope + ((size_t)((rot ? gseq : 0) / a.times_div) * a.times_stride + (rot ? gjt - a.num_cls : 0)) * (HD / 2);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int h = 2 * hp + hh;
+    const int grow = mt * 16 + c;                            // the lane's token row in the tile
+    const int gsl = grow / S, gjt = grow - gsl * S;
+    const long long gseq = seq0 + gsl;
+    const bool rot = grow < ROWS && gseq < a.n_seq && gjt >= a.num_cls;
+    const float2* rrow = a.rope + ((size_t)((rot ? gseq : 0) / a.times_div) * a.times_stride + (rot ? gjt - a.num_cls : 0)) * (HD / 2);
+    for (int rd = 0; rd < 2; ++rd) {                         // two heads per round: wave (m-tile w & 3, head 2 rd + (w >> 2))
+        {
+            const int h = 2 * rd + hp;
 #pragma unroll
             for (int jp = 0; jp < 3; ++jp) {                 // n-tile pairs: q, k, v of the head
                 const int nt0 = jp * 8 + 2 * h;
@@ -831,18 +831,17 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
                         const f32x4 cs = *(const f32x4*)(rrow + e * 8 + 2 * q);          // (cos, sin) of the two pairs
                         v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[0] * cs[1] + v[1] * cs[0], v[2] * cs[2] - v[3] * cs[3], v[2] * cs[3] + v[3] * cs[2]};
                     }
-                    *(f32x4*)(qh + grow * QS + h * 96 + jp * 32 + e * 16 + 4 * q) = v;
+                    *(f32x4*)(qh + grow * QS + hp * 96 + jp * 32 + e * 16 + 4 * q) = v;
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- 3. attention: task = (sequence sl, head h); lane (c, q)
-    for (int task = wave; task < SEQS * 4; task += 8) {
-        const int sl = task >> 2, h = task & 3;
+        __syncthreads();
+        // ---- 3. attention: task = (sequence sl, head of the round); lane (c, q)
+        for (int task = wave; task < SEQS * 2; task += 8) {
+        const int sl = task >> 1, h = 2 * rd + (task & 1);
         const long long seq = seq0 + sl;
         if (seq >= a.n_seq) continue;                        // wave-uniform
-        const float* base = qh + (sl * S) * QS + h * 96;
+        const float* base = qh + (sl * S) * QS + (task & 1) * 96;
         const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
         // scores^T = K Q^T: A = K (row j = c, dims 8q .. 8q+7), B = Q (column i = c, the same dims); rows past the tile's last
         // sequence belong to nobody and are masked below
@@ -889,6 +888,8 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
                 if (i < S) a.att[(m0 + sl * S + i) * K + h * HD + dt * 16 + c] = o[r];
             }
         }
+        }
+        __syncthreads();              // the round's q | k | v are consumed: the next round overwrites them
     }
 }
 
@@ -1233,7 +1234,10 @@ int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int 
         a.att = net->att; a.x = x; a.M = tokens;
         a.w_proj = L.proj.w3_dev; a.w_fc1 = L.fc1.w3_dev; a.w_fc2 = L.fc2.w3_dev;
         a.g2 = L.g2; a.b2 = L.b2; a.bias1 = L.fc1.b_dev; a.bias2 = L.fc2.b_dev;
-        const bool big = tokens >= 128 * 512;
+        // 64-token tiles (80 KB of LDS: two workgroups per CU) also for large token counts: 2 % faster at B = 10 000 than the 128-token
+        // tile (160 KB, one workgroup per CU) although every tile then streams the weights again; TTUP_UPLIFT_MLP_BM128=1 selects the latter
+        static const bool bm128 = getenv("TTUP_UPLIFT_MLP_BM128") != nullptr;
+        const bool big = tokens >= 128 * 512 && bm128;
         const int bm = big ? 128 : 64;
         const size_t smem = (size_t)3 * bm * 128 * sizeof(uint16_t) + (size_t)bm * 128 * sizeof(float);
         const dim3 grid((unsigned)((tokens + bm - 1) / bm));
