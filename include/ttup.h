@@ -221,6 +221,11 @@ int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* ta
  * [2] = forwards served by a replay so far. */
 int ttup_uplift_graph_info(ttup_uplift* net, int* out_host3);
 
+/* Sequences of at most 64 tokens (the table stage always; the temporal and spin stages of clips of up to 63 frames) run ALL layers
+ * of a stage in one launch with the tokens resident in LDS, while the launch stays small (at most 256 workgroups; TTUP_UPLIFT_STAGE_WG
+ * overrides, TTUP_UPLIFT_NO_STAGE=1 switches it off).  *out_host = such launches issued or captured so far. */
+int ttup_uplift_stage_info(ttup_uplift* net, long long* out_host);
+
 /* ---------------------------------------------------------------- a7: spin frame change
  * Replaces transform_rotationaxes (uplifting/helper.py:394-420): rot (B,3), pos (B,T,3) -> out (B,3). */
 int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream);

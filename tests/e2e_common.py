@@ -59,3 +59,11 @@ def hard_frames(g, key, cseed, sigma, gain, nf, h, w):
     frames, _ = synth.hard_clip(nf, h, w, seed=cseed, sigma=sigma, gain=gain)
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g[key + '/frames_sha256']), 'regenerated frames differ from the fixture\'s (%s)' % key
     return frames
+
+
+def ragged_trajectories(b, t, pad):
+    """synth.synth_trajectories(b, t, pad) with every second trajectory cut to half its length (ragged masks within a batch)."""
+    from upliftingtabletennis_amd import synth
+    ball, table, mask, times = synth.synth_trajectories(b, t, seed=100 + t, pad=pad)
+    mask[1::2, max(2, t // 2):] = 0.0
+    return ball, table, mask, times

@@ -51,7 +51,10 @@ def test_library_carries_the_hash_of_this_trees_sources(lib, tmp_path, monkeypat
 def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):
     """csrc/common.h: v_pk_*_f32 instructions that carry op_sel / op_sel_hi / neg modifiers were measured to return wrong values on
     gfx950 beside another kernel's LDS-fed MFMAs (tools/pk_coresidency_repro.hip).  The shipped library must contain none: every
-    gfx950 code object of libttup.so is disassembled and scanned (the plain element-wise forms are fine and stay)."""
+    gfx950 code object of libttup.so is disassembled and scanned (the plain element-wise forms are fine and stay).
+    The same scan refuses out-of-line CALLS in the device code (s_swappc_b64): a unit compiled with no-packed-fp32-ops cannot inline
+    a HIP header function that lacks the attribute, which in round 3 left 1852 calls (__uint_as_float, __shfl_xor, __syncthreads ...)
+    inside the uplift kernels' hot loops unnoticed (csrc/no_packed_fp32_begin.h)."""
     import struct
     objcopy, objdump = '/opt/rocm/lib/llvm/bin/llvm-objcopy', '/opt/rocm/lib/llvm/bin/llvm-objdump'
     if not (os.path.exists(objcopy) and os.path.exists(objdump)):
@@ -60,7 +63,7 @@ def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):
     subprocess.run([objcopy, '--dump-section', '.hip_fatbin=%s' % fat, _lib.LIB_PATH, str(tmp_path / 'stripped.so')], check=True)
     data = fat.read_bytes()
     magic = b'__CLANG_OFFLOAD_BUNDLE__'
-    n_objects, n_packed, bad = 0, 0, []
+    n_objects, n_packed, bad, calls = 0, 0, [], 0
     start = data.find(magic)
     while start >= 0:
         (n_entries,) = struct.unpack_from('<Q', data, start + len(magic))
@@ -76,6 +79,7 @@ def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):
             n_objects += 1
             asm = subprocess.run([objdump, '-d', '--no-show-raw-insn', str(co)], check=True, capture_output=True, text=True).stdout
             for line in asm.splitlines():
+                calls += 's_swappc_b64' in line
                 if re.search(r'v_pk_[a-z]+_f32', line):
                     n_packed += 1
                     if re.search(r'op_sel|neg_lo|neg_hi', line):
@@ -84,6 +88,7 @@ def test_no_swizzled_packed_fp32_in_the_device_code(tmp_path):
     assert n_objects >= 8, 'expected one gfx950 code object per translation unit, found %d' % n_objects
     assert n_packed > 0, 'the scan found no packed fp32 instruction at all: is the disassembly empty?'
     assert not bad, '%d swizzled packed fp32 instructions, e.g. %s' % (len(bad), bad[:3])
+    assert calls == 0, '%d function calls in the device code: a helper was not inlined (target-feature mismatch?)' % calls
 
 
 def test_argument_validation_without_gpu(lib):
@@ -104,6 +109,7 @@ def test_argument_validation_without_gpu(lib):
         assert fn(None, 1, None, None) == _lib.EINVAL
     out3 = (ctypes.c_int * 3)()
     assert lib.ttup_uplift_graph_info(None, out3) == _lib.EINVAL
+    assert lib.ttup_uplift_stage_info(None, None) == _lib.EINVAL
     assert lib.ttup_wasb_set_certify(None, 0.1, 0, 0) == _lib.EINVAL
     assert len(lib.ttup_build_id()) == 16 and lib.ttup_version() == 101
     with pytest.raises(ValueError):

@@ -244,6 +244,47 @@ def test_uplift_mask_errors_and_batching():
     assert torch.allclose(rot2, rot[3:7], rtol=1e-5, atol=1e-6) and torch.allclose(pos2, pos[3:7], rtol=1e-5, atol=1e-6)
 
 
+def test_uplift_stage_kernel_against_the_per_layer_kernels():
+    """Sequences of at most 64 tokens run all layers of a stage in one launch (stage_x3_kernel: tokens resident in LDS).  Same
+    arithmetic as the per-layer kernels apart from where the softmax is normalised, so: within 2e-6 relative of the per-layer path
+    (TTUP_UPLIFT_NO_STAGE=1, child process) and within the 1e-4 bar of the oracle, on lengths around the tile boundaries (15/16/17
+    query tiles, 63 -> a 64-token spin sequence, 64 -> the spin stage falls back), ragged masks, several sequences per launch."""
+    import subprocess, sys, tempfile
+    from e2e_common import ragged_trajectories
+    sd_seed = 11
+    shapes = [(1, 7, 1), (3, 13, 2), (2, 15, 1), (5, 13, 4), (1, 45, 3), (4, 43, 7), (2, 54, 9), (2, 59, 5)]          # lengths 8, 15, 16, 17, 48, 50, 63, 64
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from upliftingtabletennis_amd import uplift, weights; from e2e_common import ragged_trajectories;'
+            'sd = weights.random_uplift_state_dict(%d, "large"); net = uplift.get_model("connectstage", "large", "dynamic", "new", state_dict=sd, max_batch=8, max_len=64);'
+            'out = {};\n'
+            'for (b, t, pad) in %r:\n'
+            '    a = [torch.from_numpy(v) for v in ragged_trajectories(b, t, pad)]\n'
+            '    rot, pos = net(*a); rot2, pos2 = net(*a)\n'
+            '    assert torch.equal(rot, rot2) and torch.equal(pos, pos2)\n'
+            '    out["rot_%%d_%%d" %% (b, t)] = rot.cpu().numpy(); out["pos_%%d_%%d" %% (b, t)] = pos.cpu().numpy()\n'
+            'out["stage"] = np.array([net.graph_info()["stage_launches"]]); np.savez(sys.argv[1], **out)' % (root, os.path.join(root, 'tests'), sd_seed, shapes))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (('stage', {}), ('layers', {'TTUP_UPLIFT_NO_STAGE': '1'})):
+            e = dict(os.environ); e.update(env)
+            out = os.path.join(td, tag + '.npz')
+            subprocess.run([sys.executable, '-c', code, out], check=True, env=e, timeout=600)
+            res[tag] = dict(np.load(out))
+    assert int(res['stage']['stage'][0]) > 0 and int(res['layers']['stage'][0]) == 0
+    sd = weights.random_uplift_state_dict(sd_seed, 'large')
+    worst = 0.0
+    for (b, t, pad) in shapes:
+        a = [torch.from_numpy(v) for v in ragged_trajectories(b, t, pad)]
+        o_rot, o_pos = uplift_ref.uplift_forward(*a, sd)
+        for k, o in (('rot', o_rot.numpy()), ('pos', o_pos.numpy())):
+            x, y = res['stage']['%s_%d_%d' % (k, b, t)], res['layers']['%s_%d_%d' % (k, b, t)]
+            assert np.isfinite(x).all()
+            worst = max(worst, float(np.abs(x - y).max() / np.abs(o).max()))
+            assert np.abs(x - o).max() <= 1e-4 * np.abs(o).max(), (b, t, k)
+    print('\nstage kernel vs per-layer kernels: worst relative difference %.3g' % worst)
+    assert worst <= 2e-6
+
+
 # ------------------------------------------------------------------------------------------ boundary classes
 def test_interface_surface():
     from upliftingtabletennis_amd.interface import BallDetector, UpliftingModel

@@ -53,6 +53,7 @@ SIGNATURES = {
     'ttup_uplift_create': (_i, [_vp, _sz, _i, _i, _c.POINTER(_vp)]),
     'ttup_uplift_destroy': (None, [_vp]),
     'ttup_uplift_graph_info': (_i, [_vp, _vp]),
+    'ttup_uplift_stage_info': (_i, [_vp, _vp]),
     'ttup_uplift_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'ttup_transform_rotationaxes': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     'ttup_trajgen_max_samples': (_i, []),

@@ -481,28 +481,28 @@ extern "C" int ttup_certify_scan(const float* heat_dev, const int64_t* argmax_de
 // the CNN: no packed fp32 here, common.h).  NaN anywhere gives NaN (its bit pattern orders above +inf).  The 2-D form compares the
 // columns [c0, c1) of `rows` rows of `width` floats (a strip audit leaves out the columns whose receptive field reaches the strip's
 // artificial zero padding) and can keep a running maximum in `out`.
-TTUP_NO_PACKED_FP32_BEGIN
+TTUP_NO_PACKED_FP32_BEGIN          // (bracketed kernels call builtins only: a HIP header function would stay an out-of-line call, no_packed_fp32_begin.h)
 namespace ttup { namespace {
 __global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long rows, int width, int c0, int ncol,
                                                            unsigned* __restrict__ out) {
     float m = 0.f;
     bool nan = false;
     const long long n = rows * ncol;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)ttup_bid_x() * 256 + ttup_tid_x(); i < n; i += (long long)ttup_gsize_x()) {
         const long long e = ncol == width ? i : (i / ncol) * width + c0 + i % ncol;
         const float d = fabsf(a[e] - b[e]);
         nan |= d != d;
         m = d > m ? d : m;
     }
-    unsigned bits = nan ? 0x7fc00000u : __float_as_uint(m);            // non-negative floats order like their bit patterns
+    unsigned bits = nan ? 0x7fc00000u : __builtin_bit_cast(unsigned, m);            // non-negative floats order like their bit patterns
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const unsigned o = __shfl_xor(bits, 32 >> k, 64); bits = o > bits ? o : bits; }
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
+    for (int k = 0; k < 6; ++k) { const unsigned o = (unsigned)__builtin_amdgcn_ds_bpermute(((ttup_tid_x() & 63) ^ (32 >> k)) << 2, (int)bits); bits = o > bits ? o : bits; }
+    if ((ttup_tid_x() & 63) == 0 && bits) __hip_atomic_fetch_max(out, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // dst[r][j] = src[r][x0 + j]: a column strip of (rows, width) floats (the audit's strip of the pre-processed input)
 __global__ __launch_bounds__(256) void slice_columns_kernel(const float* __restrict__ src, long long rows, int width, int x0, int w, float* __restrict__ dst) {
     const long long n = rows * w;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[(i / w) * width + x0 + i % w];
+    for (long long i = (long long)ttup_bid_x() * 256 + ttup_tid_x(); i < n; i += (long long)ttup_gsize_x()) dst[i] = src[(i / w) * width + x0 + i % w];
 }
 } }
 TTUP_NO_PACKED_FP32_END

@@ -37,7 +37,9 @@ void set_error(const char* fmt, ...);   // thread-local, returned by ttup_last_e
 // 20-line rotation kernel are wrong beside a 20-line ds_read -> MFMA loop, none with the same source compiled without packed fp32;
 // the plain element-wise forms (all that the convolution epilogues contain) are not affected.  Translation units whose fp32
 // vector code the compiler turns into swizzled packed forms (the uplift transformer's RoPE / softmax arithmetic, the refine fit)
-// bracket their device code with these two; tests/test_cabi.py checks the device ISA of the whole library for such instructions.
+// include no_packed_fp32_begin.h before anything else and no_packed_fp32_end.h last (whole unit), or bracket a few self-contained
+// kernels with the two macros below -- those must not call HIP header functions (a callee without the attribute is not inlined:
+// no_packed_fp32_begin.h); tests/test_cabi.py checks the device ISA of the whole library for swizzled packed fp32 and for calls.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TTUP_NO_PACKED_FP32_BEGIN _Pragma("clang attribute push(__attribute__((target(\"no-packed-fp32-ops\"))), apply_to = function)")
 #define TTUP_NO_PACKED_FP32_END _Pragma("clang attribute pop")
@@ -45,6 +47,20 @@ void set_error(const char* fmt, ...);   // thread-local, returned by ttup_last_e
 #define TTUP_NO_PACKED_FP32_BEGIN
 #define TTUP_NO_PACKED_FP32_END
 #endif
+
+// threadIdx.x & co. as builtins: the HIP accessors go through __ockl_get_local_id / __ockl_get_group_id of the device library,
+// which a unit compiled with no-packed-fp32-ops cannot inline (no_packed_fp32_begin.h)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TTUP_DEV_BUILTIN(x) (int)(x)
+#else
+#define TTUP_DEV_BUILTIN(x) 0          // (host pass: the bodies are parsed, never run)
+#endif
+__device__ __forceinline__ int ttup_tid_x() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_workitem_id_x()); }
+__device__ __forceinline__ int ttup_bid_x() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_workgroup_id_x()); }
+__device__ __forceinline__ int ttup_bid_y() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_workgroup_id_y()); }
+__device__ __forceinline__ int ttup_bid_z() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_workgroup_id_z()); }
+__device__ __forceinline__ int ttup_bdim_x() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_workgroup_size_x()); }
+__device__ __forceinline__ int ttup_gsize_x() { return TTUP_DEV_BUILTIN(__builtin_amdgcn_grid_size_x()); }          // gridDim.x * blockDim.x
 
 typedef uint16_t bf16_t;   // raw bits
 

@@ -8,9 +8,9 @@
 // Kernel 2 (argmax_finish): one wave per map reduces the partials (ties -> smaller index, NaN wins like
 //   torch.argmax), gathers the zero-padded window and stores index + window.
 // Kernel 3 (fit): one lane per map runs the L-BFGS-B fit of lbfgsb.h in fp64 and rescales to image pixels.
+#include "no_packed_fp32_begin.h"      // this unit's kernels run beside the CNN's chain kernels: no packed fp32 (common.h)
 #include "common.h"
 
-TTUP_NO_PACKED_FP32_BEGIN      // the fit runs beside the CNN of the next micro-batch (common.h)
 
 #include "lbfgsb.h"
 
@@ -37,7 +37,7 @@ __device__ __forceinline__ Best wave_best(Best b) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ heat, long long hw, int nblk,
                                                              float* __restrict__ pv, long long* __restrict__ pi) {
-    const int map = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int map = ttup_bid_y(), blk = ttup_bid_x(), tid = ttup_tid_x();
     const float* h = heat + (size_t)map * hw;
     // slice boundaries in units of 4 floats so that vector loads stay aligned
     const long long quads = (hw + 3) / 4;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 __global__ __launch_bounds__(64) void argmax_finish_kernel(const float* __restrict__ heat, int H, int W, int nblk,
                                                            const float* __restrict__ pv, const long long* __restrict__ pi,
                                                            long long* __restrict__ argmax, float* __restrict__ win) {
-    const int map = blockIdx.x, lane = threadIdx.x;
+    const int map = ttup_bid_x(), lane = ttup_tid_x();
     Best b; b.v = -INFINITY; b.i = 0x7fffffffffffffffLL;
     for (int k = lane; k < nblk; k += 64) {
         const float v = pv[(size_t)map * nblk + k];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void argmax_finish_kernel(const float* __restri
 
 __global__ void fit_kernel(const long long* __restrict__ argmax, const float* __restrict__ win, int n_maps, int H, int W,
                            double scale_x, double scale_y, int variant, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= n_maps) return;
     float w[9];
     for (int k = 0; k < 9; ++k) w[k] = win[(size_t)i * 9 + k];
@@ -141,7 +141,7 @@ __device__ __forceinline__ void add8(float* v, const bf16_t* p) {
 }
 
 __global__ __launch_bounds__(256) void upsum_head_kernel(UpsumHeadArgs a) {
-    const int map = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int map = ttup_bid_y(), blk = ttup_bid_x(), tid = ttup_tid_x();
     const long long hw = (long long)a.H * a.W;
     const long long e = (long long)blk * 256 + tid;
     Best b; b.v = -INFINITY; b.i = 0x7fffffffffffffffLL;
@@ -274,4 +274,4 @@ extern "C" int ttup_refine(const float* heat_dev, int n_maps, int height, int wi
     return ttup_refine_windows((const int64_t*)am, wn, n_maps, height, width, img_w, img_h, variant, out_xyv_dev, stream);
 }
 
-TTUP_NO_PACKED_FP32_END
+#include "no_packed_fp32_end.h"

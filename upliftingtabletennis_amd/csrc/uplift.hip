@@ -14,18 +14,19 @@
 //   attention_kernel  per (sequence, head): RoPE(q,k) on load from a per-forward (cos,sin) table, additive {0,-inf}
 //                   row+column mask, online softmax in registers; a fully masked query row yields zeros (torch SDPA
 //                   semantics).  Short sequences (the 14-token table stage) share a wave four at a time.
+#include "no_packed_fp32_begin.h"      // this unit's kernels run beside the CNN's chain kernels: no packed fp32 (common.h)
 #include "common.h"
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
 #include <map>
+#include <type_traits>
 #include <memory>
 #include <utility>
 #include <vector>
 
 using namespace ttup;
 
-TTUP_NO_PACKED_FP32_BEGIN      // this unit's kernels run beside the CNN's chain kernels (common.h)
 
 namespace {
 
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(256 * MH) void linear_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];      // [4][64*MH][K/4 + 4]
     constexpr int BM = 64 * MH;
     const int K = a.K, KQ = K / 4, RS = KQ + 4, PLANE = BM * RS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * NTW);
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const int m0 = ttup_bid_x() * BM, n0 = ttup_bid_y() * (64 * NTW);
     // ---- stage the token rows (LayerNorm applied on the way in): 16 lanes per row, float4 per lane per 64 features
     {
         const int grp = tid >> 4, l16 = tid & 15;
@@ -193,8 +194,8 @@ template <bool LN, int NTW, int MH>
 __global__ __launch_bounds__(256 * MH) void linear_x3_kernel(LinArgs a, const uint16_t* __restrict__ w3) {
     extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64*MH][128]
     constexpr int BM = 64 * MH, K = 128, PLANE = BM * K;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * (64 * NTW);
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const int m0 = ttup_bid_x() * BM, n0 = ttup_bid_y() * (64 * NTW);
     // ---- stage the token rows (LayerNorm applied on the way in): 16 lanes per row, two float4 per lane (8 consecutive features)
     {
         const int grp = tid >> 4, l16 = tid & 15;
@@ -324,8 +325,8 @@ __global__ __launch_bounds__(256 * MH) void mlp_block_x3_kernel(MlpArgs a) {
     // (512-byte rows alias on the banks: the swizzle spreads the 8 rows of a ds_write_b128 lane group over 8 chunks; 80 KB per
     // 64-token workgroup = two per CU, 160 KB per 128-token workgroup)
     auto s2p = [&](int r, int n) __attribute__((always_inline)) { return s2 + r * K + ((((n >> 2) ^ (r & 15))) << 2); };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
-    const long long m0 = (long long)blockIdx.x * BM;
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6, wn = wave & 3, wm = wave >> 2;
+    const long long m0 = (long long)ttup_bid_x() * BM;
     const int q = lane >> 4, c = lane & 15;
     const int grp = tid >> 4, l16 = tid & 15;
     auto split_store = [&](int r, int chunk, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256 * MH) void mlp_block_x3_kernel(MlpArgs a) {
 
 // out[m][n] = relu?(sum_k x[m][k] w[n][k] + b[n]) for tiny K (2 or 3): embedding fc1
 __global__ void small_linear_kernel(const float* x, int ldx, const float* w, const float* b, float* out, int ldo, long long M, int N, int K, int relu) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= M * N) return;
     const long long m = i / N; const int n = (int)(i % N);
     float acc = 0.f;
@@ -494,7 +495,7 @@ __global__ void small_linear_kernel(const float* x, int ldx, const float* w, con
 // ------------------------------------------------------------------ attention
 // rope[r][i] = (cos, sin)(round(t_r / 0.002) * inv_freq[i]) for every time stamp r           (model.py:62-80)
 __global__ void rope_table_kernel(const float* times, const float* inv_freq, float2* rope, int half, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= total) return;
     const float pos = rintf(times[i / half] / 0.002f);          // round(t / (1/MAX_FPS)), model.py:72
     const float f = pos * inv_freq[i % half];
@@ -510,20 +511,20 @@ struct AttnArgs {
     float scale;
 };
 
-// P threads per (sequence, head); a workgroup of blockDim.x threads serves blockDim.x / P sequences.  K (rotated) and V
+// P threads per (sequence, head); a workgroup of ttup_bdim_x() threads serves ttup_bdim_x() / P sequences.  K (rotated) and V
 // of each sequence live in LDS, thread i0 owns query rows i0, i0+P, ...
 template <int HD, int P>
 __global__ __launch_bounds__(128) void attention_kernel(AttnArgs a) {      // at most 128 threads are ever launched: 256 VGPRs, no spills
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int S = a.S, G = blockDim.x / P;
+    const int S = a.S, G = ttup_bdim_x() / P;
     const int SEQ = 2 * S * HD + 16;                 // floats per sequence; the +16 words spreads the groups over LDS banks
     float* ms = sm + G * SEQ;                        // [G][S] additive mask
-    const int h = blockIdx.y, tid = threadIdx.x;
+    const int h = ttup_bid_y(), tid = ttup_tid_x();
     const int D3 = 3 * a.D, HV = HD / 4;
     // ---- stage K (RoPE applied) and V, one float4 per thread per step, 128 B rows read by HV consecutive threads
-    for (int u = tid; u < G * S * HV; u += blockDim.x) {
+    for (int u = tid; u < G * S * HV; u += ttup_bdim_x()) {
         const int g = u / (S * HV), rem = u - g * (S * HV), j = rem / HV, part = rem - j * HV;
-        const int seq = blockIdx.x * G + g;
+        const int seq = ttup_bid_x() * G + g;
         if (seq >= a.n_seq) continue;
         const float* kp = a.qkv + ((size_t)seq * S + j) * D3 + a.D + h * HD + part * 4;
         f32x4 k = *(const f32x4*)kp;
@@ -535,13 +536,13 @@ __global__ __launch_bounds__(128) void attention_kernel(AttnArgs a) {      // at
         *(f32x4*)(sm + g * SEQ + j * HD + part * 4) = k;
         *(f32x4*)(sm + g * SEQ + S * HD + j * HD + part * 4) = v;
     }
-    for (int u = tid; u < G * S; u += blockDim.x) {
-        const int seq = blockIdx.x * G + u / S;
+    for (int u = tid; u < G * S; u += ttup_bdim_x()) {
+        const int seq = ttup_bid_x() * G + u / S;
         ms[u] = seq < a.n_seq ? a.mask[(size_t)(seq / a.mask_div) * S + (u % S)] : -INFINITY;
     }
     __syncthreads();
     const int g = tid / P, i0 = tid - g * P;
-    const int seq = blockIdx.x * G + g;
+    const int seq = ttup_bid_x() * G + g;
     if (seq >= a.n_seq) return;
     const float* ks = sm + g * SEQ;
     const float* vs = ks + S * HD;
@@ -619,9 +620,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnMArgs a) {
     float* sk = sm;
     float* sv = sm + SP * KS;
     float* sinv = sv + SP * KS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, seq = blockIdx.z;
+    const int h = ttup_bid_y(), seq = ttup_bid_z();
     const float* base = a.qkv + (size_t)seq * S * D3 + h * HD;
     const float2* rbase = a.rope + (size_t)(seq / a.times_div) * a.times_stride * (HD / 2);
     const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnMArgs a) {
         *(f32x4*)(sv + j * KS + part * 4) = v;
     }
     __syncthreads();
-    const int qt = blockIdx.x * 4 + wave;                   // this wave's tile of 16 queries
+    const int qt = ttup_bid_x() * 4 + wave;                   // this wave's tile of 16 queries
     if (qt * 16 >= S) return;                                // (no barrier below: waves are independent from here on)
     const int i = qt * 16 + c;                               // the lane's query
     const bool row_ok = i < S && mrow[i < S ? i : 0] == 0.f;
@@ -741,9 +742,9 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
     // (50 KB: two workgroups per CU; with all four heads in LDS -- 99 KB, one workgroup per CU -- the kernel was latency-bound)
     constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = ATTN_QS;
     float* qh = (float*)xh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
     const int S = a.S, SEQS = BM / S, ROWS = SEQS * S;
-    const long long seq0 = (long long)blockIdx.x * SEQS;
+    const long long seq0 = (long long)ttup_bid_x() * SEQS;
     const long long m0 = seq0 * S, M = a.n_seq * S;
     const int q = lane >> 4, c = lane & 15;
     // ---- 1. LN(x) rows -> split planes (16 lanes per row, 32 rows per pass)
@@ -893,10 +894,377 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ ALL layers of a stage in one kernel, sequences of S <= 64 tokens
+// A small batch (one rally from the hub surface, the pipeline's per-clip uplift) is a dependent chain of ~80 launches of a few
+// microseconds of work each, most of them one workgroup that waits on its weight fetches.  Here a workgroup of 8 waves owns
+// SEQS = 64 / S whole sequences (the table stage: four 14-token sequences; the temporal / spin stages of a clip of up to 63 frames:
+// one) and runs EVERY layer of the stage on them:
+//   * the tokens live in registers between layers (wave w owns output features 16 w .. 16 w + 15 of all 64 rows in every GEMM, so
+//     the residuals are already where the next result lands) and pass through LDS only as LayerNorm / operand staging;
+//   * per layer  LN -> q | k | v of ALL heads (three 64 x 16 tiles per wave; bias and RoPE in the epilogue) -> attention on the fp32
+//     matrix pipe (attention_mfma_kernel's two-pass form over ceil(S/16) key tiles, K and V read from the qkv tile in LDS) ->
+//     proj + residual -> LN -> fc1 -> ReLU -> fc2 + residual: the split-bf16 arithmetic of linear_x3_kernel throughout (same
+//     split, same accumulation order per output);
+//   * a wave's next 12 KB weight tile (16 outputs x 128 inputs x three bf16 planes) is requested one GEMM ahead and stays in
+//     flight across the LDS phases in between: the barriers wait on LDS traffic only (stage_barrier), not on the vector-memory
+//     counter, which is what made the per-layer kernels (and a first version of this one: 49 us per layer for one workgroup)
+//     latency-bound on a single CU's fetches.
+// LDS: split planes [3][64][128] bf16 (48 KB; the attention output aliases them) | qkv tile [64][388] fp32 (97 KB; the fp32
+// staging of the LayerNorms and of the MLP aliases it) | 16 floats per wave | the rows' mask bits = 145.8 KB.
+// sum over the 16 lanes of a DPP row (every lane gets it): rotations by 8, 4, 2, 1 -- the same pairings, hence bit for bit the same
+// value, as the xor butterfly of __shfl_xor, without its four trips through the LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+struct StageLayerW {
+    const uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;
+    const float *b_qkv, *g1, *b1, *g2, *b2, *bias1, *bias2;
+};
+constexpr int STAGE_MAX_LAYERS = 16;   // the layer table travels in the kernel arguments (scalar loads, pointers known to be global)
+struct StageArgs {
+    float* x; long long n_seq; StageLayerW layers[STAGE_MAX_LAYERS]; int n_layers;
+    const float* mask; const float2* rope;
+    int S, num_cls, mask_div, times_div, times_stride;
+    float scale;
+    long long* stamps;                 // TTUP_STAGE_STAMPS=1: [layer][12] clock values of workgroup 0 / wave 0 at the phase boundaries (else null)
+};
+constexpr int STAGE_QS = 388;         // floats per row of the qkv tile: 4 heads x 96 + 4 (1552 B = 97 slots of 16 B: consecutive rows fall on consecutive slots)
+constexpr size_t STAGE_LDS = (size_t)3 * 64 * 128 * 2 + (size_t)64 * STAGE_QS * 4 + 8 * 16 * 4 + 64 * 4;
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (a __syncthreads() drains vmcnt too)
+__device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];       // split planes
+    constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = STAGE_QS;
+    float* att = (float*)xh;                                          // attention output (fp32, swizzled), while the planes are dead
+    float* qh = (float*)(xh + 3 * PLANE);                             // q | k | v of the four heads: [row][head][q|k|v][32]
+    float* s2 = qh;                                                   // fp32 row staging (swizzled), while the qkv tile is dead
+    float* sinv = qh + BM * QS;
+    float* smask = sinv + 8 * 16;                                     // 1.0 where the row's token takes part in attention (mask == 0), rows of no sequence 0.0
+    auto swz = [&](float* b, int r, int n) __attribute__((always_inline)) { return b + r * K + ((((n >> 2) ^ (r & 15))) << 2) + (n & 3); };
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
+    const int S = a.S, SEQS = BM / S, ROWS = SEQS * S, QT = (S + 15) >> 4;
+    const long long seq0 = (long long)ttup_bid_x() * SEQS;
+    const long long m0 = seq0 * S, M = a.n_seq * S;
+    const int q = lane >> 4, c = lane & 15;
+    const int grp = tid >> 4, l16 = tid & 15;
+    const int n = wave * 16 + 4 * q;                                  // the lane's four output features in every 128-wide GEMM
+    auto split_store = [&](int r, int chunk, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+        u32x4 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = j < 2 ? lo[2 * j] : hi[2 * (j - 2)], x1 = j < 2 ? lo[2 * j + 1] : hi[2 * (j - 2) + 1];
+            const unsigned q0 = ux3_pack2(x0, x1);
+            const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+            const unsigned q1 = ux3_pack2(r0, r1);
+            const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+            p0[j] = q0; p1[j] = q1; p2[j] = ux3_pack2(s0, s1);
+        }
+        uint16_t* d = xh + r * K + ((chunk ^ (r & 15)) << 3);
+        *(u32x4*)d = p0; *(u32x4*)(d + PLANE) = p1; *(u32x4*)(d + 2 * PLANE) = p2;
+    };
+    // LayerNorm of row r of s2 (16 lanes per row, 8 features each) -> split planes
+    auto ln_split = [&](int r, const f32x4 (&g)[2], const f32x4 (&bt)[2]) __attribute__((always_inline)) {
+        f32x4 v[2] = {*(const f32x4*)swz(s2, r, 8 * l16), *(const f32x4*)swz(s2, r, 8 * l16 + 4)};
+        float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+        sum = row16_sum(sum);
+        const float mean = sum / (float)K;
+        float var = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+        var = row16_sum(var);
+        const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * g[u][e] + bt[u][e];
+        split_store(r, l16, v[0], v[1]);
+    };
+    // one 16-output weight tile: 4 k-steps x 3 planes, 16 bytes per lane each
+    // (the scheduling barriers pin the twelve requests where they are written: left alone, the scheduler sinks them to their
+    // first use -- the next GEMM -- to save registers, which is exactly the exposed latency this kernel exists to hide)
+    auto load_tile = [&](const uint16_t* __restrict__ w3, int nt, bf16x8 (&w)[3][KS]) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p][s] = *(const bf16x8*)(w3 + ((((size_t)nt * KS + s) * 3 + p) * 64 + lane) * 8);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // acc[mt] += W_tile . planes  (64 tokens x 16 outputs x 128 inputs, six partial products smallest first)
+    auto gemm = [&](const bf16x8 (&w)[3][KS], f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        const uint16_t* xw = xh + c * K;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 xb[3][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[PA[j]][s], xb[PB[j]][mt], acc[mt], 0, 0, 0);
+        }
+    };
+    // ---- the tokens: global -> registers (row mt*16 + c, features n .. n+3)
+    f32x4 xr[4];
+    bool rot[4]; const float2* rrow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = mt * 16 + c;
+        const long long m = m0 + r;
+        xr[mt] = (r < ROWS && m < M) ? *(const f32x4*)(a.x + m * K + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int sl = r / S, jt = r - sl * S;
+        const long long sq = seq0 + sl;
+        rot[mt] = r < ROWS && sq < a.n_seq && jt >= a.num_cls;
+        rrow[mt] = a.rope + ((size_t)((rot[mt] ? sq : 0) / a.times_div) * a.times_stride + (rot[mt] ? jt - a.num_cls : 0)) * (HD / 2);
+    }
+    if (tid < BM) {
+        const int sl = tid / S, jt = tid - sl * S;
+        const long long sq = seq0 + sl;
+        smask[tid] = (tid < ROWS && sq < a.n_seq && a.mask[(size_t)(sq / a.mask_div) * S + jt] == 0.f) ? 1.f : 0.f;
+    }
+    bf16x8 wnext[3][KS];
+    if (a.n_layers > 0) load_tile(a.layers[0].w_qkv, wave, wnext);
+    const int hw = wave >> 1, ew = wave & 1;                 // a wave's q / k / v tile: head hw, dims 16 ew .. 16 ew + 15
+    for (int li = 0; li < a.n_layers; ++li) {
+        const StageLayerW& L = a.layers[li];
+        auto stamp = [&](int i) __attribute__((always_inline)) { if (a.stamps && ttup_bid_x() == 0 && tid == 0) a.stamps[li * 12 + i] = (long long)__builtin_readcyclecounter(); };
+        stamp(0);
+        // ---- 1. LN(x) -> split planes   (small operands are requested BEFORE the weight tile that is issued next: the memory
+        // counter retires in order, so waiting for them then does not wait for the tile)
+        f32x4 lg[2], lb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { lg[u] = *(const f32x4*)(L.g1 + 8 * l16 + 4 * u); lb[u] = *(const f32x4*)(L.b1 + 8 * l16 + 4 * u); }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(f32x4*)swz(s2, mt * 16 + c, n) = xr[mt];
+        stage_barrier();
+        ln_split(grp, lg, lb);
+        ln_split(grp + 32, lg, lb);
+        stage_barrier();
+        stamp(1);
+        // ---- 2. q | k | v: tiles wave, 8 + wave, 16 + wave of the 384 outputs (bias; RoPE on q and k)
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {
+            bf16x8 wc[3][KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+            const f32x4 b4 = *(const f32x4*)(L.b_qkv + jp * K + n);
+            f32x4 cs4[4];
+            if (jp < 2) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) cs4[mt] = *(const f32x4*)(rrow[mt] + ew * 8 + 2 * q);
+            }
+            if (jp < 2) load_tile(L.w_qkv, (jp + 1) * 8 + wave, wnext); else load_tile(L.w_proj, wave, wnext);
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm(wc, acc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 v = acc[mt] + b4;
+                if (jp < 2 && rot[mt]) {                     // dim pairs (16 ew + 4q, +1) and (+2, +3) of the head
+                    const f32x4 cs = cs4[mt];
+                    v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[0] * cs[1] + v[1] * cs[0], v[2] * cs[2] - v[3] * cs[3], v[2] * cs[3] + v[3] * cs[2]};
+                }
+                *(f32x4*)(qh + (mt * 16 + c) * QS + hw * 96 + jp * 32 + ew * 16 + 4 * q) = v;
+            }
+        }
+        stamp(2);
+        stage_barrier();              // qkv complete; every wave is done with the planes: the attention output goes there
+        stamp(3);
+        // ---- 3. attention: task = (sequence, head, tile of 16 queries)
+        for (int task = wave; task < SEQS * 4 * QT; task += 8) {
+            const int qt = task % QT, sh = task / QT, h = sh & 3, sl = sh >> 2;
+            const long long seq = seq0 + sl;
+            if (seq >= a.n_seq) continue;                    // wave-uniform
+            const float* base = qh + (sl * S) * QS + h * 96;
+            const float* mrow = smask + sl * S;
+            const int i = qt * 16 + c, ir = i < S ? i : S - 1;
+            const bool row_ok = i < S && mrow[ir] != 0.f;
+            const f32x4 q0 = *(const f32x4*)(base + ir * QS + 8 * q), q1 = *(const f32x4*)(base + ir * QS + 8 * q + 4);
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+            float den = 0.f;
+            // NKT key tiles at once: their score chains are independent (the matrix pipe stays fed) and the scores stay in
+            // registers between the maximum and the exponentials; per chain and per output the operation order is
+            // attention_mfma_kernel's
+            auto attend = [&](auto nkt_c) __attribute__((always_inline)) {
+                constexpr int NKT = decltype(nkt_c)::value;
+                f32x4 kk[NKT][2], sc[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const int jc = kt * 16 + c, jr = jc < S ? jc : S - 1;
+                    const float* kp = base + jr * QS + 32 + 8 * q;
+                    kk[kt][0] = *(const f32x4*)kp; kk[kt][1] = *(const f32x4*)(kp + 4);
+                    sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[kt][0][e], q0[e], sc[kt], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[kt][1][e], q1[e], sc[kt], 0, 0, 0);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = kt * 16 + 4 * q + r;
+                        const bool col_ok = j < S && mrow[j < S ? j : 0] != 0.f;
+                        sc[kt][r] = col_ok ? sc[kt][r] * a.scale : -INFINITY;
+                        mx = sc[kt][r] > mx ? sc[kt][r] : mx;
+                    }
+                { const float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; }
+                { const float o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    float pr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[kt][r] > -INFINITY) ? __expf(sc[kt][r] - mx) : 0.f; den += pr[r]; }          // (v_exp_f32: 1 ulp; sixteen libm expf per task were a third of the attention phase)
+                    // out += P V with k index (step s, lane group q) <-> key kt*16 + 4q + s: the A operand of step s is the lane's own pr[s]
+#pragma unroll
+                    for (int s2_ = 0; s2_ < 4; ++s2_) {
+                        const int j = kt * 16 + 4 * q + s2_;
+                        const float* vp = base + (j < S ? j : S - 1) * QS + 64 + c;
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[0], o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[16], o1, 0, 0, 0);
+                    }
+                }
+            };
+            switch (QT) {
+                case 1: attend(std::integral_constant<int, 1>{}); break;
+                case 2: attend(std::integral_constant<int, 2>{}); break;
+                case 3: attend(std::integral_constant<int, 3>{}); break;
+                default: attend(std::integral_constant<int, 4>{}); break;
+            }
+            den += __shfl_xor(den, 16, 64);
+            den += __shfl_xor(den, 32, 64);
+            // o[r] = out[query qt*16 + 4q + r][dim c (o0) / 16 + c (o1)]: the row's 1 / den comes from the lane that owns that query
+            if (q == 0) sinv[wave * 16 + c] = den > 0.f ? 1.f / den : 0.f;          // a fully masked query row yields zeros (torch SDPA semantics)
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int io = qt * 16 + 4 * q + r;
+                if (io >= S) continue;
+                const float inv = sinv[wave * 16 + 4 * q + r];
+                *swz(att, sl * S + io, h * HD + c) = o0[r] * inv;
+                *swz(att, sl * S + io, h * HD + 16 + c) = o1[r] * inv;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        stamp(4);
+        stage_barrier();              // att complete, q | k | v consumed
+        stamp(5);
+        // ---- 4. att (fp32, in the plane storage) -> split planes, through registers
+        {
+            f32x4 t[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { t[i][0] = *(const f32x4*)swz(att, grp + 32 * i, 8 * l16); t[i][1] = *(const f32x4*)swz(att, grp + 32 * i, 8 * l16 + 4); }
+            stage_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split_store(grp + 32 * i, l16, t[i][0], t[i][1]);
+        }
+        stage_barrier();
+        stamp(6);
+        // ---- 5. x2 = proj(att) + x (stays in the lane); a copy goes to s2 for the LayerNorm
+        f32x4 x2[4];
+        {
+            bf16x8 wc[3][KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { lg[u] = *(const f32x4*)(L.g2 + 8 * l16 + 4 * u); lb[u] = *(const f32x4*)(L.b2 + 8 * l16 + 4 * u); }
+            load_tile(L.w_fc1, wave, wnext);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) x2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm(wc, x2);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                x2[mt] += xr[mt];
+                *(f32x4*)swz(s2, mt * 16 + c, n) = x2[mt];
+            }
+        }
+        stage_barrier();
+        stamp(7);
+        ln_split(grp, lg, lb);
+        ln_split(grp + 32, lg, lb);
+        stage_barrier();
+        stamp(8);
+        // ---- 6. hid = relu(fc1(LN(x2)) + b1) -> s2 -> split planes
+        {
+            bf16x8 wc[3][KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+            const f32x4 b4 = *(const f32x4*)(L.bias1 + n);
+            load_tile(L.w_fc2, wave, wnext);
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm(wc, acc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 v = acc[mt] + b4;
+                v = f32x4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+                *(f32x4*)swz(s2, mt * 16 + c, n) = v;
+            }
+        }
+        stage_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = grp + 32 * i;
+            split_store(r, l16, *(const f32x4*)swz(s2, r, 8 * l16), *(const f32x4*)swz(s2, r, 8 * l16 + 4));
+        }
+        stage_barrier();
+        stamp(9);
+        // ---- 7. x = fc2(hid) + b2 + x2
+        {
+            bf16x8 wc[3][KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+            const f32x4 b4 = *(const f32x4*)(L.bias2 + n);
+            if (li + 1 < a.n_layers) load_tile(a.layers[li + 1].w_qkv, wave, wnext);
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm(wc, acc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xr[mt] = (acc[mt] + b4) + x2[mt];
+        }
+        stamp(10);
+        stage_barrier();              // every wave is done with the planes and with s2
+        stamp(11);
+    }
+    // ---- the tokens: registers -> global
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = mt * 16 + c;
+        const long long m = m0 + r;
+        if (r < ROWS && m < M) *(f32x4*)(a.x + m * K + n) = xr[mt];
+    }
+}
+
 // ------------------------------------------------------------------ token assembly helpers
 // x[(b,t), 0] = ball_tok[b,t]; x[(b,t), 1+n] = table_tok[b,n]      (model.py:374-378)
 __global__ void assemble_table_kernel(const float* ball_tok, const float* table_tok, float* x, int T, int NT, int D, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= total) return;
     const int d = (int)(i % D);
     long long r = i / D;
@@ -905,7 +1273,7 @@ __global__ void assemble_table_kernel(const float* ball_tok, const float* table_
 }
 // y[r] = x[r*stride_tok] rows (token 0 of every sequence)            (model.py:383-384)
 __global__ void gather_rows_kernel(const float* x, float* y, int D, int seq_tokens, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= total) return;
     const int d = (int)(i % D);
     const long long r = i / D;
@@ -913,7 +1281,7 @@ __global__ void gather_rows_kernel(const float* x, float* y, int D, int seq_toke
 }
 // y[b, 0] = cls; y[b, 1+t] = x[b, t]                                 (model.py:560)
 __global__ void prepend_cls_kernel(const float* x, const float* cls, float* y, int T, int D, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (i >= total) return;
     const int d = (int)(i % D);
     long long r = i / D;
@@ -922,7 +1290,7 @@ __global__ void prepend_cls_kernel(const float* x, const float* cls, float* y, i
 }
 // masks: mask (B,T) {0,1} -> additive m1 (B,T), m2 (B,T+1) with leading 0; table (B,13,3) -> tmask (B,14), txy (B*13,2)
 __global__ void prepare_kernel(const float* mask, const float* table, float* m1, float* m2, float* tmask, float* txy, int B, int T, int NT, int* flags) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     const long long nmask = (long long)B * T, ntab = (long long)B * NT;
     int fl = 0;
     if (i < nmask) {
@@ -944,10 +1312,10 @@ __global__ void prepare_kernel(const float* mask, const float* table, float* m1,
     // one atomic per wave (every thread used to hit the one flag word: 1.4 ms per call at B = 10 000)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) fl |= __shfl_xor(fl, off, 64);
-    if ((threadIdx.x & 63) == 0 && fl) atomicOr(flags, fl);
+    if ((ttup_tid_x() & 63) == 0 && fl) atomicOr(flags, fl);
 }
 __global__ void rotationaxes_kernel(const float* rot, const float* pos, int B, int T, float* out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = ttup_bid_x() * ttup_bdim_x() + ttup_tid_x();
     if (b >= B) return;
     const float* p = pos + (size_t)b * T * 3;
     const float vx = p[3] - p[0], vy = p[4] - p[1];
@@ -971,6 +1339,8 @@ struct ttup_uplift {
     Mlp2 ball_embed, table_embed;
     Head position_head, rotation_head;
     float* cls_dev = nullptr; float* inv_freq_dev = nullptr; float* table_times_dev = nullptr;
+    std::vector<StageLayerW> stage_pos, stage_first, stage_second;      // weight pointers of the three stages' layers (stage_x3_kernel); empty = not available
+    long long stage_launches = 0;
     float2 *rope = nullptr, *table_rope = nullptr;      // (cos, sin) tables: [chunk*max_len][hd/2] per forward, [n_table][hd/2] fixed
     std::vector<void*> allocs;
     // scratch (sized for `chunk` trajectories of max_len tokens)
@@ -1256,6 +1626,64 @@ int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int 
     return run_linear(L.fc2, net->hid, D, tokens, nullptr, nullptr, 0, net->x2, D, x, D, st);                       // x = fc2(hid) + x2
 }
 
+// the layers' weight pointers for stage_x3_kernel (left empty when a layer has no split-bf16 image or the table would not fit)
+void make_stage(ttup_uplift* net, const std::vector<Layer>& layers, std::vector<StageLayerW>* out) {
+    out->clear();
+    if (layers.empty() || layers.size() > (size_t)STAGE_MAX_LAYERS || net->D != 128 || net->heads != 4) return;
+    for (const Layer& L : layers) {
+        if (!L.qkv.w3_dev || !L.proj.w3_dev || !L.fc1.w3_dev || !L.fc2.w3_dev) { out->clear(); return; }
+        out->push_back(StageLayerW{L.qkv.w3_dev, L.proj.w3_dev, L.fc1.w3_dev, L.fc2.w3_dev, L.qkv.b_dev, L.g1, L.b1, L.g2, L.b2, L.fc1.b_dev, L.fc2.b_dev});
+    }
+}
+
+// Every layer of a stage: one stage_x3_kernel launch when the sequences fit a 64-token tile and the launch is small enough to be
+// latency-bound (at most 256 workgroups by default: the kernel holds 146 KB of LDS, one workgroup per CU, and loses to the per-layer
+// kernels -- two workgroups per CU -- once the device is full), else layer by layer.
+int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vector<StageLayerW>& stage, float* x, long long tokens, int n_seq, int S, int num_cls,
+              const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
+    static const bool off = getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_UPLIFT_UNFUSED") != nullptr || getenv("TTUP_UPLIFT_NO_STAGE") != nullptr;
+    static const long long max_wg = getenv("TTUP_UPLIFT_STAGE_WG") ? atoll(getenv("TTUP_UPLIFT_STAGE_WG")) : 256;
+    if (!stage.empty() && !off && S <= 64 && n_seq > 0) {
+        const int seqs = 64 / S;
+        const long long wgs = ((long long)n_seq + seqs - 1) / seqs;
+        if (wgs <= max_wg) {
+            StageArgs a;
+            a.x = x; a.n_seq = n_seq; a.n_layers = (int)layers.size();
+            memcpy(a.layers, stage.data(), stage.size() * sizeof(StageLayerW));
+            a.mask = mask; a.rope = rope; a.S = S; a.num_cls = num_cls; a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
+            a.scale = 1.0f / sqrtf((float)net->hd);
+            if (int rc = ensure_max_lds((const void*)stage_x3_kernel, 160 * 1024)) return rc;
+            static const bool want_stamps = getenv("TTUP_STAGE_STAMPS") != nullptr;
+            static long long* stamps_dev = nullptr;
+            a.stamps = nullptr;
+            if (want_stamps) {
+                if (!stamps_dev) TTUP_HIP_CHECK(hipMalloc((void**)&stamps_dev, STAGE_MAX_LAYERS * 12 * sizeof(long long)));
+                a.stamps = stamps_dev;
+            }
+            hipLaunchKernelGGL(stage_x3_kernel, dim3((unsigned)wgs), dim3(512), STAGE_LDS, st, a);
+            TTUP_LAUNCH_CHECK();
+            if (want_stamps) {          // debugging aid (synchronises): cycles between the phase boundaries of the LAST layer, wave 0 of workgroup 0
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(st, &cs);
+                if (cs == hipStreamCaptureStatusNone) {
+                    std::vector<long long> h((size_t)a.n_layers * 12);
+                    TTUP_HIP_CHECK(hipStreamSynchronize(st));
+                    TTUP_HIP_CHECK(hipMemcpy(h.data(), stamps_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+                    const long long* t = h.data() + (size_t)(a.n_layers - 1) * 12;
+                    fprintf(stderr, "stage S=%d n_seq=%d wgs=%lld layers=%d: whole stage %lld clk; last layer: ln1 %lld qkv %lld wait %lld attn %lld wait %lld att->planes %lld proj %lld ln2 %lld fc1+split %lld fc2 %lld wait %lld\n",
+                            S, n_seq, wgs, a.n_layers, h[(size_t)(a.n_layers - 1) * 12 + 11] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5],
+                            t[7] - t[6], t[8] - t[7], t[9] - t[8], t[10] - t[9], t[11] - t[10]);
+                }
+            }
+            net->stage_launches++;
+            return TTUP_OK;
+        }
+    }
+    for (const Layer& L : layers)
+        if (int rc = run_layer(net, L, x, tokens, n_seq, S, num_cls, mask, mask_div, rope, times_div, times_stride, st)) return rc;
+    return TTUP_OK;
+}
+
 int run_head(ttup_uplift* net, const Head& h, const float* x, int ldx, long long M, float* out, hipStream_t st) {
     const int D = net->D;
     int rc;
@@ -1290,16 +1718,14 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
         hipLaunchKernelGGL(assemble_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->tok, net->ttok, net->x, T, NT, D, total);
         TTUP_LAUNCH_CHECK();
     }
-    for (const Layer& L : net->pos_layers)
-        if ((rc = run_layer(net, L, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st))) return rc;
+    if ((rc = run_stage(net, net->pos_layers, net->stage_pos, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st))) return rc;
     {
         const long long total = (long long)B * T * D;
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->x, net->tok, D, S1, total);
         TTUP_LAUNCH_CHECK();
     }
     // temporal stage (tok is [B*T][D])
-    for (const Layer& L : net->layers)
-        if ((rc = run_layer(net, L, net->tok, (long long)B * T, B, T, 0, net->m1, 1, net->rope, 1, T, st))) return rc;
+    if ((rc = run_stage(net, net->layers, net->stage_first, net->tok, (long long)B * T, B, T, 0, net->m1, 1, net->rope, 1, T, st))) return rc;
     if ((rc = run_head(net, net->position_head, net->tok, D, (long long)B * T, pos, st))) return rc;
     // spin stage
     {
@@ -1307,8 +1733,7 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
         hipLaunchKernelGGL(prepend_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->tok, net->cls_dev, net->x, T, D, total);
         TTUP_LAUNCH_CHECK();
     }
-    for (const Layer& L : net->second)
-        if ((rc = run_layer(net, L, net->x, (long long)B * (T + 1), B, T + 1, 1, net->m2, 1, net->rope, 1, T, st))) return rc;
+    if ((rc = run_stage(net, net->second, net->stage_second, net->x, (long long)B * (T + 1), B, T + 1, 1, net->m2, 1, net->rope, 1, T, st))) return rc;
     // rotation head on the cls rows (row stride (T+1)*D)
     return run_head(net, net->rotation_head, net->x, (T + 1) * D, B, rot, st);
 }
@@ -1351,6 +1776,9 @@ extern "C" int ttup_uplift_create(const void* blob, size_t blob_bytes, int max_b
     for (auto& L : net->second) if ((rc = make_layer(net.get(), r, &L))) return rc;
     if ((rc = make_head(net.get(), r, &net->rotation_head))) return rc;
     TTUP_REQUIRE(r.left == 0, TTUP_EFORMAT, "uplift blob: %zu trailing bytes", r.left);
+    make_stage(net.get(), net->pos_layers, &net->stage_pos);
+    make_stage(net.get(), net->layers, &net->stage_first);
+    make_stage(net.get(), net->second, &net->stage_second);
     {
         std::vector<float> tt(net->n_table);
         for (int n = 0; n < net->n_table; ++n) tt[n] = (float)n / 100.0f;       // arange(13) / (MAX_FPS/5), model.py:367
@@ -1492,6 +1920,13 @@ extern "C" int ttup_uplift_graph_info(ttup_uplift* net, int* out_host3) {
     return TTUP_OK;
 }
 
+// stage_x3_kernel launches issued (or captured into a graph) so far: all layers of a stage in one launch, small batches only
+extern "C" int ttup_uplift_stage_info(ttup_uplift* net, long long* out_host) {
+    TTUP_REQUIRE(net && out_host, TTUP_EINVAL, "ttup_uplift_stage_info: null pointer");
+    *out_host = net->stage_launches;
+    return TTUP_OK;
+}
+
 extern "C" int ttup_transform_rotationaxes(const float* rot_dev, const float* pos_dev, int batch, int len, float* out_dev, void* stream) {
     TTUP_REQUIRE(rot_dev && pos_dev && out_dev, TTUP_EINVAL, "ttup_transform_rotationaxes: null pointer");
     TTUP_REQUIRE(batch >= 0 && len >= 2, TTUP_EINVAL, "ttup_transform_rotationaxes: need at least two positions");
@@ -1501,4 +1936,4 @@ extern "C" int ttup_transform_rotationaxes(const float* rot_dev, const float* po
     return TTUP_OK;
 }
 
-TTUP_NO_PACKED_FP32_END
+#include "no_packed_fp32_end.h"

@@ -54,10 +54,13 @@ class MultiStageModel:
     __call__ = forward
 
     def graph_info(self):
-        """{'graphs', 'off', 'replays'}: the small-batch path (hipGraph replay of a captured forward, csrc/uplift.hip)."""
+        """{'graphs', 'off', 'replays', 'stage_launches'}: the small-batch path (hipGraph replay of a captured forward; all layers
+        of a stage in one stage_x3_kernel launch, csrc/uplift.hip)."""
         out = (ctypes.c_int * 3)()
         _lib.check(self._lib.ttup_uplift_graph_info(self._handle, out))
-        return {'graphs': int(out[0]), 'off': bool(out[1]), 'replays': int(out[2])}
+        st = ctypes.c_longlong(0)
+        _lib.check(self._lib.ttup_uplift_stage_info(self._handle, ctypes.byref(st)))
+        return {'graphs': int(out[0]), 'off': bool(out[1]), 'replays': int(out[2]), 'stage_launches': int(st.value)}
 
 
 def get_model(name='connectstage', size='large', mode='dynamic', time_rotation='new', state_dict=None, **kw):
