@@ -909,8 +909,9 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
 //     flight across the LDS phases in between: the barriers wait on LDS traffic only (stage_barrier), not on the vector-memory
 //     counter, which is what made the per-layer kernels (and a first version of this one: 49 us per layer for one workgroup)
 //     latency-bound on a single CU's fetches.
-// LDS: split planes [3][64][128] bf16 (48 KB; the attention output aliases them) | qkv tile [64][388] fp32 (97 KB; the fp32
-// staging of the LayerNorms and of the MLP aliases it) | 16 floats per wave | the rows' mask bits = 145.8 KB.
+// LDS: split planes [3][64][128] bf16 (48 KB; the attention output aliases them) | q | k tile [64][260] fp32 (65 KB; the fp32
+// staging of the LayerNorms and of the MLP aliases it) | V transposed [4 heads][32][84] fp32 (42 KB: the P V operand of four keys
+// is one 16-byte read; a sequence's tokens start at a multiple of 4) | 16 floats per wave = 155.5 KB.
 // sum over the 16 lanes of a DPP row (every lane gets it): rotations by 8, 4, 2, 1 -- the same pairings, hence bit for bit the same
 // value, as the xor butterfly of __shfl_xor, without its four trips through the LDS crossbar
 __device__ __forceinline__ float row16_sum(float v) {
@@ -932,21 +933,22 @@ struct StageArgs {
     float scale;
     long long* stamps;                 // TTUP_STAGE_STAMPS=1: [layer][12] clock values of workgroup 0 / wave 0 at the phase boundaries (else null)
 };
-constexpr int STAGE_QS = 388;         // floats per row of the qkv tile: 4 heads x 96 + 4 (1552 B = 97 slots of 16 B: consecutive rows fall on consecutive slots)
-constexpr size_t STAGE_LDS = (size_t)3 * 64 * 128 * 2 + (size_t)64 * STAGE_QS * 4 + 8 * 16 * 4 + 64 * 4;
+constexpr int STAGE_QS = 260;         // floats per row of the q | k tile: 4 heads x 64 + 4 (1040 B = 65 slots of 16 B: consecutive rows fall on consecutive slots)
+constexpr int STAGE_VS = 84;          // floats per row of V^T [head][dim][token]: 4 x 84 = 16 (mod 64), so a transposed store of 4 dims x 16 tokens per lane group is conflict-free
+constexpr size_t STAGE_LDS = (size_t)3 * 64 * 128 * 2 + (size_t)64 * STAGE_QS * 4 + (size_t)4 * 32 * STAGE_VS * 4 + 8 * 16 * 4;
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (a __syncthreads() drains vmcnt too)
 __device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t xh[];       // split planes
-    constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = STAGE_QS;
+    constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = STAGE_QS, VS = STAGE_VS;
     float* att = (float*)xh;                                          // attention output (fp32, swizzled), while the planes are dead
-    float* qh = (float*)(xh + 3 * PLANE);                             // q | k | v of the four heads: [row][head][q|k|v][32]
-    float* s2 = qh;                                                   // fp32 row staging (swizzled), while the qkv tile is dead
-    float* sinv = qh + BM * QS;
-    float* smask = sinv + 8 * 16;                                     // 1.0 where the row's token takes part in attention (mask == 0), rows of no sequence 0.0
+    float* qh = (float*)(xh + 3 * PLANE);                             // q | k of the four heads: [row][head][q|k][32]
+    float* s2 = qh;                                                   // fp32 row staging (swizzled), while the q | k tile is dead
+    float* vt = qh + BM * QS;                                         // V^T: [head][dim][sequence sl at column sl*S4 + token]
+    float* sinv = vt + 4 * HD * VS;
     auto swz = [&](float* b, int r, int n) __attribute__((always_inline)) { return b + r * K + ((((n >> 2) ^ (r & 15))) << 2) + (n & 3); };
     const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
-    const int S = a.S, SEQS = BM / S, ROWS = SEQS * S, QT = (S + 15) >> 4;
+    const int S = a.S, SEQS = BM / S, ROWS = SEQS * S, QT = (S + 15) >> 4, S4 = (S + 3) & ~3;
     const long long seq0 = (long long)ttup_bid_x() * SEQS;
     const long long m0 = seq0 * S, M = a.n_seq * S;
     const int q = lane >> 4, c = lane & 15;
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
     };
     // ---- the tokens: global -> registers (row mt*16 + c, features n .. n+3)
     f32x4 xr[4];
-    bool rot[4]; const float2* rrow[4];
+    bool rot[4]; const float2* rrow[4]; int vcol[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int r = mt * 16 + c;
@@ -1025,11 +1027,15 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
         const long long sq = seq0 + sl;
         rot[mt] = r < ROWS && sq < a.n_seq && jt >= a.num_cls;
         rrow[mt] = a.rope + ((size_t)((rot[mt] ? sq : 0) / a.times_div) * a.times_stride + (rot[mt] ? jt - a.num_cls : 0)) * (HD / 2);
+        vcol[mt] = r < ROWS ? sl * S4 + jt : -1;             // the row's column in V^T (rows of no sequence are not stored)
     }
-    if (tid < BM) {
-        const int sl = tid / S, jt = tid - sl * S;
+    for (int i = tid; i < 4 * HD * VS + 8 * 16; i += 512) vt[i] = 0.f;          // V^T and the normalisers: never-written columns must read as finite (0 x NaN)
+    // bit r: row r of the tile takes part in attention (its mask entry is 0); every wave computes the same 64 bits
+    unsigned long long rowbits;
+    {
+        const int sl = lane / S, jt = lane - sl * S;
         const long long sq = seq0 + sl;
-        smask[tid] = (tid < ROWS && sq < a.n_seq && a.mask[(size_t)(sq / a.mask_div) * S + jt] == 0.f) ? 1.f : 0.f;
+        rowbits = __builtin_amdgcn_ballot_w64(lane < ROWS && sq < a.n_seq && a.mask[(size_t)((lane < ROWS && sq < a.n_seq ? sq : 0) / a.mask_div) * S + jt] == 0.f);
     }
     bf16x8 wnext[3][KS];
     if (a.n_layers > 0) load_tile(a.layers[0].w_qkv, wave, wnext);
@@ -1076,7 +1082,11 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                     const f32x4 cs = cs4[mt];
                     v = f32x4{v[0] * cs[0] - v[1] * cs[1], v[0] * cs[1] + v[1] * cs[0], v[2] * cs[2] - v[3] * cs[3], v[2] * cs[3] + v[3] * cs[2]};
                 }
-                *(f32x4*)(qh + (mt * 16 + c) * QS + hw * 96 + jp * 32 + ew * 16 + 4 * q) = v;
+                if (jp < 2) *(f32x4*)(qh + (mt * 16 + c) * QS + hw * 64 + jp * 32 + ew * 16 + 4 * q) = v;
+                else if (vcol[mt] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vt[(hw * HD + ew * 16 + 4 * q + e) * VS + vcol[mt]] = v[e];
+                }
             }
         }
         stamp(2);
@@ -1087,10 +1097,12 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
             const int qt = task % QT, sh = task / QT, h = sh & 3, sl = sh >> 2;
             const long long seq = seq0 + sl;
             if (seq >= a.n_seq) continue;                    // wave-uniform
-            const float* base = qh + (sl * S) * QS + h * 96;
-            const float* mrow = smask + sl * S;
+            const float* base = qh + (sl * S) * QS + h * 64;
+            const float* vbase = vt + (h * HD + c) * VS + sl * S4 + 4 * q;          // V^T[dim c][keys 4q ..] of the sequence; dims 16 + c are 16 rows on
             const int i = qt * 16 + c, ir = i < S ? i : S - 1;
-            const bool row_ok = i < S && mrow[ir] != 0.f;
+            const unsigned long long seqbits = (rowbits >> (sl * S)) & (S >= 64 ? ~0ull : (1ull << S) - 1);          // bit j: key / query j of this sequence is valid
+            const bool row_ok = (seqbits >> (i & 63)) & 1 && i < S;
+            const unsigned long long colbits = seqbits >> (4 * q);          // bit kt*16 + r: key kt*16 + 4q + r
             const f32x4 q0 = *(const f32x4*)(base + ir * QS + 8 * q), q1 = *(const f32x4*)(base + ir * QS + 8 * q + 4);
             f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
             float den = 0.f;
@@ -1099,7 +1111,7 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
             // attention_mfma_kernel's
             auto attend = [&](auto nkt_c) __attribute__((always_inline)) {
                 constexpr int NKT = decltype(nkt_c)::value;
-                f32x4 kk[NKT][2], sc[NKT];
+                f32x4 kk[NKT][2], sc[NKT], vv[NKT][2];
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     const int jc = kt * 16 + c, jr = jc < S ? jc : S - 1;
@@ -1107,6 +1119,10 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                     kk[kt][0] = *(const f32x4*)kp; kk[kt][1] = *(const f32x4*)(kp + 4);
                     sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                // V^T of keys kt*16 + 4q .. + 3 (columns past the sequence hold other tokens, zeros or -- past the array -- the
+                // normalisers: their p is 0 and all of it is finite, the storage having been cleared once)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) { vv[kt][0] = *(const f32x4*)(vbase + kt * 16); vv[kt][1] = *(const f32x4*)(vbase + kt * 16 + 16 * VS); }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1120,8 +1136,7 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = kt * 16 + 4 * q + r;
-                        const bool col_ok = j < S && mrow[j < S ? j : 0] != 0.f;
+                        const bool col_ok = (colbits >> (kt * 16 + r)) & 1;
                         sc[kt][r] = col_ok ? sc[kt][r] * a.scale : -INFINITY;
                         mx = sc[kt][r] > mx ? sc[kt][r] : mx;
                     }
@@ -1135,10 +1150,8 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                     // out += P V with k index (step s, lane group q) <-> key kt*16 + 4q + s: the A operand of step s is the lane's own pr[s]
 #pragma unroll
                     for (int s2_ = 0; s2_ < 4; ++s2_) {
-                        const int j = kt * 16 + 4 * q + s2_;
-                        const float* vp = base + (j < S ? j : S - 1) * QS + 64 + c;
-                        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[0], o0, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vp[16], o1, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vv[kt][0][s2_], o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vv[kt][1][s2_], o1, 0, 0, 0);
                     }
                 }
             };
@@ -1643,7 +1656,7 @@ int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vec
               const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
     static const bool off = getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_UPLIFT_UNFUSED") != nullptr || getenv("TTUP_UPLIFT_NO_STAGE") != nullptr;
     static const long long max_wg = getenv("TTUP_UPLIFT_STAGE_WG") ? atoll(getenv("TTUP_UPLIFT_STAGE_WG")) : 256;
-    if (!stage.empty() && !off && S <= 64 && n_seq > 0) {
+    if (!stage.empty() && !off && S <= 64 && n_seq > 0 && (64 / S) * ((S + 3) & ~3) <= STAGE_VS) {          // (V^T holds every sequence of the tile at a multiple of 4)
         const int seqs = 64 / S;
         const long long wgs = ((long long)n_seq + seqs - 1) / seqs;
         if (wgs <= max_wg) {
