@@ -222,8 +222,8 @@ int ttup_uplift_forward(ttup_uplift* net, const float* ball_dev, const float* ta
 int ttup_uplift_graph_info(ttup_uplift* net, int* out_host3);
 
 /* Sequences of at most 64 tokens (the table stage always; the temporal and spin stages of clips of up to 63 frames) run ALL layers
- * of a stage in one launch with the tokens resident in LDS, while the launch stays small (at most 256 workgroups; TTUP_UPLIFT_STAGE_WG
- * overrides, TTUP_UPLIFT_NO_STAGE=1 switches it off).  *out_host = such launches issued or captured so far. */
+ * of a stage in one launch with the tokens resident on the CU (TTUP_UPLIFT_NO_STAGE=1 switches it off, TTUP_UPLIFT_STAGE_WG caps the
+ * launch size it is used for).  *out_host = such launches issued or captured so far. */
 int ttup_uplift_stage_info(ttup_uplift* net, long long* out_host);
 
 /* ---------------------------------------------------------------- a7: spin frame change

@@ -43,6 +43,15 @@ struct Linear {
     uint16_t* w3_dev = nullptr;
 };
 
+// sum over the 16 lanes of a DPP row (every lane gets it): rotations by 8, 4, 2, 1 -- the same pairings, hence bit for bit the same
+// value, as the xor butterfly of __shfl_xor, without its four trips through the LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
 struct LinArgs {
     const float* x; int ldx;
     const float* w; const float* bias;
@@ -77,8 +86,7 @@ __global__ __launch_bounds__(256 * MH) void linear_kernel(LinArgs a) {
                 float sum = 0.f;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) sum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                sum = row16_sum(sum);
                 const float mean = sum / (float)K;
                 float var = 0.f;
 #pragma unroll
@@ -87,8 +95,7 @@ __global__ __launch_bounds__(256 * MH) void linear_kernel(LinArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
                 }
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+                var = row16_sum(var);
                 const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -209,16 +216,14 @@ __global__ __launch_bounds__(256 * MH) void linear_x3_kernel(LinArgs a, const ui
                 // (mean / variance with the summation tree of linear_kernel's staging is not required: any order is within the bar;
                 // a 16-lane tree over 8 features per lane)
                 float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                sum = row16_sum(sum);
                 const float mean = sum / (float)K;
                 float var = 0.f;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+                var = row16_sum(var);
                 const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -412,16 +417,14 @@ __global__ __launch_bounds__(256 * MH) void mlp_block_x3_kernel(MlpArgs a) {
         const int r = grp + i * 16 * MH;
         f32x4 v[2] = {*(const f32x4*)s2p(r, 8 * l16), *(const f32x4*)s2p(r, 8 * l16 + 4)};
         float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        sum = row16_sum(sum);
         const float mean = sum / (float)K;
         float var = 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+        var = row16_sum(var);
         const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnMArgs a) {
         const f32x4 sc = scores(kt);
         float pr[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? expf(sc[r] - mx) : 0.f; den += pr[r]; }
+        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? __expf(sc[r] - mx) : 0.f; den += pr[r]; }
         // out += P V with k index (step s, lane group q) <-> key kt*16 + 4q + s: the A operand of step s is the lane's own pr[s]
         const float* vp = sv + (kt * 16 + 4 * q) * KS + c;
 #pragma unroll
@@ -761,16 +764,14 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) v[u] = ok ? *(const f32x4*)(a.x + m * K + 8 * l16 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
             float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            sum = row16_sum(sum);
             const float mean = sum / (float)K;
             float var = 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) var += __shfl_xor(var, off, 64);
+            var = row16_sum(var);
             const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
             u32x4 p0, p1, p2;
 #pragma unroll
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
         { const float o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
         float pr[4], den = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? expf(sc[r] - mx) : 0.f; den += pr[r]; }
+        for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[r] > -INFINITY) ? __expf(sc[r] - mx) : 0.f; den += pr[r]; }
         den += __shfl_xor(den, 16, 64);
         den += __shfl_xor(den, 32, 64);
         const float inv = den > 0.f ? 1.f / den : 0.f;       // a fully masked query row yields zeros (torch SDPA semantics)
@@ -912,15 +913,6 @@ __global__ __launch_bounds__(512) void attn_block_x3_kernel(AttnBlockArgs a) {
 // LDS: split planes [3][64][128] bf16 (48 KB; the attention output aliases them) | q | k tile [64][260] fp32 (65 KB; the fp32
 // staging of the LayerNorms and of the MLP aliases it) | V transposed [4 heads][32][84] fp32 (42 KB: the P V operand of four keys
 // is one 16-byte read; a sequence's tokens start at a multiple of 4) | 16 floats per wave = 155.5 KB.
-// sum over the 16 lanes of a DPP row (every lane gets it): rotations by 8, 4, 2, 1 -- the same pairings, hence bit for bit the same
-// value, as the xor butterfly of __shfl_xor, without its four trips through the LDS crossbar
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-}
 struct StageLayerW {
     const uint16_t *w_qkv, *w_proj, *w_fc1, *w_fc2;
     const float *b_qkv, *g1, *b1, *g2, *b2, *bias1, *bias2;
@@ -1649,13 +1641,15 @@ void make_stage(ttup_uplift* net, const std::vector<Layer>& layers, std::vector<
     }
 }
 
-// Every layer of a stage: one stage_x3_kernel launch when the sequences fit a 64-token tile and the launch is small enough to be
-// latency-bound (at most 256 workgroups by default: the kernel holds 146 KB of LDS, one workgroup per CU, and loses to the per-layer
-// kernels -- two workgroups per CU -- once the device is full), else layer by layer.
+// Every layer of a stage: one stage_x3_kernel launch when the sequences fit a 64-token tile (the table stage always; the temporal
+// and spin stages of clips of up to 63 frames), else layer by layer.  The kernel holds 156 KB of LDS -- one workgroup per CU -- and
+// still beats the per-layer kernels (two per CU) on a full device: 55 k cycles per 64-token layer against 19 k (attention block,
+// bound by the L1 traffic of its weight fragments: every m-tile wave streams its head's weights) + 38 k (MLP block); B = 10 000,
+// T = 120: 50.1 k -> 55.4 k trajectories/s, B = 4096, T = 50: 123 k -> 149 k.  TTUP_UPLIFT_STAGE_WG caps the launch size it is used for.
 int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vector<StageLayerW>& stage, float* x, long long tokens, int n_seq, int S, int num_cls,
               const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
     static const bool off = getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_UPLIFT_UNFUSED") != nullptr || getenv("TTUP_UPLIFT_NO_STAGE") != nullptr;
-    static const long long max_wg = getenv("TTUP_UPLIFT_STAGE_WG") ? atoll(getenv("TTUP_UPLIFT_STAGE_WG")) : 256;
+    static const long long max_wg = getenv("TTUP_UPLIFT_STAGE_WG") ? atoll(getenv("TTUP_UPLIFT_STAGE_WG")) : (1ll << 40);
     if (!stage.empty() && !off && S <= 64 && n_seq > 0 && (64 / S) * ((S + 3) & ~3) <= STAGE_VS) {          // (V^T holds every sequence of the tile at a multiple of 4)
         const int seqs = 64 / S;
         const long long wgs = ((long long)n_seq + seqs - 1) / seqs;
