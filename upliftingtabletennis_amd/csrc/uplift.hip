@@ -52,6 +52,8 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
     return v;
 }
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (a __syncthreads() drains vmcnt too)
+__device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct LinArgs {
     const float* x; int ldx;
     const float* w; const float* bias;
@@ -479,6 +481,163 @@ __global__ __launch_bounds__(256 * MH) void mlp_block_x3_kernel(MlpArgs a) {
                 const long long m = m0 + wm * 64 + mt * 16 + c;
                 if (m < a.M) *(f32x4*)(a.x + m * K + n) = (acc[t][mt] + b4) + x2[t][mt];
             }
+        }
+    }
+}
+
+// The same block in the form of stage_x3_kernel's MLP half (round 4, after that kernel turned out twice as fast per tile): 8 waves on
+// a 64-token tile, wave w owns output features 16 w .. 16 w + 15 of all 64 rows in each of the three GEMMs (no weight fragment is
+// fetched twice by a workgroup), its 12 KB weight tile of the NEXT GEMM is requested before the current one starts and stays in
+// flight across the LDS phases (LDS-only barriers, loads pinned with scheduling barriers), LayerNorm row sums on DPP.  80 KB of LDS:
+// two workgroups per CU, whose phases interleave.  Arithmetic identical to mlp_block_x3_kernel (same split, same order per output).
+__global__ __launch_bounds__(512) void mlp_block8_x3_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t xh[];      // [3][64][128] split planes | float s2[64][128] (swizzled)
+    constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32;
+    float* s2 = (float*)(xh + 3 * PLANE);
+    auto swz = [&](float* b, int r, int n) __attribute__((always_inline)) { return b + r * K + ((((n >> 2) ^ (r & 15))) << 2) + (n & 3); };
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
+    const long long m0 = (long long)ttup_bid_x() * BM;
+    const int q = lane >> 4, c = lane & 15;
+    const int grp = tid >> 4, l16 = tid & 15;
+    const int n = wave * 16 + 4 * q;
+    auto split_store = [&](int r, int chunk, const f32x4& lo, const f32x4& hi) __attribute__((always_inline)) {
+        u32x4 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = j < 2 ? lo[2 * j] : hi[2 * (j - 2)], x1 = j < 2 ? lo[2 * j + 1] : hi[2 * (j - 2) + 1];
+            const unsigned q0 = ux3_pack2(x0, x1);
+            const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+            const unsigned q1 = ux3_pack2(r0, r1);
+            const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+            p0[j] = q0; p1[j] = q1; p2[j] = ux3_pack2(s0, s1);
+        }
+        uint16_t* d = xh + r * K + ((chunk ^ (r & 15)) << 3);
+        *(u32x4*)d = p0; *(u32x4*)(d + PLANE) = p1; *(u32x4*)(d + 2 * PLANE) = p2;
+    };
+    auto load_tile = [&](const uint16_t* __restrict__ w3, bf16x8 (&w)[3][KS]) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p][s] = *(const bf16x8*)(w3 + ((((size_t)wave * KS + s) * 3 + p) * 64 + lane) * 8);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto gemm = [&](const bf16x8 (&w)[3][KS], f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        const uint16_t* xw = xh + c * K;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 xb[3][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[p][mt] = *(const bf16x8*)(xw + p * PLANE + mt * 16 * K + (((4 * s + q) ^ c) << 3));
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[PA[j]][s], xb[PB[j]][mt], acc[mt], 0, 0, 0);
+        }
+    };
+    // ---- small operands first (the memory counter retires in order), then the first weight tile, then the att rows
+    f32x4 xr[4], lg[2], lb[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const long long m = m0 + mt * 16 + c;
+        xr[mt] = m < a.M ? *(const f32x4*)(a.x + m * K + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { lg[u] = *(const f32x4*)(a.g2 + 8 * l16 + 4 * u); lb[u] = *(const f32x4*)(a.b2 + 8 * l16 + 4 * u); }
+    const f32x4 bias1 = *(const f32x4*)(a.bias1 + n), bias2 = *(const f32x4*)(a.bias2 + n);
+    f32x4 at[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + grp + 32 * i;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        at[i][0] = m < a.M ? *(const f32x4*)(a.att + m * K + 8 * l16) : z;
+        at[i][1] = m < a.M ? *(const f32x4*)(a.att + m * K + 8 * l16 + 4) : z;
+    }
+    bf16x8 wnext[3][KS];
+    load_tile(a.w_proj, wnext);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split_store(grp + 32 * i, l16, at[i][0], at[i][1]);
+    stage_barrier();
+    // ---- x2 = proj(att) + x
+    f32x4 x2[4];
+    {
+        bf16x8 wc[3][KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+        load_tile(a.w_fc1, wnext);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) x2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm(wc, x2);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            x2[mt] += xr[mt];
+            *(f32x4*)swz(s2, mt * 16 + c, n) = x2[mt];
+        }
+    }
+    stage_barrier();
+    // ---- LN(x2) -> split planes
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = grp + 32 * i;
+        f32x4 v[2] = {*(const f32x4*)swz(s2, r, 8 * l16), *(const f32x4*)swz(s2, r, 8 * l16 + 4)};
+        float sum = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+        sum = row16_sum(sum);
+        const float mean = sum / (float)K;
+        float var = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var = fmaf(d, d, var); }
+        var = row16_sum(var);
+        const float rstd = 1.0f / sqrtf(var / (float)K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = (v[u][e] - mean) * rstd * lg[u][e] + lb[u][e];
+        split_store(r, l16, v[0], v[1]);
+    }
+    stage_barrier();
+    // ---- hid = relu(fc1(LN(x2)) + b1) -> s2 -> split planes
+    {
+        bf16x8 wc[3][KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wc[p][s] = wnext[p][s];
+        load_tile(a.w_fc2, wnext);
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm(wc, acc);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 v = acc[mt] + bias1;
+            v = f32x4{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+            *(f32x4*)swz(s2, mt * 16 + c, n) = v;
+        }
+    }
+    stage_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = grp + 32 * i;
+        split_store(r, l16, *(const f32x4*)swz(s2, r, 8 * l16), *(const f32x4*)swz(s2, r, 8 * l16 + 4));
+    }
+    stage_barrier();
+    // ---- x = fc2(hid) + b2 + x2
+    {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm(wnext, acc);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const long long m = m0 + mt * 16 + c;
+            if (m < a.M) *(f32x4*)(a.x + m * K + n) = (acc[mt] + bias2) + x2[mt];
         }
     }
 }
@@ -923,13 +1082,15 @@ struct StageArgs {
     const float* mask; const float2* rope;
     int S, num_cls, mask_div, times_div, times_stride;
     float scale;
+    // table stage without the assembled token tensor (model.py:374-378 and the gather after the stage): when `table_tok` is set, row 0
+    // of sequence (b, t) is read from x[(b*T + t)] (the ball token), row 1 + n from table_tok[b*NT + n], and only row 0 is written back
+    // -- to the same place.  14 of 15 token rows of the stage never exist in HBM.
+    const float* table_tok; int T, NT;
     long long* stamps;                 // TTUP_STAGE_STAMPS=1: [layer][12] clock values of workgroup 0 / wave 0 at the phase boundaries (else null)
 };
 constexpr int STAGE_QS = 260;         // floats per row of the q | k tile: 4 heads x 64 + 4 (1040 B = 65 slots of 16 B: consecutive rows fall on consecutive slots)
 constexpr int STAGE_VS = 84;          // floats per row of V^T [head][dim][token]: 4 x 84 = 16 (mod 64), so a transposed store of 4 dims x 16 tokens per lane group is conflict-free
 constexpr size_t STAGE_LDS = (size_t)3 * 64 * 128 * 2 + (size_t)64 * STAGE_QS * 4 + (size_t)4 * 32 * STAGE_VS * 4 + 8 * 16 * 4;
-// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (a __syncthreads() drains vmcnt too)
-__device__ __forceinline__ void stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t xh[];       // split planes
     constexpr int BM = 64, K = 128, PLANE = BM * K, KS = K / 32, HD = 32, QS = STAGE_QS, VS = STAGE_VS;
@@ -1014,9 +1175,11 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
     for (int mt = 0; mt < 4; ++mt) {
         const int r = mt * 16 + c;
         const long long m = m0 + r;
-        xr[mt] = (r < ROWS && m < M) ? *(const f32x4*)(a.x + m * K + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         const int sl = r / S, jt = r - sl * S;
         const long long sq = seq0 + sl;
+        const float* src = a.x + m * K;
+        if (a.table_tok) src = jt == 0 ? a.x + sq * K : a.table_tok + ((sq < a.n_seq ? sq / a.T : 0) * a.NT + jt - 1) * K;
+        xr[mt] = (r < ROWS && m < M) ? *(const f32x4*)(src + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         rot[mt] = r < ROWS && sq < a.n_seq && jt >= a.num_cls;
         rrow[mt] = a.rope + ((size_t)((rot[mt] ? sq : 0) / a.times_div) * a.times_stride + (rot[mt] ? jt - a.num_cls : 0)) * (HD / 2);
         vcol[mt] = r < ROWS ? sl * S4 + jt : -1;             // the row's column in V^T (rows of no sequence are not stored)
@@ -1262,7 +1425,12 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
     for (int mt = 0; mt < 4; ++mt) {
         const int r = mt * 16 + c;
         const long long m = m0 + r;
-        if (r < ROWS && m < M) *(f32x4*)(a.x + m * K + n) = xr[mt];
+        if (!(r < ROWS && m < M)) continue;
+        if (!a.table_tok) *(f32x4*)(a.x + m * K + n) = xr[mt];
+        else {
+            const int sl = r / S;
+            if (r == sl * S) *(f32x4*)(a.x + (seq0 + sl) * K + n) = xr[mt];
+        }
     }
 }
 
@@ -1620,8 +1788,14 @@ int run_layer(ttup_uplift* net, const Layer& L, float* x, long long tokens, int 
             if ((rc = ensure_max_lds((const void*)mlp_block_x3_kernel<2>, 160 * 1024))) return rc;
             hipLaunchKernelGGL(mlp_block_x3_kernel<2>, grid, dim3(512), smem, st, a);
         } else {
-            if ((rc = ensure_max_lds((const void*)mlp_block_x3_kernel<1>, 160 * 1024))) return rc;
-            hipLaunchKernelGGL(mlp_block_x3_kernel<1>, grid, dim3(256), smem, st, a);
+            static const bool four = getenv("TTUP_UPLIFT_MLP_4WAVES") != nullptr;          // the round-3 form: 4 waves, two n-tiles each
+            if (four) {
+                if ((rc = ensure_max_lds((const void*)mlp_block_x3_kernel<1>, 160 * 1024))) return rc;
+                hipLaunchKernelGGL(mlp_block_x3_kernel<1>, grid, dim3(256), smem, st, a);
+            } else {
+                if ((rc = ensure_max_lds((const void*)mlp_block8_x3_kernel, 160 * 1024))) return rc;
+                hipLaunchKernelGGL(mlp_block8_x3_kernel, grid, dim3(512), smem, st, a);
+            }
         }
         TTUP_LAUNCH_CHECK();
         return TTUP_OK;
@@ -1647,7 +1821,11 @@ void make_stage(ttup_uplift* net, const std::vector<Layer>& layers, std::vector<
 // bound by the L1 traffic of its weight fragments: every m-tile wave streams its head's weights) + 38 k (MLP block); B = 10 000,
 // T = 120: 50.1 k -> 55.4 k trajectories/s, B = 4096, T = 50: 123 k -> 149 k.  TTUP_UPLIFT_STAGE_WG caps the launch size it is used for.
 int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vector<StageLayerW>& stage, float* x, long long tokens, int n_seq, int S, int num_cls,
-              const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st) {
+              const float* mask, int mask_div, const float2* rope, int times_div, int times_stride, hipStream_t st,
+              const float* table_tok = nullptr, int T = 0, int NT = 0, bool* fused_tokens = nullptr) {
+    // (table_tok: the table stage.  When the stage kernel runs, `x` is then the ball-token tensor [n_seq][D], read and written in
+    // place, and *fused_tokens = true; otherwise the caller assembles / gathers around the per-layer kernels, which get `x` as usual)
+    if (fused_tokens) *fused_tokens = false;
     static const bool off = getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_UPLIFT_UNFUSED") != nullptr || getenv("TTUP_UPLIFT_NO_STAGE") != nullptr;
     static const long long max_wg = getenv("TTUP_UPLIFT_STAGE_WG") ? atoll(getenv("TTUP_UPLIFT_STAGE_WG")) : (1ll << 40);
     if (!stage.empty() && !off && S <= 64 && n_seq > 0 && (64 / S) * ((S + 3) & ~3) <= STAGE_VS) {          // (V^T holds every sequence of the tile at a multiple of 4)
@@ -1659,6 +1837,8 @@ int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vec
             memcpy(a.layers, stage.data(), stage.size() * sizeof(StageLayerW));
             a.mask = mask; a.rope = rope; a.S = S; a.num_cls = num_cls; a.mask_div = mask_div; a.times_div = times_div; a.times_stride = times_stride;
             a.scale = 1.0f / sqrtf((float)net->hd);
+            a.table_tok = table_tok; a.T = T; a.NT = NT;
+            if (fused_tokens) *fused_tokens = table_tok != nullptr;
             if (int rc = ensure_max_lds((const void*)stage_x3_kernel, 160 * 1024)) return rc;
             static const bool want_stamps = getenv("TTUP_STAGE_STAMPS") != nullptr;
             static long long* stamps_dev = nullptr;
@@ -1686,6 +1866,7 @@ int run_stage(ttup_uplift* net, const std::vector<Layer>& layers, const std::vec
             return TTUP_OK;
         }
     }
+    if (table_tok) return TTUP_OK;          // declined (*fused_tokens is false, nothing launched): the caller assembles the tokens and calls again
     for (const Layer& L : layers)
         if (int rc = run_layer(net, L, x, tokens, n_seq, S, num_cls, mask, mask_div, rope, times_div, times_stride, st)) return rc;
     return TTUP_OK;
@@ -1718,17 +1899,21 @@ int forward_chunk(ttup_uplift* net, const float* ball, const float* table, const
     if ((rc = run_linear(net->ball_embed.fc2, net->h1, D, (long long)B * T, nullptr, nullptr, 0, nullptr, 0, net->tok, D, st))) return rc;
     if ((rc = run_linear(net->table_embed.fc1, net->txy, 2, (long long)B * NT, nullptr, nullptr, 1, nullptr, 0, net->h1, D, st))) return rc;
     if ((rc = run_linear(net->table_embed.fc2, net->h1, D, (long long)B * NT, nullptr, nullptr, 0, nullptr, 0, net->ttok, D, st))) return rc;
-    // table stage
+    // table stage: every (b, t) is a 14-token sequence [ball token, 13 table tokens]; its row 0 replaces the ball token afterwards
     const long long tok1 = (long long)B * T * S1;
-    {
+    static const bool no_token_fusion = getenv("TTUP_UPLIFT_ASSEMBLE") != nullptr;
+    bool fused = false;
+    if (!no_token_fusion) {
+        // stage kernel: reads the two token tensors itself and writes row 0 only (nothing has been launched if it declines)
+        if ((rc = run_stage(net, net->pos_layers, net->stage_pos, net->tok, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st, net->ttok, T, NT, &fused))) return rc;
+    }
+    if (!fused) {
         const long long total = tok1 * D;
         hipLaunchKernelGGL(assemble_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->tok, net->ttok, net->x, T, NT, D, total);
         TTUP_LAUNCH_CHECK();
-    }
-    if ((rc = run_stage(net, net->pos_layers, net->stage_pos, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st))) return rc;
-    {
-        const long long total = (long long)B * T * D;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, net->x, net->tok, D, S1, total);
+        if ((rc = run_stage(net, net->pos_layers, net->stage_pos, net->x, tok1, B * T, S1, 1, net->tmask, T, net->table_rope, 1, 0, st))) return rc;
+        const long long total2 = (long long)B * T * D;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, st, net->x, net->tok, D, S1, total2);
         TTUP_LAUNCH_CHECK();
     }
     // temporal stage (tok is [B*T][D])
