@@ -877,6 +877,134 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnMArgs a) {
     }
 }
 
+// The same attention for sequences of at most 128 tokens (KT <= 8 key tiles: the 121-token trajectories of the headline and of config 3)
+// in the form the stage kernel's attention phase arrived at: all score tiles of a query tile are computed ONCE, as independent MFMA
+// chains (groups of four key tiles), and stay in registers between the maximum and the exponentials; the mask is two ballots per wave
+// instead of a global load per score; V is staged TRANSPOSED ([dim][token], row stride SP + 4) so that the P V operand of four keys is
+// one 16-byte read; exponentials on v_exp_f32.  Per output the operation order is attention_mfma_kernel's.  NG = groups of four key tiles.
+template <int NG>
+__global__ __launch_bounds__(256) void attention_mfma8_kernel(AttnMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // K [SP][36] | V^T [32][SP + 4] | inv [4 waves][16]
+    constexpr int HD = 32, D = 128, D3 = 384, KS = ATTM_KS, NK = NG * 4;
+    const int S = a.S, KT = (S + 15) / 16, SP = KT * 16, VS = SP + 4;
+    float* sk = sm;
+    float* svt = sm + SP * KS;
+    float* sinv = svt + HD * VS;
+    const int tid = ttup_tid_x(), lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int h = ttup_bid_y(), seq = ttup_bid_z();
+    const float* base = a.qkv + (size_t)seq * S * D3 + h * HD;
+    const float2* rbase = a.rope + (size_t)(seq / a.times_div) * a.times_stride * (HD / 2);
+    const float* mrow = a.mask + (size_t)(seq / a.mask_div) * S;
+    // ---- stage K (rotated) and V^T: 8 threads per token, one float4 of each per thread; tokens past S are zero
+    for (int u = tid; u < SP * 8; u += 256) {
+        const int j = u >> 3, part = u & 7;
+        f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+        if (j < S) {
+            k = *(const f32x4*)(base + (size_t)j * D3 + D + part * 4);
+            v = *(const f32x4*)(base + (size_t)j * D3 + 2 * D + part * 4);
+            if (j >= a.num_cls) {
+                const f32x4 cs = *(const f32x4*)(rbase + (size_t)(j - a.num_cls) * (HD / 2) + part * 2);
+                k = f32x4{k[0] * cs[0] - k[1] * cs[1], k[0] * cs[1] + k[1] * cs[0], k[2] * cs[2] - k[3] * cs[3], k[2] * cs[3] + k[3] * cs[2]};
+            }
+        }
+        *(f32x4*)(sk + j * KS + part * 4) = k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) svt[(part * 4 + e) * VS + j] = v[e];
+    }
+    // bit j of (lo, hi): token j / 64 + j is a valid key and query
+    const unsigned long long lo = __builtin_amdgcn_ballot_w64(lane < S && mrow[lane < S ? lane : 0] == 0.f);
+    const unsigned long long hi = __builtin_amdgcn_ballot_w64(64 + lane < S && mrow[64 + lane < S ? 64 + lane : 0] == 0.f);
+    __syncthreads();
+    const int qt = ttup_bid_x() * 4 + wave;                 // this wave's tile of 16 queries
+    if (qt * 16 >= S) return;                                // (no barrier below: waves are independent from here on)
+    const int i = qt * 16 + c;                               // the lane's query
+    const bool row_ok = i < S && (((i < 64 ? lo : hi) >> (i & 63)) & 1);
+    f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+    if (i < S) {
+        q0 = *(const f32x4*)(base + (size_t)i * D3 + 8 * q);
+        q1 = *(const f32x4*)(base + (size_t)i * D3 + 8 * q + 4);
+        if (i >= a.num_cls) {
+            const float2* rp = rbase + (size_t)(i - a.num_cls) * (HD / 2) + 4 * q;
+            const f32x4 c0 = *(const f32x4*)rp, c1 = *(const f32x4*)(rp + 2);
+            q0 = f32x4{q0[0] * c0[0] - q0[1] * c0[1], q0[0] * c0[1] + q0[1] * c0[0], q0[2] * c0[2] - q0[3] * c0[3], q0[2] * c0[3] + q0[3] * c0[2]};
+            q1 = f32x4{q1[0] * c1[0] - q1[1] * c1[1], q1[0] * c1[1] + q1[1] * c1[0], q1[2] * c1[2] - q1[3] * c1[3], q1[2] * c1[3] + q1[3] * c1[2]};
+        }
+    }
+    // ---- scores^T = K Q^T for every key tile (tiles past KT repeat the last one and are masked: their bits are 0)
+    f32x4 sc[NK];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        f32x4 kk[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = g * 4 + t < KT ? g * 4 + t : KT - 1;
+            const float* kp = sk + (kt * 16 + c) * KS + 8 * q;
+            kk[t][0] = *(const f32x4*)kp; kk[t][1] = *(const f32x4*)(kp + 4);
+            sc[g * 4 + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc[g * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t][0][e], q0[e], sc[g * 4 + t], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc[g * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t][1][e], q1[e], sc[g * 4 + t], 0, 0, 0);
+    }
+    // sc[kt][r] = q_i . k_j for j = kt*16 + 4q + r
+    const unsigned long long lo_q = lo >> (4 * q), hi_q = hi >> (4 * q);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool col_ok = kt < KT && (((kt < 4 ? lo_q : hi_q) >> ((kt & 3) * 16 + r)) & 1);
+            sc[kt][r] = col_ok ? sc[kt][r] * a.scale : -INFINITY;
+            mx = sc[kt][r] > mx ? sc[kt][r] : mx;
+        }
+    { const float o = __shfl_xor(mx, 16, 64); mx = o > mx ? o : mx; }
+    { const float o = __shfl_xor(mx, 32, 64); mx = o > mx ? o : mx; }
+    // ---- p = exp(s - max), out += P V with k index (step s, lane group q) <-> key kt*16 + 4q + s: the A operand is the lane's own p
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    const float* vbase = svt + c * VS + 4 * q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        f32x4 vv[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = g * 4 + t < KT ? g * 4 + t : KT - 1;
+            vv[t][0] = *(const f32x4*)(vbase + kt * 16); vv[t][1] = *(const f32x4*)(vbase + 16 * VS + kt * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = (row_ok && sc[g * 4 + t][r] > -INFINITY) ? __expf(sc[g * 4 + t][r] - mx) : 0.f; den += pr[r]; }
+#pragma unroll
+            for (int s2_ = 0; s2_ < 4; ++s2_) {
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vv[t][0][s2_], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[s2_], vv[t][1][s2_], o1, 0, 0, 0);
+            }
+        }
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    if (q == 0) sinv[wave * 16 + c] = den > 0.f ? 1.f / den : 0.f;          // a fully masked query row yields zeros (torch SDPA semantics)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int io = qt * 16 + 4 * q + r;
+        if (io >= S) continue;
+        const float inv = sinv[wave * 16 + 4 * q + r];
+        float* op = a.out + ((size_t)seq * S + io) * D + h * HD;
+        op[c] = o0[r] * inv;
+        op[16 + c] = o1[r] * inv;
+    }
+}
+
 // ------------------------------------------------------------------ fused attention half of a layer, short sequences
 // att = softmax-attention(RoPE(q), RoPE(k), v) with qkv = LN(x) Wqkv^T + b, for sequences of S <= 16 tokens (the table stage: 14),
 // D = 128, 4 heads of 32: ONE kernel instead of the qkv linear + the attention launch, and the 1536 bytes of qkv per token never
@@ -1730,6 +1858,14 @@ int run_attention(ttup_uplift* net, const float* qkv, float* out, int n_seq, int
         m.qkv = qkv; m.out = out; m.mask = mask; m.rope = rope; m.n_seq = n_seq; m.S = S; m.num_cls = num_cls;
         m.mask_div = mask_div; m.times_div = times_div; m.times_stride = times_stride; m.scale = a.scale;
         const int KT = (S + 15) / 16;
+        static const bool two_pass = getenv("TTUP_UPLIFT_ATTENTION_2PASS") != nullptr;          // the first matrix-pipe form (cross-check)
+        if (KT <= 8 && !two_pass) {
+            const size_t smem8 = ((size_t)KT * 16 * ATTM_KS + (size_t)32 * (KT * 16 + 4) + 64) * sizeof(float);
+            if (KT <= 4) hipLaunchKernelGGL(attention_mfma8_kernel<1>, dim3((KT + 3) / 4, net->heads, n_seq), dim3(256), smem8, st, m);
+            else hipLaunchKernelGGL(attention_mfma8_kernel<2>, dim3((KT + 3) / 4, net->heads, n_seq), dim3(256), smem8, st, m);
+            TTUP_LAUNCH_CHECK();
+            return TTUP_OK;
+        }
         const size_t smem = ((size_t)2 * KT * 16 * ATTM_KS + 64) * sizeof(float);
         if (int rc = ensure_max_lds((const void*)attention_mfma_kernel, 160 * 1024)) return rc;
         hipLaunchKernelGGL(attention_mfma_kernel, dim3((KT + 3) / 4, net->heads, n_seq), dim3(256), smem, st, m);
