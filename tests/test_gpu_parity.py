@@ -285,6 +285,40 @@ def test_uplift_stage_kernel_against_the_per_layer_kernels():
     assert worst <= 2e-6
 
 
+@pytest.mark.parametrize('variant', ['TTUP_UPLIFT_ASSEMBLE', 'TTUP_UPLIFT_ATTENTION_2PASS', 'TTUP_UPLIFT_MLP_4WAVES'])
+def test_uplift_kernel_variants_agree(variant):
+    """Round 4 replaced three pieces of the uplift forward by faster forms and kept the first ones behind environment switches: the
+    table stage reading its tokens in place vs the assembled token tensor, the single-pass matrix-pipe attention (<= 128 tokens) vs the
+    two-pass one, the 8-wave MLP block vs the 4-wave one.  Same arithmetic per output: the results agree within 2e-6 relative, on
+    lengths with 5 .. 8 key tiles, ragged masks and a cls row (the spin stage's 121 + 1 tokens)."""
+    import subprocess, sys, tempfile
+    from e2e_common import ragged_trajectories
+    shapes = [(3, 118, 3), (2, 97, 3), (5, 69, 1), (2, 127, 1)]          # lengths 121, 100, 70, 128
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from upliftingtabletennis_amd import uplift, weights; from e2e_common import ragged_trajectories;'
+            'sd = weights.random_uplift_state_dict(13, "large"); net = uplift.get_model("connectstage", "large", "dynamic", "new", state_dict=sd, max_batch=8, max_len=128);'
+            'out = {};\n'
+            'for (b, t, pad) in %r:\n'
+            '    a = [torch.from_numpy(v) for v in ragged_trajectories(b, t, pad)]\n'
+            '    rot, pos = net(*a)\n'
+            '    out["rot_%%d_%%d" %% (b, t)] = rot.cpu().numpy(); out["pos_%%d_%%d" %% (b, t)] = pos.cpu().numpy()\n'
+            'np.savez(sys.argv[1], **out)' % (root, os.path.join(root, 'tests'), shapes))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (('default', {}), ('variant', {variant: '1'})):
+            e = dict(os.environ); e.update(env)
+            out = os.path.join(td, tag + '.npz')
+            subprocess.run([sys.executable, '-c', code, out], check=True, env=e, timeout=600)
+            res[tag] = dict(np.load(out))
+    worst = 0.0
+    for k, x in res['default'].items():
+        y = res['variant'][k]
+        assert np.isfinite(x).all() and np.isfinite(y).all()
+        worst = max(worst, float(np.abs(x - y).max() / np.abs(x).max()))
+    print('\n%s=1 vs default: worst relative difference %.3g' % (variant, worst))
+    assert worst <= 2e-6
+
+
 # ------------------------------------------------------------------------------------------ boundary classes
 def test_interface_surface():
     from upliftingtabletennis_amd.interface import BallDetector, UpliftingModel
