@@ -285,11 +285,11 @@ def test_uplift_stage_kernel_against_the_per_layer_kernels():
     assert worst <= 2e-6
 
 
-@pytest.mark.parametrize('variant', ['TTUP_UPLIFT_ASSEMBLE', 'TTUP_UPLIFT_ATTENTION_2PASS', 'TTUP_UPLIFT_MLP_4WAVES'])
+@pytest.mark.parametrize('variant', ['TTUP_UPLIFT_ASSEMBLE', 'TTUP_UPLIFT_ATTENTION_2PASS', 'TTUP_UPLIFT_MLP_4WAVES', 'TTUP_UPLIFT_QKV_LINEAR'])
 def test_uplift_kernel_variants_agree(variant):
-    """Round 4 replaced three pieces of the uplift forward by faster forms and kept the first ones behind environment switches: the
+    """Round 4 replaced four pieces of the uplift forward by faster forms and kept the first ones behind environment switches: the
     table stage reading its tokens in place vs the assembled token tensor, the single-pass matrix-pipe attention (<= 128 tokens) vs the
-    two-pass one, the 8-wave MLP block vs the 4-wave one.  Same arithmetic per output: the results agree within 2e-6 relative, on
+    two-pass one, the 8-wave MLP block vs the 4-wave one, the 8-wave LN + qkv block (small launches) vs the general linear kernel.  Same arithmetic per output: the results agree within 2e-6 relative, on
     lengths with 5 .. 8 key tiles, ragged masks and a cls row (the spin stage's 121 + 1 tokens)."""
     import subprocess, sys, tempfile
     from e2e_common import ragged_trajectories
