@@ -1500,10 +1500,6 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                     kk[kt][0] = *(const f32x4*)kp; kk[kt][1] = *(const f32x4*)(kp + 4);
                     sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                // V^T of keys kt*16 + 4q .. + 3 (columns past the sequence hold other tokens, zeros or -- past the array -- the
-                // normalisers: their p is 0 and all of it is finite, the storage having been cleared once)
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) { vv[kt][0] = *(const f32x4*)(vbase + kt * 16); vv[kt][1] = *(const f32x4*)(vbase + kt * 16 + 16 * VS); }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1512,6 +1508,10 @@ __global__ __launch_bounds__(512) void stage_x3_kernel(StageArgs a) {
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int kt = 0; kt < NKT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[kt][1][e], q1[e], sc[kt], 0, 0, 0);
+                // V^T of keys kt*16 + 4q .. + 3, requested once the K fragments are dead (columns past the sequence hold other tokens,
+                // zeros or -- past the array -- the normalisers: their p is 0 and all of it is finite, the storage having been cleared once)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) { vv[kt][0] = *(const f32x4*)(vbase + kt * 16); vv[kt][1] = *(const f32x4*)(vbase + kt * 16 + 16 * VS); }
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
