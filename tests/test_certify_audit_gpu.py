@@ -204,6 +204,17 @@ def test_widening_within_the_guard_factor_reruns_only_guarded_heatmaps():
     assert worker.recertified_heatmaps - before == n_guard and worker.recertified_clips == 0
     ref_idx, ref_win, ref_xyv = _fp32_peaks(sd, fr, (W, H))
     assert torch.equal(t['idx'], ref_idx)
+    # the status of a re-run heatmap is the RE-RUN's: 1 only where its window holds fp32 values (crops or the full-frame repair), 0
+    # where it is a single candidate under the widened eps and keeps its bf16 window (a 60-clip soak on noisier weights found two
+    # such heatmaps labelled 1: tools/soak_debug.py)
+    st = np.asarray(o['status'])
+    assert set(np.unique(st)) <= {0, 1}
+    n_fp32 = 0
+    for k in range(st.shape[0]):
+        if st[k] != 0:
+            n_fp32 += 1
+            assert torch.equal(t['win'][k].reshape(-1), ref_win[k].reshape(-1)), (k, int(raw[k]))
+    print('%d of %d windows hold fp32 values and equal the fp32 path\'s' % (n_fp32, st.shape[0]))
     # the same clip run from scratch under the widened eps gives the same detections
     again = worker.process_clip(fr, table_px, 60.0)
     assert torch.equal(again['xyv'], o['xyv'])

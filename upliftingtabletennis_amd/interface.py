@@ -150,7 +150,6 @@ class _CertifiedDetector:
                 todo = m.recertify_subset(idx, win, st, eps_used, fr)       # only the heatmaps whose guard band is not empty
                 if todo is None:
                     continue                                              # eps grew past the guard factor: the whole call again
-                st[todo] = 1
             m.fix_uncertified(idx, win, frames_u8=fr, status=st)
             return idx, win
 
@@ -181,8 +180,7 @@ class _CertifiedDetector:
                     changed.add(k)
                     continue
                 if todo.size:
-                    st[todo] = 1
-                    changed.add(k)
+                    changed.add(k)          # (st[todo] holds the re-runs' own status now: settled, 0 or 1)
             if ((st & 3) == 2).any():
                 # rare: crop budget exceeded -> those samples on the full-frame fp32 path (with the call's own status)
                 m.fix_uncertified(c['idx'], c['win'], frames_u8=fr, status=st)

@@ -245,7 +245,7 @@ class StreamWorker:
         if todo.size:
             sel = torch.as_tensor(todo, device=self.device)
             xyv[sel] = self._refine.refine_windows_device(idx[sel], win[sel], self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
-            status_host[todo] = 1          # settled under the current eps (repaired inside when over budget)
+            # (status_host[todo] now holds the re-runs' own status: 0 = single candidate under the current eps, 1 = fp32 values)
         return xyv
 
     def _detect_blocking(self, frames_u8, full=False):

@@ -309,8 +309,11 @@ class WASBNet:
     def recertify_subset(self, idx, win, status_raw, eps_used, frames_u8):
         """eps has been widened since the call that produced (idx, win, status_raw) from the uint8 clip `frames_u8`.  Heatmaps whose
         guard band was empty keep their certified result (same candidate set under any eps up to GUARD * eps_used); the others are
-        run again one sample at a time under the current eps and repaired on the fp32 handle if they overflow the budget.  Returns the indices re-run, or None when eps grew past the guard factor (the caller then re-runs the
-        whole call; also when more than SUBSET_MAX_SHARE of the heatmaps are guarded)."""
+        run again one sample at a time under the current eps and repaired on the fp32 handle if they overflow the budget; their entries
+        of `status_raw` (a host array) are REPLACED by the re-run's own status -- 0 = single candidate (bf16 window), 1 = settled on fp32
+        values (crops, or the full-frame repair) -- so the status keeps saying which windows hold fp32 values.  Returns the indices
+        re-run, or None when eps grew past the guard factor (the caller then re-runs the whole call; also when more than
+        SUBSET_MAX_SHARE of the heatmaps are guarded)."""
         if self.eps > eps_used * self.GUARD * (1 - 1e-6):
             return None
         st = status_raw.cpu().numpy() if torch.is_tensor(status_raw) else np.asarray(status_raw)
@@ -333,10 +336,14 @@ class WASBNet:
             t = int(t)
             fr = frames_u8[t:t + self.NF]
             _, i1, w1 = h.forward_frames(fr, want_heatmap=False)
-            h.fix_uncertified(i1, w1, frames_u8=fr, status=h.certify_status(K))
+            s1 = h.certify_status(K)
+            s1 = (s1.cpu().numpy() if torch.is_tensor(s1) else np.asarray(s1)) & 3
+            h.fix_uncertified(i1, w1, frames_u8=fr, status=s1)
             for m in todo[todo // K == t]:
                 idx[int(m)] = i1[int(m) - t * K]
                 win[int(m)] = w1[int(m) - t * K]
+                if isinstance(status_raw, np.ndarray):
+                    status_raw[int(m)] = 0 if s1[int(m) - t * K] == 0 else 1
         return todo
 
     def internal_streams(self):
