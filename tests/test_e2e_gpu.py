@@ -123,3 +123,17 @@ def test_e2e_full_size_worker_and_hub_match_reference_chain(golden, tmp_path, mo
     dev = check_spin_pos(spin.cpu().numpy(), pos3d, g, 'full', REL_3D[False])
     print('[e2e full, %s] hub predict: table xy %.2e network px; pos3d %.2e, |spin| %.2e, spin_z %.2e, spin_xy %.2e rel' % ('exact windows' if exact else 'production', d_table, *dev))
     assert d_table <= XY_NET_PX[False] and n == len(images)
+
+
+def test_hub_clip_lengths_around_the_chunk_boundaries():
+    """tools/hub_lengths_probe.py on five clip lengths (one triple, a partial second chunk, the 48-frame case + 1, three chunks + 1,
+    the long-chunk regime): the overlapped clip path gives the detections of the detectors' own clip calls and `predict` the result
+    (or the reference's ValueError for clips of more than 51 detections) of the serial path, bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e['TTUP_PROBE_LENGTHS'] = '3,25,49,73,130'; e['TTUP_SYNTHETIC_WEIGHTS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'hub_lengths_probe.py')], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if 'frames:' in l or 'mismatching' in l]
+    print('\n' + '\n'.join(lines))
+    assert lines[-1].strip() == 'mismatching lengths: 0' and len(lines) == 6
