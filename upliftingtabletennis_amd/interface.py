@@ -335,6 +335,25 @@ class UpliftingModel:
         return self.predict_without_normalization(ball_coords, table_coords, torch.tensor(mask).to(self.device), times)
 
     def predict_without_normalization(self, ball_coords, table_coords, mask, times):
+        host = all(isinstance(a, np.ndarray) or (torch.is_tensor(a) and a.device.type == 'cpu') for a in (ball_coords, table_coords, mask, times))
+        if host and np.asarray(ball_coords).ndim == 2:
+            # one rally from host arrays (what the pipeline hands over): padded on the host, ONE upload, the number of valid steps from the
+            # host mask -- instead of four uploads, four pad kernels and a device-side mask.sum().item() (three host round trips less)
+            b_, t_, m_, tm_ = [np.asarray(a, dtype=np.float32) for a in (ball_coords, table_coords, mask, times)]
+            n = m_.shape[-1]
+            buf = torch.zeros((4 * n + 39,), dtype=torch.float32).pin_memory()
+            hb = buf.numpy()
+            hb[:2 * b_.shape[0]] = b_.reshape(-1); hb[2 * n:2 * n + 39] = t_.reshape(-1)
+            hb[2 * n + 39:3 * n + 39] = m_.reshape(-1); hb[3 * n + 39:3 * n + 39 + tm_.shape[0]] = tm_.reshape(-1)
+            # the reference's mask check (uplifting/model.py:541-546) on the host copy: no device round trip for it
+            if not (m_.size and float(m_.min()) == 0.0 and float(m_.max()) == 1.0):
+                raise ValueError('wrong format for masks. Should be 0, 1 or -1e9, 0.')
+            dev = buf.to(self.device, non_blocking=True)
+            pred_rotation, pred_position = self.model(dev[:2 * n].view(1, n, 2), dev[2 * n:2 * n + 39].view(1, 13, 3), dev[2 * n + 39:3 * n + 39].view(1, n),
+                                                      dev[3 * n + 39:].view(1, n), check_mask=False)
+            pred_rotation_local = uplift.transform_rotationaxes(pred_rotation, pred_position.clone()) if self.transform_mode == 'global' else pred_rotation
+            t_prime = int(m_.sum())
+            return pred_rotation_local.squeeze(0), pred_position[0, :t_prime, :].cpu().numpy()
         ball_coords, table_coords, mask, times = [torch.as_tensor(a).to(self.device, torch.float32) for a in (ball_coords, table_coords, mask, times)]
         if ball_coords.dim() == 2:      # (N,2) -> pad to the mask length like the reference's callers do
             n = mask.shape[-1]
