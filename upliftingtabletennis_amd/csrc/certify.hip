@@ -81,10 +81,19 @@ constexpr int CERT_MAX_K = 512;
 constexpr int CERT_MAX_FRAME_CROPS = 16;
 constexpr int CERT_PENDING = 8;          // provisional status of a heatmap whose crops wait for their ids on the shared list
 __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
-    __shared__ int s_idx[CERT_MAX_K];
+    // The whole wave works on the assignment (round 4, second half): in its first form lane 0 walked the sorted list in GLOBAL memory --
+    // a dependent load per candidate, a read-modify-write per candidate for the final crop ids: 19 us on average and up to 63 us per
+    // micro-batch on varied content with one lane; 12 / 26 us in this form.  (The 0.18 ms average / 0.7 ms maximum this kernel shows
+    // in the two-lane kernel trace is NOT its own time: its eight small workgroups wait for a slot while the other lane's persistent
+    // kernels -- two 256-VGPR waves per SIMD on every CU -- run to their end; the trace counts from the dispatch.)  Same decisions as
+    // the serial walk: a candidate goes to the FIRST crop of the frame's list whose core holds it; the first candidate (in index
+    // order) that no crop holds opens a new one.
+    __shared__ int s_idx[CERT_MAX_K];            // as scanned, then the crop slot of every sorted candidate
     __shared__ float s_bf[CERT_MAX_K];
+    __shared__ int s_sorted[CERT_MAX_K];
     __shared__ int my_y0[CERT_MAX_FRAME_CROPS], my_x0[CERT_MAX_FRAME_CROPS];
-    __shared__ int n_my_s;
+    __shared__ int n_my_s, s_base;
+    constexpr int PER = CERT_MAX_K / 64;         // candidates per lane
     const int lane = threadIdx.x;
     const int frame = a.frame0 + blockIdx.x;
     if (lane == 0) n_my_s = 0;
@@ -99,44 +108,60 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
         int* ci = a.cand_idx + (size_t)map * a.K;
         float* cb = a.cand_bf + (size_t)map * a.K;
-        __syncthreads();                                          // (the previous channel's lane-0 pass has finished with s_idx)
+        __syncthreads();                                          // (the previous channel is done with the shared lists)
         for (int i = lane; i < cnt; i += 64) { s_idx[i] = ci[i]; s_bf[i] = cb[i]; }
         __syncthreads();
         for (int i = lane; i < cnt; i += 64) {
             const int v = s_idx[i];
             int rank = 0;
             for (int j = 0; j < cnt; ++j) rank += s_idx[j] < v;          // pixel indices are distinct: ranks are a permutation
-            ci[rank] = v; cb[rank] = s_bf[i];
+            ci[rank] = v; cb[rank] = s_bf[i]; s_sorted[rank] = v;
         }
         __syncthreads();
-        if (lane != 0) continue;
-        if (cnt == 1) atomicAdd(&a.stats[7], 1ull);
+        if (lane == 0 && cnt == 1) atomicAdd(&a.stats[7], 1ull);
+        // the lane's candidates lane, lane + 64, ...: position and the slot of the first crop that holds them (-1: none yet)
+        int cy[PER], cx[PER], found[PER];
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int i = lane + 64 * m;
+            const int v = i < cnt ? s_sorted[i] : 0;
+            cy[m] = v / a.W; cx[m] = v - cy[m] * a.W; found[m] = -1;
+        }
         // crops the frame has so far (from its earlier channels) are tried first; new ones are added behind them and dropped again
-        // if this heatmap turns out to need more than its budget (a heatmap that overflows after three crops used to leave those
-        // three on the list: wasted fp32 passes and budget taken from the heatmaps behind it)
+        // if this heatmap turns out to need more than its budget
         int n_my = n_my_s;
         const int n_before = n_my;
         bool over = false;
-        for (int k = 0; k < cnt && !over; ++k) {
-            const int cy = ci[k] / a.W, cx = ci[k] % a.W;
-            int found = -1;
-            for (int c = 0; c < n_my && found < 0; ++c) {
+        int c_from = 0;                                           // crops [c_from, n_my) have not been tried on the uncovered candidates yet
+        while (true) {
+            for (int c = c_from; c < n_my; ++c) {
                 int ylo, yhi, xlo, xhi;
                 core_range(my_y0[c], a.Hc, a.H, a.R, ylo, yhi);
                 core_range(my_x0[c], a.Wc, a.W, a.R, xlo, xhi);
-                if (cy >= ylo && cy < yhi && cx >= xlo && cx < xhi) found = c;
+#pragma unroll
+                for (int m = 0; m < PER; ++m)
+                    if (found[m] < 0 && cy[m] >= ylo && cy[m] < yhi && cx[m] >= xlo && cx[m] < xhi) found[m] = c;
             }
-            if (found < 0) {
-                if (n_my - n_before >= a.maxc || n_my >= a.maxf) { over = true; break; }
-                // A new crop, centred on the bounding box of the candidates from k on that can share it (k is the top-most uncovered
-                // one: the list is sorted by index).  With the origin ROUNDED to a multiple of 8 the core covers centre - 7 .. centre + 7
-                // at least, so a cluster of up to 15 x 15 pixels -- the flat top of a saturated blob -- takes ONE crop (a crop centred on
-                // the first candidate, the top row of the blob, left its lower half to a second crop).
+            c_from = n_my;
+            int first = -1;                                       // the first candidate (index order) that no crop holds
+#pragma unroll
+            for (int m = 0; m < PER; ++m) {
+                const unsigned long long unc = __builtin_amdgcn_ballot_w64(lane + 64 * m < cnt && found[m] < 0);
+                if (first < 0 && unc) first = 64 * m + __builtin_ctzll(unc);
+            }
+            if (first < 0) break;
+            if (n_my - n_before >= a.maxc || n_my >= a.maxf) { over = true; break; }
+            if (lane == 0) {
+                // A new crop, centred on the bounding box of the candidates from `first` on that can share it (it is the top-most
+                // uncovered one: the list is sorted by index).  With the origin ROUNDED to a multiple of 8 the core covers centre - 7 ..
+                // centre + 7 at least, so a cluster of up to 15 x 15 pixels -- the flat top of a saturated blob -- takes ONE crop (a crop
+                // centred on the first candidate, the top row of the blob, left its lower half to a second crop).
+                const int k = first, fy = s_sorted[k] / a.W, fx = s_sorted[k] % a.W;
                 const int span_y = a.Hc - 2 * a.R - 2 - 7, span_x = a.Wc - 2 * a.R - 2 - 7;
-                int ylo = cy, yhi = cy, xlo = cx, xhi = cx;
+                int ylo = fy, yhi = fy, xlo = fx, xhi = fx;
                 for (int j = k + 1; j < cnt; ++j) {
-                    const int yj = ci[j] / a.W, xj = ci[j] % a.W;
-                    if (yj - cy >= span_y) break;
+                    const int yj = s_sorted[j] / a.W, xj = s_sorted[j] % a.W;
+                    if (yj - fy >= span_y) break;
                     const int nxlo = xj < xlo ? xj : xlo, nxhi = xj > xhi ? xj : xhi;
                     if (nxhi - nxlo >= span_x) continue;
                     xlo = nxlo; xhi = nxhi; yhi = yj;
@@ -150,39 +175,49 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
                     int cylo, cyhi, cxlo, cxhi;
                     core_range(y0, a.Hc, a.H, a.R, cylo, cyhi);
                     core_range(x0, a.Wc, a.W, a.R, cxlo, cxhi);
-                    if (!(cy >= cylo && cy < cyhi && cx >= cxlo && cx < cxhi)) { y0 = origin(cy, a.Hc, a.H); x0 = origin(cx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
+                    if (!(fy >= cylo && fy < cyhi && fx >= cxlo && fx < cxhi)) { y0 = origin(fy, a.Hc, a.H); x0 = origin(fx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
                 }
                 my_y0[n_my] = y0; my_x0[n_my] = x0;
-                found = n_my++;
             }
-            a.cand_crop[(size_t)map * a.K + k] = found;          // slot in the frame's list for now
+            ++n_my;
+            __syncthreads();
         }
-        if (over) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); continue; }          // (n_my_s keeps the list without this heatmap's new crops)
-        n_my_s = n_my;
-        a.status[map] = CERT_PENDING | gbit;
+        if (over) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }          // (n_my_s keeps the list without this heatmap's new crops)
+#pragma unroll
+        for (int m = 0; m < PER; ++m)
+            if (lane + 64 * m < cnt) a.cand_crop[(size_t)map * a.K + lane + 64 * m] = found[m];          // slot in the frame's list for now
+        __syncthreads();                                          // (every lane has read n_my_s)
+        if (lane == 0) { n_my_s = n_my; a.status[map] = CERT_PENDING | gbit; }
     }
     __syncthreads();
-    if (lane != 0) return;
     const int n_my = n_my_s;
     if (n_my == 0) return;
-    const int base = atomicAdd(a.n_crops, n_my);
-    for (int c = 0; c < n_my && base + c < a.max_crops; ++c) {          // (records also for a list that fills up half way: the slots are run)
-        int* rec = a.crop_rec + 4 * (base + c);
-        rec[0] = frame; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
+    if (lane == 0) {
+        const int base = atomicAdd(a.n_crops, n_my);
+        s_base = base;
+        for (int c = 0; c < n_my && base + c < a.max_crops; ++c) {          // (records also for a list that fills up half way: the slots are run)
+            int* rec = a.crop_rec + 4 * (base + c);
+            rec[0] = frame; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
+        }
+        if (!(base + n_my > a.max_crops)) atomicAdd(&a.stats[4], (unsigned long long)n_my);
     }
+    __threadfence_block();
+    __syncthreads();
+    const int base = s_base;
     const bool full = base + n_my > a.max_crops;                          // crop list full: the frame's heatmaps stay uncertified
-    if (!full) atomicAdd(&a.stats[4], (unsigned long long)n_my);
     for (int ch = 0; ch < a.C; ++ch) {
         const int map = frame * a.C + ch;
-        const int st = a.status[map];
+        const int st = a.status[map];          // (written by lane 0 of this workgroup above: visible after the barrier)
         if (!(st & CERT_PENDING)) continue;
         const int gbit = st & 4;
-        if (full) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); continue; }
+        if (full) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
         const int cnt = a.cand_cnt[map];
-        for (int k = 0; k < cnt; ++k) a.cand_crop[(size_t)map * a.K + k] += base;
-        a.status[map] = 1 | gbit;
-        atomicAdd(&a.stats[2], 1ull);
-        atomicAdd(&a.stats[5], (unsigned long long)cnt);
+        for (int k = lane; k < cnt; k += 64) a.cand_crop[(size_t)map * a.K + k] += base;
+        if (lane == 0) {
+            a.status[map] = 1 | gbit;
+            atomicAdd(&a.stats[2], 1ull);
+            atomicAdd(&a.stats[5], (unsigned long long)cnt);
+        }
     }
 }
 
