@@ -114,6 +114,93 @@ def test_eps_audit_widens_on_brighter_frames_and_recertifies():
     assert torch.equal(o1['xyv'], o2['xyv'])
 
 
+class _FixedPick:
+    """Stands in for the worker's audit rng: the side-stream audit then re-runs the triple the test names."""
+    def __init__(self, t):
+        self.t = t
+
+    def integers(self, n):
+        return min(self.t, n - 1)
+
+
+def test_one_out_of_bound_frame_between_audits_missed_is_stated_caught_is_recertified():
+    """What the sampled audit does with ONE frame whose bf16 error exceeds eps inside an otherwise quiet clip.
+    A dark clip calibrates eps; the next clip is the same dark scene with a single high-contrast frame planted in the middle (the
+    three triples that contain it have errors above the bound).
+      (a) the side-stream audit samples a triple that does NOT contain the frame: the strip audit cannot see it.  Either the
+          candidate-level audit (the fp32 crops that the frame's own heatmaps needed) catches it -- then eps is widened and every
+          index is the fp32 path's -- or nobody does: then the bound still holds on every OTHER triple (their indices equal the
+          fp32 path's), `audit` states what share of the frames was audited (< 1), and max_err_seen is below the planted error.
+      (b) the audit samples a triple that contains it: eps is widened by the strip audit, the clip is re-certified, every index
+          equals the fp32 path's and the observed error sits inside the safety factor again.
+    Also covers the adaptive rate: the fast rate until eps has stood for `audit_settle_clips` clips, the steady rate after."""
+    sd = weights.random_wasb_state_dict(9)
+    usd = weights.random_uplift_state_dict(9, 'large')
+    base, _ = synth.synth_frames(14, H, W, seed=9)
+    dark = np.clip(115.0 + (base.astype(np.float32) - 70.0) * 0.1, 0, 255).astype(np.uint8)
+    mixed = dark.copy()
+    mixed[7] = np.clip(128.0 + (base[7].astype(np.float32) - 70.0) * 4.0, 0, 255).astype(np.uint8)
+    fd, fm = torch.from_numpy(dark).cuda(), torch.from_numpy(mixed).cuda()
+    table_px = np.concatenate([np.random.default_rng(0).uniform(100, 900, (13, 2)), np.ones((13, 1))], 1)
+    ref_idx, _, _ = _fp32_peaks(sd, fm, (W, H))
+
+    def run(pick):
+        # one audited triple per 12-triple clip at both rates, so that the pick is the only thing that differs between (a) and (b)
+        worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=12, audit_every_fast=12,
+                                       audit_settle_clips=2, audit_seed=1)
+        worker.process_clip(fd, table_px, 60.0)
+        eps0 = worker.certify_eps
+        errs = np.array([float(worker.net.heatmap_error(fm, t).item()) for t in range(12)])
+        assert errs[[5, 6, 7]].max() * 1.5 > eps0, 'premise: the planted frame must break the dark clip\'s bound (%.3g vs eps %.3g)' % (errs.max(), eps0)
+        worker._rng = _FixedPick(pick)
+        out = worker.process_clip(fm, table_px, 60.0)
+        _, idx, win = worker.net.forward_frames(fm)
+        worker.net.fix_uncertified(idx, win, frames_u8=fm)
+        return worker, eps0, errs, out, idx
+    # (a) the audit looks elsewhere
+    worker, eps0, errs, out, idx = run(0)
+    a = worker.audit
+    assert a['frames_seen'] >= 24 and 0 < a['audited_share'] <= 1 and a['audit_every_now'] == 12          # (36 when a widening past the guard factor re-ran the clip)
+    inbound = errs <= worker.certify_eps
+    assert torch.equal(idx.cpu()[torch.from_numpy(inbound)], ref_idx.cpu()[torch.from_numpy(inbound)]), 'the bound holds on these triples: their indices must be the fp32 path\'s'
+    if worker.certify_eps > eps0:
+        assert a['widen_sources']['candidates'] >= 1 and a['max_err_over_eps'] <= 1 / 1.5 + 1e-6
+        caught_by = 'the candidate-level audit'
+    else:
+        assert a['max_err_seen'] < errs.max() and a['audited_share'] < 1, a
+        caught_by = 'nobody (stated: audited share %.3f)' % a['audited_share']
+    n_bad = int((idx.cpu() != ref_idx.cpu()).sum())
+    print('\n(a) audit elsewhere: eps %.4g -> %.4g, planted errors %s, caught by %s, %d of 12 indices differ from the fp32 path'
+          % (eps0, worker.certify_eps, ['%.3g' % e for e in errs[[5, 6, 7]]], caught_by, n_bad))
+    # (b) the audit samples the planted frame
+    worker, eps0, errs, out, idx = run(6)
+    a = worker.audit
+    assert worker.certify_eps > eps0 and a['widened'] >= 1 and a['max_err_over_eps'] <= 1 / 1.5 + 1e-6, a
+    inbound = errs <= worker.certify_eps
+    assert inbound[6] and a['max_err_seen'] >= errs[6] * (1 - 1e-6)
+    assert torch.equal(idx.cpu()[torch.from_numpy(inbound)], ref_idx.cpu()[torch.from_numpy(inbound)])
+    assert inbound.all(), 'the neighbours of the audited triple carry the same planted frame: 1.5 x its error should cover them (%s vs eps %.3g)' % (errs[[5, 6, 7]], worker.certify_eps)
+    print('(b) audit on the planted frame: eps %.4g -> %.4g, widened %d (sources %s), %d heatmaps / %d clips re-certified'
+          % (eps0, worker.certify_eps, a['widened'], a['widen_sources'], a['recertified_heatmaps'], a['recertified_clips']))
+    # adaptive rate: fast until eps has stood for audit_settle_clips clips in a row, steady afterwards, fast again after a widening
+    w2 = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=48, audit_every_fast=6, audit_settle_clips=2)
+    assert w2.audit_rate() == 6
+    w2.process_clip(fd, table_px, 60.0)                    # calibration (8 frames) + 12 triples at one audit per 6
+    assert w2.audit['audited_frames'] == 8 + 2 and w2.audit['frames_seen'] == 12
+    for _ in range(20):                                    # the same clip until eps has stood for two clips in a row
+        if w2.audit['quiet_clips'] >= 2:
+            break
+        w2.process_clip(fd, table_px, 60.0)
+    assert w2.audit['quiet_clips'] >= 2 and w2.audit_rate() == 48
+    n0 = w2.audit['audited_frames']
+    for _ in range(3):
+        w2.process_clip(fd, table_px, 60.0)
+    assert w2.audit['audited_frames'] - n0 <= 1            # 36 triples at one per 48
+    assert abs(w2.audit['audited_share'] - w2.audit['audited_frames'] / w2.audit['frames_seen']) < 1e-12
+    w2._quiet_clips = 0
+    assert w2.audit_rate() == 6
+
+
 def test_pipelined_repair_uses_the_tickets_own_status():
     """collect() of clip k runs after submit() of clip k+1 has flipped the handle's per-call slot: the heatmaps of clip k that the
     crop budget could not settle (status 2) must be repaired from clip k's OWN status.  A tiny budget and a wide eps on noise

@@ -820,6 +820,17 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['collective']['ranks'] == 2 and rec['collective']['backend'] == 'gloo' and rec['rccl_ranks'] == 0
+    # the line says whether the process group's streams moved the worker's stream -> queue grouping (VERDICT r4 #5b): both
+    # probes of every rank are in it (with the ranks SHARING this GPU the flag's value is not meaningful, its presence is)
+    q = rec['stream_queue_groups']
+    assert isinstance(rec['queue_mapping_changed'], bool) and rec['queue_mapping_changed'] == q['queue_mapping_changed']
+    assert len(q['pre_init_per_rank']) == 2 and all(isinstance(g, str) and 'lane0' in g for g in q['pre_init_per_rank']), q
+    # a rank that dies takes the run down with a non-zero exit code and no JSON line (VERDICT r4 #5c): the parent never touches
+    # the GPU, the ranks are fresh children of torch.distributed.run, nothing is re-exec'd
+    dead = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--no-roofline', '--no-cpu-baseline', '--no-extras'],
+                          env=dict(env, TTUP_BENCH_FAIL_RANK='1'), cwd=root, capture_output=True, text=True, timeout=900)
+    assert dead.returncode != 0 and not [l for l in dead.stdout.splitlines() if l.startswith('{')], (dead.returncode, dead.stdout[-500:])
+    assert 'failed' in dead.stderr
     # a mismatch between --gpus and the launcher's world size is diagnosed, not ignored
     env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
@@ -902,3 +913,61 @@ dist.barrier(); dist.destroy_process_group(); print('rccl ok', dist.is_nccl_avai
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'rccl ok True' in out.stdout, out.stderr[-2000:]
+
+
+_RCCL2_CODE = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from upliftingtabletennis_amd import pipeline
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(rank)
+dev = torch.device('cuda', rank)
+dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+ones = torch.ones(1, device=dev); dist.all_reduce(ones); assert int(ones.item()) == world
+spec = {'xyv': (8, (3,), torch.float64), 'spin': (4, (3,), torch.float32), 'pos3d': (4, (5, 3), torch.float32), 'n_valid': (4, (), torch.int64)}
+g = torch.Generator(device=dev).manual_seed(100 + rank)
+rows_xyv, rows_tr = (8, 2) if rank == 0 else (5, 0)
+rec = {'xyv': torch.randn((rows_xyv, 3), device=dev, generator=g, dtype=torch.float64), 'spin': torch.randn((rows_tr, 3), device=dev, generator=g),
+       'pos3d': torch.randn((rows_tr, 5, 3), device=dev, generator=g), 'n_valid': torch.arange(rows_tr, device=dev, dtype=torch.int64)}
+calls = []
+orig = dist.all_gather_into_tensor
+def counted(out, inp, *a, **k):
+    calls.append((out.is_cuda, inp.is_cuda, inp.numel()))
+    return orig(out, inp, *a, **k)
+dist.all_gather_into_tensor = counted
+out = pipeline.gather_records(rec, dist, spec=spec)
+dist.all_gather_into_tensor = orig
+assert calls == [(True, True, calls[0][2])], calls          # ONE collective, on device buffers
+if rank == 0:
+    for r in range(world):
+        gr = torch.Generator(device=torch.device('cuda', r)).manual_seed(100 + r)
+        n1, n2 = (8, 2) if r == 0 else (5, 0)
+        want = {'xyv': torch.randn((n1, 3), device=torch.device('cuda', r), generator=gr, dtype=torch.float64),
+                'spin': torch.randn((n2, 3), device=torch.device('cuda', r), generator=gr), 'pos3d': torch.randn((n2, 5, 3), device=torch.device('cuda', r), generator=gr),
+                'n_valid': torch.arange(n2, dtype=torch.int64)}
+        for k in spec:
+            assert out[k][r].dtype == spec[k][2] and torch.equal(out[k][r], want[k].cpu()), (k, r)
+    print('rccl2 ok')
+else:
+    assert out is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_rccl_two_rank_gather_on_device_buffers():
+    """`pipeline.gather_records` end to end over RCCL with world = 2 and DEVICE buffers (VERDICT r4 missing #2 / next #5a): two ranks,
+    one GPU each, different row counts, one `all_gather_into_tensor` per call, rank 0 gets both ranks' records back intact.  Needs
+    two devices (RCCL refuses two ranks on one GPU): skipped on the 1-GPU test box, runs wherever the driver has >= 2 visible."""
+    import subprocess, sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (RCCL does not accept two ranks on one device); covered on CPU by tests/test_dist_gloo.py')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, 'gpurun_out', '_rccl2_rank.py')
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, 'w') as f:
+        f.write(_RCCL2_CODE % root)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29547', script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'rccl2 ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

@@ -101,14 +101,16 @@ class StreamWorker:
     Raises RuntimeError without a HIP device (no CPU fallback).
 
     Certified argmax (`certify=True`, bf16): eps -- the bound on |bf16 heatmap - fp32 heatmap| the certification rests on -- is
-    estimated on the first clip and then AUDITED while the worker runs: one random triple per `audit_every` triples is re-run on
+    estimated on the first clip and then AUDITED while the worker runs: one random triple per `audit_every` triples (per
+    `audit_every_fast` until eps has stood for `audit_settle_clips` clips in a row) is re-run on
     the fp32 twin on a side stream, and every fp32 crop the certification computes anyway reports the error at its candidates.
     eps is 1.5 times the largest error seen so far (calibration frames, audits); a new maximum widens it, and of the clips certified
     under the old value only the heatmaps whose guard band (pixels between 2 eps and 2.5 eps below the maximum) is not empty are
     run again -- the whole clip only when eps grows by more than a quarter at once.  `audit` reports the counts; `audit_every=0` switches the side-stream audit off."""
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
-                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False):
+                 traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False,
+                 audit_every_fast=64, audit_settle_clips=8):
         from . import glue, refine, uplift, wasb, _lib
         _lib.require_gpu()
         self._glue, self._refine, self._uplift, self._lib = glue, refine, uplift, _lib
@@ -127,7 +129,16 @@ class StreamWorker:
         self.fp32_reruns = 0
         self.recertified_clips = 0
         self.recertified_heatmaps = 0
+        # Side-stream audit rate (triples per audited triple), ADAPTIVE: `audit_every_fast` while the bound is still moving -- until
+        # `audit_settle_clips` consecutive clips have passed without a widening of eps -- and `audit_every` afterwards; a widening
+        # drops back to the fast rate.  New content is where a too-small eps is found (the soaks widen within the first clips of a
+        # content change and not again), so the audits are spent there.  `audit['audited_share']` = audited / processed triples.
         self.audit_every = int(audit_every)
+        self.audit_every_fast = min(int(audit_every_fast), self.audit_every) if int(audit_every_fast) > 0 else self.audit_every
+        self.audit_settle_clips = int(audit_settle_clips)
+        self._quiet_clips = 0
+        self.frames_seen = 0
+        self.widen_sources = {'strip': 0, 'candidates': 0}
         self._since_audit = 0
         self._rng = np.random.default_rng(audit_seed)
         # measurement (bench.py `ambiguous_share`): when set to a list, every collected clip appends the fp32 top-2 margins of its
@@ -147,7 +158,21 @@ class StreamWorker:
         a['max_err_over_eps'] = (a['max_err_seen'] / self.certify_eps) if self.certify_eps else None
         a['recertified_clips'] = self.recertified_clips
         a['recertified_heatmaps'] = self.recertified_heatmaps
+        # what the side-stream audit has covered: audited triples (calibration frames included) / triples processed.  A frame whose
+        # error exceeds eps while no audited frame's does is missed with probability 1 - (the audit rate at that time) by the strip
+        # audit (the candidate-level audit still sees it when it needs a crop): the guarantee is statistical and this is its rate
+        a['frames_seen'] = self.frames_seen
+        a['audited_share'] = (a['audited_frames'] / self.frames_seen) if self.frames_seen else None
+        a['audit_every_now'] = self.audit_rate()
+        a['quiet_clips'] = self._quiet_clips
+        a['widen_sources'] = dict(self.widen_sources)
         return a
+
+    def audit_rate(self):
+        """Triples per audited triple right now (0 = side-stream audit off)."""
+        if not self.certify or self.audit_every <= 0:
+            return 0
+        return self.audit_every_fast if self._quiet_clips < self.audit_settle_clips else self.audit_every
 
     def detect(self, frames_u8):
         """(N,h,w,3) uint8 on the device -> (N-2,3) float64 [x, y, visibility] in 1920x1080 px (table-variant refine,
@@ -177,12 +202,14 @@ class StreamWorker:
 
     def _pick_audits(self, n_triples):
         """Indices of the triples of a clip that the side-stream audit re-runs on the fp32 twin: one per `audit_every` triples."""
-        if not self.certify or self.audit_every <= 0 or n_triples <= 0:
+        self.frames_seen += max(0, int(n_triples))
+        every = self.audit_rate()
+        if every <= 0 or n_triples <= 0:
             return []
         self._since_audit += n_triples
         picks = []
-        while self._since_audit >= self.audit_every:
-            self._since_audit -= self.audit_every
+        while self._since_audit >= every:
+            self._since_audit -= every
             picks.append(int(self._rng.integers(n_triples)))
         return picks
 
@@ -203,12 +230,15 @@ class StreamWorker:
         had to be widened (clips certified under a smaller eps must be re-run)."""
         net = self.net
         err = net.note_error(cand_err)
-        if audit_ticket is not None:
-            err = max(err, net.audit_result(audit_ticket))
+        strip_err = net.audit_result(audit_ticket) if audit_ticket is not None else 0.0
+        source = 'strip' if strip_err > err else 'candidates'
+        err = max(err, strip_err)
         widened = False
         if net.eps_violated(err):
             self.certify_eps = net.widen_eps(err)
             widened = True
+            self.widen_sources[source] += 1
+        self._quiet_clips = 0 if widened else self._quiet_clips + 1
         # crop budget of the next clips (it sizes the number of fp32 passes a call provisions; an unused pass still costs its launches):
         # one and a half times the most any of the last eight clips asked for (+ slack) -- content that alternates between easy and
         # hard clips keeps the hard clips' budget (twice the LAST clip's count sent 40 % of a hard clip that followed an easy one to
