@@ -21,7 +21,7 @@ from upliftingtabletennis_amd import weights
 pytestmark = pytest.mark.gpu
 
 # bars (measured values are printed by the tests; DESIGN.md 3 quotes them)
-XY_NET_PX = {False: 0.02, True: 1e-5}          # refined xy, in network pixels (output px / (1920 / W)); measured 3.4e-3 .. 7.6e-3 / 2.6e-7
+XY_NET_PX = {False: 0.015, True: 1e-5}         # refined xy, in network pixels (output px / (1920 / W)); measured 3.4e-3 .. 7.6e-3 / 2.6e-7: production bar = 2 x the largest measured
 REL_3D = {False: 1e-4, True: 1e-4}             # pos3d, |spin|, spin_z relative to the largest entry (north_star); measured <= 3.0e-5 / 1.9e-5
 
 

@@ -37,6 +37,9 @@ def _wasb_case(g, name):
 
 
 # ------------------------------------------------------------------------------------------ a2: CNN
+XY_OUT_PX_BF16 = 0.05          # production-mode (bf16 window) bar of the refined xy in OUTPUT pixels; the measured value is printed by the test
+
+
 @pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160', 'planted_96x160'])
 def test_wasb_f32_path_matches_reference(golden, name):
     """fp32 HIP path vs the reference heatmap: tolerance 2e-4 of the heatmap range (fp32 re-association only)."""
@@ -83,7 +86,7 @@ def test_wasb_bf16_path_close_to_reference(golden, name):
 
 def test_wasb_fullsize_planted_argmax_and_refine(golden):
     """BASELINE size 704x1280: bit-exact argmax vs the reference run, refined position close to the
-    reference's (bf16 heatmap values differ slightly, so the fit input differs: tolerance 0.05 px of 1920)."""
+    reference's (bf16 heatmap values differ slightly, so the fit input differs: XY_OUT_PX_BF16 px of 1920)."""
     g = golden('wasb_full.npz')
     seed, b, h, w = [int(v) for v in g['meta']]
     sd = weights.random_wasb_state_dict(seed, planted=True)
@@ -104,7 +107,9 @@ def test_wasb_fullsize_planted_argmax_and_refine(golden):
     for variant, key in ((_lib.REFINE_BALL, 'ball'), (_lib.REFINE_TABLE, 'table')):
         xyv = refine.refine_windows_device(idx, win, h, w, 1920, 1080, variant).cpu().numpy()
         ref = g[key].reshape(b, 3)
-        assert np.abs(xyv[:, :2] - ref[:, :2]).max() < 0.05, (xyv, ref)
+        d_xy = np.abs(xyv[:, :2] - ref[:, :2]).max()
+        print('\n[wasb_full, %s variant] refined xy %.2e output px (= %.2e network px) off the reference (bf16 windows)' % (key, d_xy, d_xy * w / 1920))
+        assert d_xy < XY_OUT_PX_BF16, (xyv, ref)
         assert np.array_equal(xyv[:, 2], ref[:, 2])
     # f32 path at full size: argmax identical as well
     net32 = wasb.WASBNet(sd, resolution=(w, h), max_batch=1, dtype='f32')
@@ -242,6 +247,32 @@ def test_uplift_mask_errors_and_batching():
     # independence of trajectories: a sub-batch gives the same rows
     rot2, pos2 = net(ball[3:7], table[3:7], mask[3:7], times[3:7])
     assert torch.allclose(rot2, rot[3:7], rtol=1e-5, atol=1e-6) and torch.allclose(pos2, pos[3:7], rtol=1e-5, atol=1e-6)
+
+
+def test_uplift_graph_replay_on_a_side_stream_equals_eager():
+    """The small-batch uplift forward replays a captured hipGraph from its second same-shape call on a NON-default stream
+    (csrc/uplift.hip ttup_uplift_forward).  A runtime where the capture silently fails would still pass the bit-equality checks of
+    the e2e tests while the latency numbers in DESIGN.md no longer hold (round-4 advisor): assert that replays happen, that the
+    path has not switched itself off, and that a replay returns exactly what the eager call returned."""
+    usd = weights.random_uplift_state_dict(4, 'large')
+    ball, table, mask, times = [torch.from_numpy(a).cuda() for a in synth.synth_trajectories(3, 40, seed=4, pad=9)]
+    up = uplift.get_model('connectstage', 'large', 'dynamic', 'new', state_dict=usd, max_batch=4, max_len=50)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(4):          # 1st call eager, 2nd captures + launches, 3rd and 4th replay
+            rot, pos = up(ball, table, mask, times)
+            outs.append((rot.clone(), pos.clone()))
+    side.synchronize()
+    gi = up.graph_info()
+    assert not gi['off'] and gi['graphs'] >= 1 and gi['replays'] >= 3, gi
+    for rot, pos in outs[1:]:
+        assert torch.equal(rot, outs[0][0]) and torch.equal(pos, outs[0][1])
+    # the default stream runs eagerly (stream 0 cannot be captured): same values, no further replays
+    r0, p0 = up(ball, table, mask, times)
+    torch.cuda.synchronize()
+    assert torch.equal(r0, outs[0][0]) and torch.equal(p0, outs[0][1]) and up.graph_info()['replays'] == gi['replays']
 
 
 def test_uplift_stage_kernel_against_the_per_layer_kernels():

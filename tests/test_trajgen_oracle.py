@@ -115,6 +115,46 @@ def test_seed_order_is_the_pool_round_robin():
     assert T.seed_order(1024, 4, 128)[:4] == [1024, 1025, 1026, 1027]
 
 
+def test_trajectory_batch_reads_like_the_reference_list_of_dicts(tmp_path):
+    """Host logic of `trajgen.TrajectoryBatch` (no GPU): stacked chunk arrays read back as the reference's per-trajectory
+    dictionaries (mujocosimulation.py:213-218) -- indexing across chunk boundaries, negative indices, slices, iteration,
+    `stacked()`, `save_dataset` -- and the vectorised pool order equals the oracle's `seed_order`."""
+    from upliftingtabletennis_amd import trajgen
+    for cur, b, p in ((0, 1024, 128), (7, 10, 4), (3, 6, 4), (0, 5, 8), (100, 1024, 96)):
+        assert list(trajgen._seed_order_array(cur, b, p)) == T.seed_order(cur, b, p)
+    rng = np.random.default_rng(0)
+    ex, mint = trajgen.camera_matrices()
+    chunks, want = [], []
+    for nk in ([3, 5], [4], [2, 2, 6]):
+        nk = np.array(nk, dtype=np.int64)
+        rows = rng.standard_normal((int(nk.sum()), 9))
+        nb = rng.integers(0, 4, len(nk)).astype(np.int32)
+        bo = rng.standard_normal((len(nk), 4))
+        sd = rng.integers(0, 1 << 40, len(nk))
+        off = np.concatenate([[0], np.cumsum(nk)])
+        chunks.append({'rows': rows, 'offsets': off, 'n_keep': nk, 'bounces': bo, 'n_bounces': nb, 'seeds': sd})
+        for j in range(len(nk)):
+            want.append((rows[off[j]:off[j + 1]], bo[j, :nb[j]], int(sd[j])))
+    tb = trajgen.TrajectoryBatch(chunks, trajgen.save_times(), ex, mint)
+    assert len(tb) == 6 and len(list(tb)) == 6 and len(tb[1:5:2]) == 2
+    for i, (rows, bo, sd) in enumerate(want):
+        for t in (tb[i], tb[i - 6]):
+            assert set(t) == {'positions', 'velocities', 'rotations', 'times', 'Mext', 'Mint', 'bounces', 'seed'}
+            assert np.array_equal(np.concatenate([t['positions'], t['velocities'], t['rotations']], 1), rows)
+            assert np.array_equal(t['bounces'], bo) and t['seed'] == sd and isinstance(t['seed'], int)
+            n = len(rows)
+            assert np.array_equal(t['times'], T.save_times()[:n]) and t['Mext'].shape == (n, 4, 4) and t['Mint'].shape == (n, 3, 3)
+            assert np.array_equal(t['Mext'][-1], ex) and np.array_equal(t['Mint'][0], mint)
+    with pytest.raises(IndexError):
+        tb[6]
+    st = tb.stacked()
+    assert st['rows'].shape == (22, 9) and list(st['offsets']) == [0, 3, 8, 12, 14, 16, 22] and list(st['seeds']) == [w[2] for w in want]
+    trajgen.save_dataset(str(tmp_path / 'ds'), tb)
+    assert np.array_equal(np.load(str(tmp_path / 'ds' / 'trajectory_0004' / 'Mext.npy')), np.repeat(ex[None], 2, 0))
+    assert np.array_equal(np.load(str(tmp_path / 'ds' / 'trajectory_0005' / 'velocities.npy')), want[5][0][:, 3:6])
+    assert len(trajgen.TrajectoryBatch([], trajgen.save_times(), ex, mint)) == 0
+
+
 def test_every_mode_is_accepted_and_rejected_like_the_reference_worker(golden):
     """Seeds that pass each of the six modes (and their mostly rejected neighbours): oracle sampling loop + selection against
     the reference worker's decisions, kept lengths and bounce times (every mode's cut / count branch is taken)."""

@@ -99,7 +99,15 @@ def _check_build_id(lib):
     if 'TTUP_LIB' in os.environ or os.environ.get('TTUP_ALLOW_STALE_LIB') == '1':
         return
     from . import build
-    have, want = lib.ttup_build_id().decode(), build.source_id()
+    try:
+        want = build.source_id()
+    except OSError as e:
+        # a deployed copy without the source tree (the package + libttup.so, no csrc/ or include/): nothing to compare with
+        import warnings
+        warnings.warn('libttup.so: the source tree is not next to the package (%s), so the library\'s build id (%s) cannot be checked against it; '
+                      'set TTUP_ALLOW_STALE_LIB=1 to silence this' % (e, lib.ttup_build_id().decode()))
+        return
+    have = lib.ttup_build_id().decode()
     if have != want:
         raise RuntimeError('libttup.so was built from other sources (library %s, tree %s): rebuild it with '
                            '`python -m upliftingtabletennis_amd.build`' % (have, want))

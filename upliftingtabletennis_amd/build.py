@@ -3,7 +3,7 @@ HIP library only.
 
     python -m upliftingtabletennis_amd.build [--force]
 
-The library carries the hash of the sources it was built from (`ttup_build_id()`): `source_id()` below hashes csrc/*.hip,
+The library carries the hash of the sources it was built from (`ttup_build_id()`): `source_id()` below hashes the SOURCES under csrc/,
 csrc/*.h, include/ttup.h and the compiler flags; it is compiled into api.o, `_lib.load()` refuses a library whose id differs
 from the tree's, and an object is rebuilt when the hash of ITS inputs differs from the one recorded for it (csrc/.stamps.json)
 -- modification times are not consulted.
@@ -41,7 +41,7 @@ def _digest(paths, extra=''):
 
 def source_id():
     """16 hex digits identifying the library's inputs: every .hip / .h under csrc/, include/ttup.h, the flags."""
-    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    srcs = sorted(os.path.join(CSRC, f) for f in SOURCES)          # exactly what build() compiles: a stray .hip in csrc/ does not change the id
     return _digest(srcs + _headers(), ' '.join(FLAGS))[:16]
 
 

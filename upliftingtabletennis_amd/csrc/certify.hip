@@ -316,6 +316,7 @@ void cert_free(ttup_wasb* net) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.read_status) (void)hipEventDestroy(sl.read_status);
         if (sl.read_info) (void)hipEventDestroy(sl.read_info);
+        if (sl.read_margin) (void)hipEventDestroy(sl.read_margin);
         sl = CertState::Slot();
     }
     if (c.stats) (void)hipFree(c.stats);
@@ -333,6 +334,7 @@ int cert_begin(ttup_wasb* net, int batch, hipStream_t caller) {
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.done, 0));          // the call that last used this slot has finished its fp32 passes
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_status, 0));   // ... and its caller's status / info copies have been made
     TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_info, 0));
+    TTUP_HIP_CHECK(hipStreamWaitEvent(caller, sl.read_margin, 0));   // (own event: hipEventRecord overwrites, and the margin copy may be issued on another stream than the status copy)
     const size_t maps = (size_t)batch * net->n_out;
     TTUP_HIP_CHECK(hipMemsetAsync(sl.cand_cnt, 0, maps * sizeof(int), caller));
     TTUP_HIP_CHECK(hipMemsetAsync(sl.guard_cnt, 0, maps * sizeof(int), caller));
@@ -443,6 +445,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     c.CH = net->max_batch < 64 ? net->max_batch : 64;
     const int per_map = env_list > 0 && env_list <= 8 ? env_list : 4;
     c.max_crops = per_map * net->max_batch > c.CH ? per_map * net->max_batch : c.CH;   // capacity of the call's crop list: four per heatmap on average; the overflow is flagged
+    if (c.max_crops < c.maxf) c.max_crops = c.maxf;          // ... and never less than ONE frame may ask for (one-sample handles: re-certification of single frames, round-4 advisor)
     // (round 4: 2 -> 4 and 4 -> 8 crops per heatmap: on pure noise weights 5.5 % of the heatmaps overflowed and went to the full-frame fp32 path --
     // 3.6 ms each, the price of 32 crops; now none: 737 -> 854 frames/s, tools/noise_regime.py)
     c.nchunks = cdiv(c.max_crops, c.CH);
@@ -465,11 +468,12 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.roi_flag, (size_t)c.max_crops * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.status, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipMalloc((void**)&sl.margin, nb * sizeof(float)));
-        TTUP_HIP_CHECK(hipMemset(sl.margin, 0x7f, nb * sizeof(float)));
+        TTUP_HIP_CHECK(hipMemsetD32((hipDeviceptr_t)sl.margin, 0x7f800000, nb));          // +inf: heatmaps never planned or resolved (ttup.h)
         TTUP_HIP_CHECK(hipMemset(sl.status, 0, nb * sizeof(int)));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_status, hipEventDisableTiming));
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_info, hipEventDisableTiming));
+        TTUP_HIP_CHECK(hipEventCreateWithFlags(&sl.read_margin, hipEventDisableTiming));
     }
     TTUP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     TTUP_HIP_CHECK(hipEventCreateWithFlags(&c.lanes_done, hipEventDisableTiming));
@@ -621,7 +625,7 @@ extern "C" int ttup_wasb_certify_margins(ttup_wasb* net, int batch, float* margi
     TTUP_REQUIRE(batch >= 0 && batch <= net->max_batch * net->n_out, TTUP_EINVAL, "ttup_wasb_certify_margins: %d heatmaps outside [0,%d]", batch, net->max_batch * net->n_out);
     CertState::Slot& sl = net->cert.slot[net->cert.cur];
     if (batch > 0) TTUP_HIP_CHECK(hipMemcpyAsync(margin_dev, sl.margin, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    TTUP_HIP_CHECK(hipEventRecord(sl.read_status, (hipStream_t)stream));
+    TTUP_HIP_CHECK(hipEventRecord(sl.read_margin, (hipStream_t)stream));
     return TTUP_OK;
 }
 // status | 4 where the guard band is not empty

@@ -42,8 +42,8 @@ struct CertState {
     static constexpr float GUARD = 1.25f;   // a heatmap with an empty guard band stays certified when eps is widened by up to this factor
     int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
     int K = 256;                         // candidates kept per heatmap (<= CERT_MAX_K, csrc/certify.hip): the flat top of a saturated blob fits
-    int maxc = 8;                        // new crops a heatmap may add
-    int maxf = 4;                        // crops per frame (the channels of a frame share them: min(16, maxc * channels))
+    int maxc = 8;                        // new crops a heatmap may add (ttup.h: max_crops_per_map, 0 = 8)
+    int maxf = 8;                        // crops per frame, set by ttup_wasb_set_certify to min(16, maxc * channels): the channels of a frame share them
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
     bool exact_windows = false;          // every heatmap gets an fp32 crop (also single-candidate ones): all 3x3 windows are fp32 values
@@ -62,7 +62,7 @@ struct CertState {
         // caller issued them) have finished: the next call that takes the slot waits for them before it zeroes the slot (a call
         // issued on ANOTHER stream -- e.g. after an odd number of extra calls changed the stream / slot pairing -- would otherwise
         // reset the status under a pending copy; round-3 advisor, medium)
-        hipEvent_t read_status = nullptr, read_info = nullptr;
+        hipEvent_t read_status = nullptr, read_info = nullptr, read_margin = nullptr;          // one event per KIND of copy: a record overwrites the event's previous record
     } slot[2];
     int cur = 0;                            // slot of the call being issued / last issued
     unsigned long long* stats = nullptr;

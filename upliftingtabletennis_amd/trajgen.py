@@ -9,6 +9,7 @@ MuJoCo is not available, so the flight/contact arithmetic is a restatement of it
 see DESIGN.md); sampling (`random.Random(seed)`), the sampling loop and all selection rules are pinned by the
 reference's own code.
 """
+import collections.abc
 import ctypes
 import os
 
@@ -115,40 +116,111 @@ def select_positions(samples, n_saved, mode, direction):
     return n_keep, bounces, n_bounces
 
 
+def _seed_order_array(current_seed, batch_size, num_processes):
+    """`seed_order` as an int64 array (a stable sort of the batch by seed % num_processes)."""
+    k = np.arange(batch_size, dtype=np.int64)
+    return current_seed + k[np.argsort(k % num_processes, kind='stable')]
+
+
+class TrajectoryBatch(collections.abc.Sequence):
+    """What `get_valid_trajectories` returns: the survivors as STACKED arrays, read like the reference's list of dictionaries.
+
+    `len(batch)`, `batch[i]`, slices and iteration give reference-format dictionaries ('positions', 'velocities', 'rotations',
+    'times', 'Mext', 'Mint', 'bounces', 'seed'; mujocosimulation.py:213-218) that are built ON ACCESS as views of the stacked
+    buffers -- 125 000 trajectories are a handful of large arrays, not 125 000 x 8 small ones (building those was 96 % of the
+    call's time in round 4).  The views are read-only where several trajectories share the storage ('times', 'Mext', 'Mint').
+    `chunks`: one entry per device launch with `rows` (R, 9) float64 -- the kept samples of its trajectories back to back
+    (position, velocity, rotation) -- `offsets` (V+1,), `n_keep`, `bounces` (V, 4), `n_bounces`, `seeds`; `stacked()` concatenates them."""
+
+    def __init__(self, chunks, times, ex, mint):
+        self.chunks = chunks
+        self.times, self.Mext, self.Mint = times, ex, mint
+        self.times.setflags(write=False)
+        self._starts = np.concatenate([[0], np.cumsum([len(c['n_keep']) for c in chunks])]).astype(np.int64)
+
+    def __len__(self):
+        return int(self._starts[-1])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        n_all = len(self)
+        if i < 0:
+            i += n_all
+        if not 0 <= i < n_all:
+            raise IndexError('trajectory index out of range')
+        c = int(np.searchsorted(self._starts, i, side='right')) - 1
+        ch, j = self.chunks[c], int(i - self._starts[c])
+        o, n = int(ch['offsets'][j]), int(ch['n_keep'][j])
+        tr = ch['rows'][o:o + n]
+        return {'positions': tr[:, 0:3], 'velocities': tr[:, 3:6], 'rotations': tr[:, 6:9], 'times': self.times[:n],
+                'Mext': np.broadcast_to(self.Mext, (n, 4, 4)), 'Mint': np.broadcast_to(self.Mint, (n, 3, 3)),
+                'bounces': ch['bounces'][j, :int(ch['n_bounces'][j])], 'seed': int(ch['seeds'][j])}
+
+    def stacked(self):
+        """{'rows' (R, 9), 'offsets' (N+1,), 'n_keep' (N,), 'bounces' (N, 4), 'n_bounces' (N,), 'seeds' (N,)} over all launches."""
+        cat = torch.cat if any(torch.is_tensor(c['rows']) for c in self.chunks) else np.concatenate
+        nk = np.concatenate([c['n_keep'] for c in self.chunks]) if self.chunks else np.zeros(0, np.int64)
+        return {'rows': cat([c['rows'] for c in self.chunks]) if self.chunks else np.zeros((0, 9)),
+                'offsets': np.concatenate([[0], np.cumsum(nk)]).astype(np.int64), 'n_keep': nk,
+                'bounces': np.concatenate([c['bounces'] for c in self.chunks]) if self.chunks else np.zeros((0, 4)),
+                'n_bounces': np.concatenate([c['n_bounces'] for c in self.chunks]) if self.chunks else np.zeros(0, np.int32),
+                'seeds': np.concatenate([c['seeds'] for c in self.chunks]) if self.chunks else np.zeros(0, np.int64)}
+
+
 def get_valid_trajectories(num_trajectories, num_processes, mode, direction, substeps=SUBSTEPS, device=None, batches_per_launch=64,
                            as_numpy=True):
     """`get_valid_trajectories` (mujocosimulation.py:222-238): seeds are consumed in batches of min(1024, num_trajectories),
     each batch in the order the reference's `num_processes`-way pool returns it; the first `num_trajectories` survivors
-    are returned.  Several batches are integrated per launch (`batches_per_launch`); the result does not depend on it."""
+    are returned.  Several batches are integrated per launch (`batches_per_launch`); the result does not depend on it.
+
+    Returns a `TrajectoryBatch`: a sequence of reference-format dictionaries backed by stacked arrays.  Per launch the kept samples
+    of the survivors are packed back to back on the device ((rows, 9) float64) and copied into pinned host memory on a side stream
+    while the next launch integrates (as_numpy=False: they stay device tensors)."""
     times = save_times()
     ex, mint = camera_matrices()
     batch = min(1024, num_trajectories)
-    found, current = [], 0
-    while len(found) < num_trajectories:
-        seeds = []
-        for _ in range(batches_per_launch):
-            seeds.extend(seed_order(current, batch, num_processes))
-            current += batch
+    dev = torch.device(device if device is not None else 'cuda')
+    chunks, found, current = [], 0, 0
+    copy_stream = None
+    while found < num_trajectories:
+        seeds = np.concatenate([_seed_order_array(current + k * batch, batch, num_processes) for k in range(batches_per_launch)])
+        current += batch * batches_per_launch
         res = simulate_seeds(seeds, mode, direction, substeps, device)
         keep = res['n_keep']
         idx = torch.nonzero(keep > 0).flatten()
-        idx = idx[:num_trajectories - len(found)]
-        if idx.numel() == 0:
+        idx = idx[:num_trajectories - found]
+        v = int(idx.numel())
+        if v == 0:
             continue
-        sel = res['samples'][:, :, idx].permute(2, 0, 1).contiguous()           # (V, S, 9)
-        nk = keep[idx].cpu().numpy()
-        nb = res['n_bounces'][idx].cpu().numpy()
+        nk_dev = keep[idx].to(torch.int64)
+        sel = res['samples'].index_select(2, idx).permute(2, 0, 1)                  # (V, S, 9) view of the (S, 9, V) gather
+        mask = torch.arange(sel.shape[1], device=sel.device)[None, :] < nk_dev[:, None]
+        packed = sel[mask]                                                           # (rows, 9): every trajectory's kept samples, back to back
+        meta = torch.stack([nk_dev, res['n_bounces'][idx].to(torch.int64), res['seeds'][idx].to(torch.int64)]).cpu().numpy()
         bo = res['bounces'][idx].cpu().numpy()
-        sd = res['seeds'][idx].cpu().numpy()
-        sel_h = sel.cpu().numpy() if as_numpy else sel
-        for j in range(len(nk)):
-            n = int(nk[j])
-            tr = sel_h[j, :n]
-            found.append({'positions': tr[:, 0:3], 'velocities': tr[:, 3:6], 'rotations': tr[:, 6:9], 'times': times[:n].copy(),
-                          'Mext': np.repeat(ex[None], n, 0), 'Mint': np.repeat(mint[None], n, 0), 'bounces': bo[j, :int(nb[j])].copy(),
-                          'seed': int(sd[j])})
-    final = found[:num_trajectories]
-    return final
+        nk = meta[0]
+        if as_numpy:
+            if copy_stream is None:
+                copy_stream = torch.cuda.Stream(dev)
+            host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            copy_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_stream):
+                host.copy_(packed, non_blocking=True)
+            packed.record_stream(copy_stream)
+            rows = host
+        else:
+            rows = packed
+        chunks.append({'rows': rows, 'offsets': np.concatenate([[0], np.cumsum(nk)]).astype(np.int64), 'n_keep': nk,
+                       'bounces': bo, 'n_bounces': meta[1].astype(np.int32), 'seeds': meta[2]})
+        found += v
+        del res, sel, mask, packed
+    if copy_stream is not None:
+        copy_stream.synchronize()
+        for c in chunks:
+            c['_pinned'] = c['rows']                 # keeps the pinned block alive for the views below
+            c['rows'] = c['rows'].numpy()
+    return TrajectoryBatch(chunks, times, ex, mint)
 
 
 def save_dataset(path, trajectories_data):

@@ -331,6 +331,9 @@ class WASBNet:
             h._f32_twin = self._twin()
         if not h.certified or h.eps != self.eps or h.exact_windows != self.exact_windows:
             h.set_certify(self.eps, exact_windows=self.exact_windows)
+            # a one-sample handle defaults to ONE crop per call; a re-run frame may plan up to 8 per heatmap / 16 per frame, and what
+            # does not fit the budget goes to the full-frame fp32 repair (3.6 ms instead of 0.1 ms per crop; round-4 advisor)
+            h.certify_budget(min(16, 8 * self.OUT_CH))
         K = self.OUT_CH
         for t in np.unique(todo // K):
             t = int(t)
