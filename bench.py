@@ -207,6 +207,38 @@ def heatmap_roofline(device, eps_abs):
     return prod, seam
 
 
+def _cpu_child(style, n, threads):
+    """One CPU-oracle timing in a FRESH process (`python bench.py --cpu-child style n threads`): no GPU, its own thread pool.
+    Prints one JSON line {seconds, triples, threads}."""
+    torch.set_num_threads(threads)
+    from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
+    from upliftingtabletennis_amd import synth, weights
+    frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
+    sd = weights.random_wasb_state_dict(0, planted=True)
+    if style == 'b1':          # batch 1 per triple + table-variant fit, like interface.py:102-119, + one trajectory through the uplift net
+        usd = weights.random_uplift_state_dict(0, 'large')
+        x0 = glue_ref.triple_to_tensor(frames[0], frames[1], frames[2], (W_NET, H_NET))[None, :, :64]
+        wasb_ref.wasb_forward(x0, sd)                      # warm the pool (thread creation, allocator) on a 64-row strip, outside the timing
+        t0 = time.time()
+        for i in range(n):
+            x = glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET))[None]
+            heat = wasb_ref.wasb_forward(x, sd).numpy()
+            refine_ref.extract_position_table(heat, 1920, 1080)
+        ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=1)
+        rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
+        uplift_ref.transform_rotationaxes(rot, p3)
+        dt = time.time() - t0
+    else:                      # micro-batches of 4 + ball-variant fit, like inference/utils.py:51-59
+        x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
+        wasb_ref.wasb_forward(x[:1, :, :64], sd)
+        t0 = time.time()
+        for b0 in range(0, n, 4):
+            heat = wasb_ref.wasb_forward(x[b0:b0 + 4], sd).numpy()
+            refine_ref.extract_position_ball(heat, 1920, 1080)
+        dt = time.time() - t0
+    print(json.dumps({'seconds': dt, 'triples': n, 'threads': torch.get_num_threads()}), flush=True)
+
+
 def _cpu_model():
     try:
         for ln in open('/proc/cpuinfo'):
@@ -218,59 +250,50 @@ def _cpu_model():
 
 
 def cpu_baseline():
-    """The CPU oracle (torch fp32, kind "port") on a bounded sample of the same workload, on ALL host threads this process may
-    use ("all threads, core count stated" -- `cores` = len(os.sched_getaffinity(0)), the pool is widened
-    for this leg and restored afterwards), in the reference's two calling styles: (a) batch 1 per triple with the table-variant fit,
-    like the hub surface (interface.py:102-119), + one 120-point trajectory through the uplift net; (b) micro-batch 4 with the
-    ball-variant fit, like the evaluation path (inference/utils.py:51-59).  12 triples each.  `threads8` repeats style (a) on 8
-    threads (the figure of rounds 1-4, whose bench capped the pool at 8) on a smaller sample."""
-    from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
-    from upliftingtabletennis_amd import synth, weights
-    n = int(os.environ.get('TTUP_CPU_BASELINE_TRIPLES', '12'))
-    frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
-    sd = weights.random_wasb_state_dict(0, planted=True)
-    usd = weights.random_uplift_state_dict(0, 'large')
-    try:
-        all_cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        all_cores = os.cpu_count() or 1
-    model = _cpu_model()
-    before = torch.get_num_threads()
+    """The CPU oracle (torch fp32, kind "port") on a bounded sample of the same workload, in the reference's two calling styles:
+    (a) batch 1 per triple with the table-variant fit, like the hub surface (interface.py:102-119), + one 120-point trajectory through
+    the uplift net; (b) micro-batch 4 with the ball-variant fit, like the evaluation path (inference/utils.py:51-59).
 
-    def style_a(k):
-        t0 = time.time()
-        for i in range(k):          # batch 1 per triple, like interface.py:102-119
-            x = glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET))[None]
-            heat = wasb_ref.wasb_forward(x, sd).numpy()
-            refine_ref.extract_position_table(heat, 1920, 1080)
-        ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=1)
-        rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
-        uplift_ref.transform_rotationaxes(rot, p3)
-        return time.time() - t0
+    Threads ("all threads, core count stated"): every timing runs in a FRESH child process (CPU only, its
+    own OpenMP pool -- widening the pool of this process to 256 threads and back left the 8-thread figure six times slower).  A sweep
+    times ONE triple on all hardware threads, on the physical cores, on 32 and on 8 threads (a configuration slower than 20 s per
+    triple is cut off: torch's CPU convolutions at batch 1 do not scale to 256 threads -- 63 s per triple there); the sample (12
+    triples per style) then runs on the fastest.  `cores` = the threads that run used; `host_threads` = what the box offers."""
+    n = int(os.environ.get('TTUP_CPU_BASELINE_TRIPLES', '12'))
     try:
-        torch.set_num_threads(all_cores)
-        style_a(1)          # warm the widened pool (thread creation, first-touch of the conv workspaces) outside the timing
-        dt = style_a(n)
-        base = {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_model': model,
-                'sample': '%d triples 1280x720, batch 1 (resize+normalise, CNN fp32, table-variant refine) + 1 trajectory of %d points; %.1f s on %d threads'
-                          % (n, TRAJ_LEN, dt, torch.get_num_threads())}
-        t0 = time.time()
-        x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
-        for b0 in range(0, n, 4):
-            heat = wasb_ref.wasb_forward(x[b0:b0 + 4], sd).numpy()          # micro-batches of 4, inference/utils.py:51-57
-            refine_ref.extract_position_ball(heat, 1920, 1080)               # ball-variant fit, :59
-        dt4 = time.time() - t0
-        b4 = {'value': round(n / dt4, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_model': model,
-              'sample': '%d triples 1280x720 in micro-batches of 4 (resize+normalise, CNN fp32, ball-variant refine), inference/utils.py:51-59; %.1f s on %d threads'
-                        % (n, dt4, torch.get_num_threads())}
-        if all_cores > 8:
-            torch.set_num_threads(8)
-            n8 = max(2, n // 3)
-            dt8 = style_a(n8)
-            base['threads8'] = {'value': round(n8 / dt8, 4), 'unit': 'frames/s', 'cores': 8,
-                                'sample': 'the batch-1 style on 8 threads, %d triples; %.1f s (rounds 1-4 reported this figure)' % (n8, dt8)}
-    finally:
-        torch.set_num_threads(before)
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    model = _cpu_model()
+
+    def child(style, k, threads, timeout):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        env.pop('TTUP_LIB', None)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', style, str(k), str(threads)], env=env, cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
+            for ln in r.stdout.splitlines():
+                if ln.startswith('{'):
+                    return json.loads(ln)
+        except subprocess.TimeoutExpired:
+            return None
+        return None
+    sweep, best = [], None
+    for t in sorted({avail, max(1, avail // 2), min(32, avail), min(8, avail)}, reverse=True):
+        res = child('b1', 1, t, 30)
+        sweep.append({'threads': t, 'seconds_per_triple': round(res['seconds'], 2) if res else '> 20 (cut off)'})
+        if res and (best is None or res['seconds'] < best[1]):
+            best = (t, res['seconds'])
+    t_best = best[0] if best else min(8, avail)
+    ra = child('b1', n, t_best, 600)
+    rb = child('b4', n, t_best, 600)
+    base = {'value': round(n / ra['seconds'], 4) if ra else None, 'unit': 'frames/s', 'cores': t_best, 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
+            'sample': '%d triples 1280x720, batch 1 (resize+normalise, CNN fp32, table-variant refine) + 1 trajectory of %d points; %s s on %d threads (fresh process)'
+                      % (n, TRAJ_LEN, ('%.1f' % ra['seconds']) if ra else 'n/a', t_best),
+            'thread_sweep': sweep, 'thread_sweep_note': 'one triple of the batch-1 style per thread count, each in a fresh process; the sample runs on the fastest'}
+    b4 = {'value': round(n / rb['seconds'], 4) if rb else None, 'unit': 'frames/s', 'cores': t_best, 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
+          'sample': '%d triples 1280x720 in micro-batches of 4 (resize+normalise, CNN fp32, ball-variant refine), inference/utils.py:51-59; %s s on %d threads (fresh process)'
+                    % (n, ('%.1f' % rb['seconds']) if rb else 'n/a', t_best)}
     return base, b4
 
 
@@ -596,6 +619,8 @@ def pin_rank_to_cores(local, n_local):
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-child':          # a CPU-oracle timing of cpu_baseline(): never touches the GPU
+        return _cpu_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     a = parse()
     share = os.environ.get('TTUP_BENCH_SHARE_GPU') == '1'
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -37,7 +37,10 @@ def _wasb_case(g, name):
 
 
 # ------------------------------------------------------------------------------------------ a2: CNN
-XY_OUT_PX_BF16 = 0.05          # production-mode (bf16 window) bar of the refined xy in OUTPUT pixels; the measured value is printed by the test
+# production-mode (bf16 window) bars of the refined xy in OUTPUT pixels, about 2 x what is measured and printed by the test:
+# table variant (the hub surface's) 5.1e-3 measured; ball variant 3.2e-2 measured (its sigma bounds let the flat valley of a wide
+# blob move the optimum further for the same change of the window)
+XY_OUT_PX_BF16 = {'ball': 0.06, 'table': 0.011}
 
 
 @pytest.mark.parametrize('name', ['noise_64x96', 'noise_96x160', 'planted_96x160'])
@@ -86,7 +89,7 @@ def test_wasb_bf16_path_close_to_reference(golden, name):
 
 def test_wasb_fullsize_planted_argmax_and_refine(golden):
     """BASELINE size 704x1280: bit-exact argmax vs the reference run, refined position close to the
-    reference's (bf16 heatmap values differ slightly, so the fit input differs: XY_OUT_PX_BF16 px of 1920)."""
+    reference's (bf16 heatmap values differ slightly, so the fit input differs: XY_OUT_PX_BF16[variant] px of 1920)."""
     g = golden('wasb_full.npz')
     seed, b, h, w = [int(v) for v in g['meta']]
     sd = weights.random_wasb_state_dict(seed, planted=True)
@@ -109,7 +112,7 @@ def test_wasb_fullsize_planted_argmax_and_refine(golden):
         ref = g[key].reshape(b, 3)
         d_xy = np.abs(xyv[:, :2] - ref[:, :2]).max()
         print('\n[wasb_full, %s variant] refined xy %.2e output px (= %.2e network px) off the reference (bf16 windows)' % (key, d_xy, d_xy * w / 1920))
-        assert d_xy < XY_OUT_PX_BF16, (xyv, ref)
+        assert d_xy < XY_OUT_PX_BF16[key], (xyv, ref)
         assert np.array_equal(xyv[:, 2], ref[:, 2])
     # f32 path at full size: argmax identical as well
     net32 = wasb.WASBNet(sd, resolution=(w, h), max_batch=1, dtype='f32')

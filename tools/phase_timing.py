@@ -27,7 +27,7 @@ print('in-kernel shader clock: %.0f MHz (s_memtime span / s_memrealtime span x 1
 buf2 = np.zeros(3 * 32 * 64 * 8, dtype=np.uint64)
 lib.ttup_debug_read_timing_it(buf2.ctypes.data_as(ctypes.c_void_p), buf2.size)
 t2 = buf2.reshape(3, 32, 64, 8).astype(np.int64)
-for kid, name, labels in ((0, 'stem', ['wait top barrier', 'X0 commit+barrier+issue', 'conv1', 'barrier', 'conv2', 'epilogue+follower+stores (to next top)']),
+for kid, name, labels in ((0, 'stem', ['(empty)', 'top barrier', 'conv1', 'barrier + X0 commit (next tile) + issue', 'conv2', 'epilogue+follower+stores (to next top)']),
                           (2, 'bb32 (last launch)', ['wait top barrier', 'commit+barrier+issue', 'conv1', 'barrier', 'conv2+epilogue (to next top)']),
                           (1, 'bneck', ['wait top barrier', 'phase 1', 'barrier', 'phase 2a', 'phase 2b', 'barrier', 'partials+barrier+reduce (to next top)'])):
     x = t2[kid][:, 2:(60 if kid < 2 else 9)]                    # skip warm-up iterations (the 32-channel block has ~11 tiles per workgroup)

@@ -113,6 +113,17 @@ __device__ __forceinline__ void stage_store_512(bf16_t* dst, const StageRegs<UNI
     for (int k = 0; k < (UNITS + 511) / 512; ++k) { const int u = tid + k * 512; if (u < UNITS) ((u32x4*)dst)[u] = r.v[k]; }
 }
 
+// "These prefetched registers are needed HERE": an empty asm statement that takes them as inputs makes the compiler place its
+// s_waitcnt for their loads at this point and treat them as complete afterwards.  The persistent kernels call it BEFORE an epilogue
+// issues its stores: the vector-memory counter retires in order and the compiler cannot count stores that sit behind a branch, so a
+// wait for prefetched loads that comes AFTER the stores is an s_waitcnt vmcnt(0) -- it drains the stores just issued, with every wave
+// of the workgroup parked for a store round trip per tile (round 5: the stem spent 2.7 k of its 11.9 k cycles per tile there).
+template <int N>
+__device__ __forceinline__ void prefetch_arrived(const u32x4 (&r)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" :: "v"(r[k]));
+}
+
 // Persistent, software-pipelined version: a workgroup walks work items (tile, channel chunk); the global loads of
 // item i+1 (halo tile chunk + that chunk's weight fragments) are issued into registers BEFORE the MFMA loop of item i
 // and written to LDS after it, so HBM/L2 latency hides behind the matrix work (single LDS buffer, two barriers per item).
@@ -213,7 +224,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
     }
 
     f32x4 acc[MT][NT];
-    if (n_items > 0) issue(0);
+    if (n_items <= 0) return;          // (workgroup-uniform)
+    issue(0);
+    prefetch_arrived(pin); prefetch_arrived(pw);          // every path into the loop has the prefetch registers complete (see prefetch_arrived)
     for (int item = 0; item < n_items; ++item) {
         const int chunk = item % nchunk;
         if (item > 0) __syncthreads();          // every wave finished reading the previous item's LDS image
@@ -253,6 +266,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 #ifdef TTUP_ABLATE_EPILOGUE
         if (chunk != nchunk - 1 || a.H > 0) continue;
 #endif
+        // the next item's tile and weights (requested before the MFMA loop) are waited for HERE, in front of the epilogue's stores
+        // (on every path through the item: behind a branch the compiler would wait again at the top, prefetch_arrived)
+        prefetch_arrived(pin); prefetch_arrived(pw);
         if (chunk != nchunk - 1) continue;
         // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
         const int tl0 = blockIdx.x + (item / nchunk) * gridDim.x;
@@ -270,20 +286,34 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r];
-            auto add_term = [&](const bf16_t* base) {
-                const u32x2* rp = (const u32x2*)base;
+            // the terms are REQUESTED together and added in the reference's order (residual, res2, res3): a load issued behind the
+            // previous term's wait costs one memory round trip per term
+            // (wide outputs keep the one-term-at-a-time form: 3 x MT x 2 more registers do not fit beside 8 m-tiles of accumulators)
+            constexpr int TM = MT <= 4 ? MT : 1;
+            u32x2 tv[3][TM];
+            auto load_term = [&](int k, const bf16_t* base) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m) tv[k][m] = ((const u32x2*)base)[m];
+            };
+            auto add_term = [&](int k, const bf16_t* base) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const u32x2 rv = rp[m];
+                    const u32x2 rv = MT <= 4 ? tv[k][m < TM ? m : 0] : ((const u32x2*)base)[m];
                     v[m * 4 + 0] += bf16_to_f32((bf16_t)(rv.x & 0xffff));
                     v[m * 4 + 1] += bf16_to_f32((bf16_t)(rv.x >> 16));
                     v[m * 4 + 2] += bf16_to_f32((bf16_t)(rv.y & 0xffff));
                     v[m * 4 + 3] += bf16_to_f32((bf16_t)(rv.y >> 16));
                 }
             };
-            if (a.residual) add_term(a.residual + o);
-            if (a.res2) add_term(a.res2 + o);
-            if (a.res3) add_term(a.res3 + ((size_t)(b * (a.OH >> a.sh3) + (oy >> a.sh3)) * (a.OW >> a.sh3) + (ox >> a.sh3)) * COUT + g * 4 * MT);
+            const bf16_t* t3 = a.res3 ? a.res3 + ((size_t)(b * (a.OH >> a.sh3) + (oy >> a.sh3)) * (a.OW >> a.sh3) + (ox >> a.sh3)) * COUT + g * 4 * MT : nullptr;
+            if (MT <= 4) {
+                if (a.residual) load_term(0, a.residual + o);
+                if (a.res2) load_term(1, a.res2 + o);
+                if (a.res3) load_term(2, t3);
+            }
+            if (a.residual) add_term(0, a.residual + o);
+            if (a.res2) add_term(1, a.res2 + o);
+            if (a.res3) add_term(2, t3);
             unsigned pk[2 * MT];
 #pragma unroll
             for (int i = 0; i < 2 * MT; ++i) pk[i] = pack2(v[2 * i], v[2 * i + 1]);
@@ -366,6 +396,7 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
     stage_load_512<WA_UNITS>(wa, a.wpack, tid);
     stage_load_512<WB_UNITS>(wb, a.wpack_b, tid);
     u32x4 pin[IN_PT];
+    unsigned pin_ok = 0u;
     auto issue = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
@@ -376,11 +407,12 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
             const int c8 = u % (CK / 8), pix = u / (CK / 8);
             const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
             const bool ok = u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const u32x4 v = *(const u32x4*)(ok ? a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * CK + c8 * 8 : a.src0);      // branch-free: the loads go out together
-            pin[k] = u32x4{ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u};
+            pin[k] = *(const u32x4*)(ok ? a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * CK + c8 * 8 : a.src0);      // branch-free: the loads go out together
+            pin_ok = ok ? pin_ok | (1u << k) : pin_ok & ~(1u << k);       // zeroed when the unit is written to LDS: a select HERE would wait for the load at once (no prefetch)
         }
     };
-    if (my_tiles > 0) issue(0);
+    if (my_tiles <= 0) return;          // (workgroup-uniform)
+    issue(0);
     stage_store_512<WA_UNITS>(s_wa, wa, tid);
     stage_store_512<WB_UNITS>(s_wb, wb, tid);
     f32x4 bias_a[MTA], bias_b;
@@ -397,12 +429,14 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
     }
     // the wave's 16-pixel group of the 4x32 tile: row wave / 2, column half wave % 2
     const int r = wave >> 1, cg = wave & 1;
+    prefetch_arrived(pin);          // every path into the loop has the prefetch registers complete (see prefetch_arrived)
     for (int it = 0; it < my_tiles; ++it) {
         if (it > 0) __syncthreads();            // every wave finished reading the previous tile
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
             const int u = tid + k * 512;
-            if (u < IN_UNITS) { const int c8 = u % (CK / 8), pix = u / (CK / 8); *(u32x4*)(s_in + lds_off<CK, IW>(pix / IW, pix % IW, c8)) = pin[k]; }
+            const bool okk = (pin_ok >> k) & 1u;
+            if (u < IN_UNITS) { const int c8 = u % (CK / 8), pix = u / (CK / 8); *(u32x4*)(s_in + lds_off<CK, IW>(pix / IW, pix % IW, c8)) = u32x4{okk ? pin[k].x : 0u, okk ? pin[k].y : 0u, okk ? pin[k].z : 0u, okk ? pin[k].w : 0u}; }
         }
         __syncthreads();
         if (it + 1 < my_tiles) issue(it + 1);
@@ -414,6 +448,7 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
             for (int m = 0; m < MTA; ++m) acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(s_wa + ((s5 * MTA + m) * 64 + lane) * 8), bfr, acc_a[m], 0, 0, 0);
             acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(s_wb + (s5 * 64 + lane) * 8), bfr, acc_b, 0, 0, 0);
         }
+        prefetch_arrived(pin);          // the next tile's input is waited for in front of this tile's stores
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy = (tt / a.tiles_x) * TH + r, ox = (tt % a.tiles_x) * TW + cg * 16 + n;
@@ -444,6 +479,47 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
             const unsigned w0 = pack2(acc_b[0], acc_b[1]), w1 = pack2(acc_b[2], acc_b[3]);
             *(u32x2*)(a.dst_b + opix * 16 + g * 4) = u32x2{a.relu_b ? relu_pk(w0) : w0, a.relu_b ? relu_pk(w1) : w1};
         }
+    }
+}
+
+// 3x3 64 -> 64 on an 8x32 tile from LDS (conv64_kernel and the stem's conv2): both 32-channel planes of the 10x34 halo tile and all
+// 72 weight fragments are LDS-resident; a wave owns two vertically adjacent 16-pixel groups (rows 2q, 2q+1 of column half ch), whose
+// four input rows are read once per (plane, tap column) and shared by both outputs.  18 k-steps (plane c, tap column dx, tap row dy --
+// the summation order of every accumulator), 8 MFMAs each.
+// PIPELINED (round 5): the fragments of step s+1 are requested BEFORE the MFMAs of step s, and a scheduling barrier keeps the
+// requests where they are (the compiler otherwise sinks every ds_read to just in front of its first use: rrrr M wait M wait M ...,
+// i.e. four reads covered by one MFMA, then the LDS latency in the open, 18 times per tile with only two waves per SIMD to hide it).
+__device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_t* const (&bB)[3], const bf16_t* s_w, int wave, int lane) {
+    constexpr int IW = 34, NPIX = 340;
+    bf16x8 brow[2][4], af[2][4];
+    auto load_b = [&](bf16x8 (&br)[4], int c, int dx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)(bB[dx] + c * (NPIX * 32) + ((2 * (wave >> 1) + rr) * IW + (wave & 1) * 16) * 32);
+    };
+    auto load_a = [&](bf16x8 (&a4)[4], int st) __attribute__((always_inline)) {          // st = (c * 9 + dy * 3 + dx): the packed k-step
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a4[m] = *(const bf16x8*)(s_w + ((st * 4 + m) * 64 + lane) * 8);
+    };
+    load_b(brow[0], 0, 0);
+    load_a(af[0], 0);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        const int dy = s % 3, gi = s / 3;                       // gi = (plane, tap column) group: c = gi / 3, dx = gi % 3
+        if (s + 1 < 18) {
+            const int s1 = s + 1, dy1 = s1 % 3, g1 = s1 / 3, c1 = g1 / 3, dx1 = g1 % 3;
+            if (dy1 == 0) load_b(brow[g1 & 1], c1, dx1);
+            load_a(af[s1 & 1], c1 * 9 + dy1 * 3 + dx1);
+        }
+#ifndef TTUP_NO_FRAG_PIPELINE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][m], brow[gi & 1][dy + t], acc[m][t], 0, 0, 0);
+#ifndef TTUP_NO_FRAG_PIPELINE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
@@ -505,49 +581,53 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
                 pin[k] = *(const u32x4*)(a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * 64 + c8 * 8);
         }
     };
-    if (my_tiles > 0) issue(0);
-    stage_store_512<W_U>(s_w, wregs, tid);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
+    // The tile image of tile it+1 is committed to LDS in the MIDDLE of iteration it -- behind the barrier that ends the MFMA loop,
+    // BEFORE the epilogue's stores are issued: the wait for its loads (requested a whole tile earlier) then finds nothing recent in
+    // the vector-memory queue.  Committed at the loop top, behind the epilogue, the same wait was an s_waitcnt vmcnt(0) that also
+    // drained the stores just issued (the counter retires in order and the compiler cannot count stores behind a branch): every
+    // wave of the workgroup sat out a store round trip per tile with the matrix pipe idle (round 5).
+    auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
             const int u = tid + k * 512;
             if (u < IN_UNITS) { const int c8 = u & 7, pix = u >> 3; *(u32x4*)(s_in + (c8 >> 2) * (NPIX * 32) + lds_off<32, IW>(pix / IW, pix % IW, c8 & 3)) = pin[k]; }
         }
-        __syncthreads();
-        if (it + 1 < my_tiles) issue(it + 1);
+    };
+    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
+    issue(0);
+    stage_store_512<W_U>(s_w, wregs, tid);
+    commit();                           // unconditional: its wait also retires every older load (bias, follower fragments) on EVERY path into the
+    if (my_tiles > 1) issue(1);         // loop -- otherwise the first use of such a register inside the loop gets an s_waitcnt vmcnt(0) per tile
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();                      // this tile's image (and, on the first pass, the weights) visible
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
-        // two vertically adjacent 16-pixel groups per wave: their four input rows are read once per (chunk, tap column)
+        conv64_tile_mfma(acc, bB, s_w, wave, lane);
+        __syncthreads();                      // every wave is done reading this tile's image
+        // UNCONDITIONAL (on the last tile it re-writes a stale image nobody reads): behind a branch the compiler could not tell that
+        // the prefetch registers have been consumed and would put an s_waitcnt vmcnt(0) in front of the next issue() -- behind the
+        // epilogue's stores, i.e. the very drain this order is there to avoid
+        commit();
+        // the block input (residual) of BOTH pixel groups is requested before the first group's stores: a load behind a store would
+        // make its wait drain that store too
+        u32x4 rres[2][2];
+        if (a.residual) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 brow[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(bB[dx] + c * (NPIX * 32) + ((2 * (wave >> 1) + rr) * IW + (wave & 1) * 16) * 32);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    bf16x8 af[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w + (((c * 9 + dy * 3 + dx) * 4 + m) * 64 + lane) * 8);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[dy + t], acc[m][t], 0, 0, 0);
-                }
+            for (int t = 0; t < 2; ++t) {
+                const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
+                const bool ok = oy < a.H && ox < a.W;
+                const bf16_t* rp = a.residual + (ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 : 0);      // branch-free: masked lanes read the tensor's first bytes
+                rres[t][0] = *(const u32x4*)rp; rres[t][1] = *(const u32x4*)(rp + 8);
             }
+        }
+        // pass 1: both groups' outputs (bias + block input, ReLU, rounding) -- every residual value is consumed before the first store
+        u32x4 pk[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
-            const bool ok = oy < a.H && ox < a.W;
-            if (!(L16 || L32) && !ok) continue;           // with followers every lane stays for the MFMAs; only the stores are masked
-            const size_t opix = ok ? (size_t)(b * a.H + oy) * a.W + ox : 0;
-            const size_t o = opix * 64 + g * 16;
             float v[16];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -556,23 +636,32 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
             if (a.residual) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const u32x4 rv = *(const u32x4*)(a.residual + o + q * 8);
+                    const u32x4 rv = rres[t][q];
                     const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[q * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
                 }
             }
-            u32x4 pk[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[q][i] = a.relu ? relu_pk(w) : w; }
-                if (ok) *(u32x4*)(a.dst + o + q * 8) = pk[q];
-            }
+                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[t][q][i] = a.relu ? relu_pk(w) : w; }
+        }
+        // pass 2: stores and the fuse-layer followers
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
+            const bool ok = oy < a.H && ox < a.W;
+            if (!(L16 || L32) && !ok) continue;           // with followers every lane stays for the MFMAs; only the stores are masked
+            const size_t opix = ok ? (size_t)(b * a.H + oy) * a.W + ox : 0;
+            const size_t o = opix * 64 + g * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (ok) *(u32x4*)(a.dst + o + q * 8) = pk[t][q];
             if (L16) {
                 f32x4 c = bl16;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al16[k], __builtin_bit_cast(bf16x8, pk[k]), c, 0, 0, 0);
+                for (int k = 0; k < 2; ++k) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al16[k], __builtin_bit_cast(bf16x8, pk[t][k]), c, 0, 0, 0);
                 if (ok) *(u32x2*)(a.dl16 + opix * 16 + g * 4) = u32x2{pack2(c[0], c[1]), pack2(c[2], c[3])};
             }
             if (L32) {
@@ -580,10 +669,11 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al32[k][m], __builtin_bit_cast(bf16x8, pk[k]), c[m], 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al32[k][m], __builtin_bit_cast(bf16x8, pk[t][k]), c[m], 0, 0, 0);
                 if (ok) *(u32x4*)(a.dl32 + opix * 32 + g * 8) = u32x4{pack2(c[0][0], c[0][1]), pack2(c[0][2], c[0][3]), pack2(c[1][0], c[1][1]), pack2(c[1][2], c[1][3])};
             }
         }
+        if (it + 2 < my_tiles) issue(it + 2);       // behind the epilogue's own (residual) loads: their wait does not wait for these
     }
 }
 
@@ -710,17 +800,12 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
                 px[k & (NF ? 0 : 1)] = *(const u32x4*)(a.x0 + ((size_t)(b * a.H + gy) * a.W + gx) * 16 + c8 * 8);
         }
     };
-    if (my_tiles > 0) issue(0);
-    stage_store_512<W1_U>(s_w1, w1regs, tid);
-    stage_store_512<W2_U>(s_w2, w2regs, tid);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        TTUP_STAMP_IT(0, it, 0);
-        // The X0 tile was last read in conv1 of the previous tile, which every wave left before the barrier in the middle
-        // of that iteration: it can be overwritten without waiting.  ONE barrier then covers "X0 tile complete" and
-        // "previous conv2 done reading the T1 tile" (and the weights on the first pass).
+    // The X0 tile of tile it+1 is committed to LDS in the MIDDLE of iteration it: behind the barrier that ends conv1 (the last
+    // reader of the X0 buffer) and BEFORE conv2's epilogue issues its stores, and the loads of tile it+2 are requested right there.
+    // Committed at the loop top -- behind the epilogue -- the wait for the prefetched loads was an s_waitcnt vmcnt(0) that also
+    // drained the T2 / A1 stores just issued (the counter retires in order, and the compiler cannot count stores that sit behind
+    // a branch): 2.7 k of the tile's 11.9 k cycles with every wave of the CU parked (round 5).
+    auto commit = [&]() {
         if (NF) {
 #pragma unroll
             for (int k = 0; k < X_PT; ++k) {
@@ -731,9 +816,22 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k & (NF ? 0 : 1)]; }
         }
+    };
+    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
+    issue(0);
+    stage_store_512<W1_U>(s_w1, w1regs, tid);
+    stage_store_512<W2_U>(s_w2, w2regs, tid);
+    commit();                           // unconditional: its wait retires every older load (biases, follower fragments) on every path into the loop
+    if (my_tiles > 1) issue(1);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        TTUP_STAMP_IT(0, it, 0);
         TTUP_STAMP_IT(0, it, 1);
+        // ONE barrier covers "X0 tile complete" (committed in the middle of the previous iteration) and "previous conv2 done reading
+        // the T1 tile" (and the weights on the first pass)
         __syncthreads();
-        if (it + 1 < my_tiles) issue(it + 1);
         TTUP_STAMP_IT(0, it, 2);
         // ---------------- conv1 on the 10x34 region (22 groups of 16 pixels, linear pixel index)
 #pragma unroll
@@ -773,32 +871,16 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         }
         TTUP_STAMP_IT(0, it, 3);
         __syncthreads();
+        commit();                                        // conv1 was the X0 buffer's last reader; unconditional (see conv64_kernel): on the last tile a stale image nobody reads
+        if (it + 2 < my_tiles) issue(it + 2);
         TTUP_STAMP_IT(0, it, 4);
         // ---------------- conv2 on the 8x32 tile, both 32-channel planes straight from LDS
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
 #ifndef TTUP_ABLATE_S2
-        // a wave owns two vertically adjacent 16-pixel groups (rows 2q, 2q+1 of column half ch): the four input rows they
-        // touch are read once per (chunk, tap column) and shared by both outputs
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 brow[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(bB[dx] + c * (NP1 * 32) + ((2 * (wave >> 1) + rr) * TW1 + (wave & 1) * 16) * 32);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    bf16x8 af[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(s_w2 + (((c * 9 + dy * 3 + dx) * 4 + m) * 64 + lane) * 8);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[dy + t], acc[m][t], 0, 0, 0);
-                }
-            }
+        static_assert(TW1 == 34 && NP1 == 340, "conv64_tile_mfma's tile");
+        conv64_tile_mfma(acc, bB, s_w2, wave, lane);
 #endif
         TTUP_STAMP_IT(0, it, 5);
         // ---------------- T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
@@ -906,6 +988,16 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
 
     u32x4 pb[3][3];
     bool p_in[3];
+    // the lane's three halo pixels as (row << 8 | column), one register each, unpacked inside issue_pix behind an opaque copy: left to
+    // itself the compiler hoists the six quotients / remainders out of the tile loop and, at 256 registers, spills them -- and a
+    // spill's reload inside issue_pix is a scratch load whose s_waitcnt vmcnt(0) drains the stores in front of it
+    unsigned pyx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int pix = (wave + 8 * t) * 16 + n;
+        pix = pix < NPIX ? pix : NPIX - 1;
+        pyx[t] = (unsigned)((pix / IW) << 8 | (pix % IW));
+    }
     auto issue_pix = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
@@ -913,9 +1005,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t;
-            int pix = j * 16 + n;
-            pix = pix < NPIX ? pix : NPIX - 1;
-            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            unsigned q = pyx[t];
+            asm volatile("" : "+v"(q));
+            const int gy = gy0 + (int)(q >> 8), gx = gx0 + (int)(q & 255u);
             p_in[t] = j < NT1 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             const size_t gp = (size_t)(b * a.H + gy) * a.W + gx;
 #pragma unroll
@@ -925,10 +1017,14 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             }
         }
     };
-    if (my_tiles > 0) issue_pix(0);
+    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
+    issue_pix(0);
     stage_store_512<W1_U>(s_w1, w1regs, tid);
     stage_store_512<W5_U>(s_w5, w5regs, tid);
     if (tid < 128) s_b1[tid] = b1v;
+    // every path into the tile loop has the prefetch registers COMPLETE (here: the first tile's; inside the loop: prefetch_arrived in
+    // front of phase 2a's stores) -- a path on which they might be pending would put an s_waitcnt vmcnt(0) at the top of every tile
+    prefetch_arrived(pb[0]); prefetch_arrived(pb[1]); prefetch_arrived(pb[2]);
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
@@ -975,13 +1071,18 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         TTUP_STAMP_IT(1, it, 2);
         __syncthreads();
         TTUP_STAMP_IT(1, it, 3);
-        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phase 2
+#ifndef TTUP_BNECK_PIPELINE
+        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phase 2a
+#endif
         // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile.  A wave owns two VERTICALLY adjacent 16-pixel groups
         // (rows 2q, 2q+1 of column half ch): the four input rows they touch are read once per (chunk, tap column) and
         // shared by both outputs -- 4 fragment reads instead of 6.
         {
             const int q2 = wave >> 1, ch = wave & 1;
             f32x4 acc[2] = {b5, b5};
+#ifndef TTUP_BNECK_PIPELINE
+            // (the pipelined form below needs 28 more registers than this kernel has: at 256 it spills lane constants of issue_pix, whose
+            // reloads -- scratch loads -- put an s_waitcnt vmcnt(0) behind the tile's stores; experiment: -DTTUP_BNECK_PIPELINE)
 #pragma unroll 2
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -996,6 +1097,36 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, brow[dy + 1], acc[1], 0, 0, 0);
                     }
                 }
+#else
+            // pipelined like conv64_tile_mfma: the seven fragments of (chunk, tap column) group j+1 are requested before the six MFMAs
+            // of group j, and a scheduling barrier keeps the requests there (same k order per accumulator)
+            bf16x8 brow[2][4], af[2][3];
+            auto load_group = [&](int j, bf16x8 (&br)[4], bf16x8 (&a3)[3]) __attribute__((always_inline)) {
+                const int c = j / 3, dx = j % 3;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n + dx, c * 4 + g));
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) a3[dy] = *(const bf16x8*)(s_w5 + ((c * 9 + dy * 3 + dx) * 64 + lane) * 8);
+            };
+            load_group(0, brow[0], af[0]);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                if (j + 1 < 12) load_group(j + 1, brow[(j + 1) & 1], af[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j & 1][dy], brow[j & 1][dy], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j & 1][dy], brow[j & 1][dy + 1], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+#ifndef TTUP_BNECK_PIPELINE
+            // the next tile's pixel fragments (requested behind the barrier above) have had phase 2a to arrive: waited for HERE, in front
+            // of this tile's stores, not at the top of the next tile behind them (prefetch_arrived; unconditional: behind a branch the
+            // compiler would wait again at the top)
+            prefetch_arrived(pb[0]); prefetch_arrived(pb[1]); prefetch_arrived(pb[2]);
+#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int oy = oy0 + 2 * q2 + t, ox = ox0 + ch * 16 + n;
@@ -1004,6 +1135,11 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                         u32x2{relu_pk(pack2(acc[t][0], acc[t][1])), relu_pk(pack2(acc[t][2], acc[t][3]))};
             }
         }
+#ifdef TTUP_BNECK_PIPELINE
+        // next tile's pixel fragments: requested behind phase 2a (whose pipelined fragment reads need the 36 registers) and its
+        // stores, in flight during phase 2b and the reduction, waited for in front of the reduction's stores (prefetch_arrived)
+        if (it + 1 < my_tiles) issue_pix(it + 1);
+#endif
         TTUP_STAMP_IT(1, it, 4);
         // ---------------- phase 2b: 3x3 s2 128 -> 32, K-chunk cc / m-tile m6 of all four output rows
         f32x4 part[4];
@@ -1039,6 +1175,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             for (int c = 1; c < 4; ++c) v += *(const f32x4*)(s_part + (((mr * 4 + c) * 4 + rr) * 64 + lane) * 4);
             const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
             const int oy = (oy0 >> 1) + rr, ox = (ox0 >> 1) + n;
+#ifdef TTUP_BNECK_PIPELINE
+            prefetch_arrived(pb[0]); prefetch_arrived(pb[1]); prefetch_arrived(pb[2]);
+#endif
             if (oy < OH && ox < OW)
                 *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + mr * 4) = u32x2{relu_pk(pack2(v[0], v[1])), relu_pk(pack2(v[2], v[3]))};
         }
@@ -1405,6 +1544,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
             for (int xt = 0; xt < XT; ++xt)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[xt][m] = bias[m];
+#ifdef TTUP_NO_FRAG_PIPELINE
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 bf16x8 bfr[XT];
@@ -1416,6 +1556,26 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[xt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][m], bfr[xt], acc[xt][m], 0, 0, 0);
             }
+#else
+            // pipelined (see conv64_tile_mfma): the pixel fragments of k-step s+1 are requested before the MFMAs of step s
+            bf16x8 bfr[2][XT];
+            auto load_step = [&](int s, bf16x8 (&bf)[XT]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt)
+                    bf[xt] = (xt < XT - 1) ? *(const bf16x8*)(pk0[s] + yj * ROWSTEP + xt * 16 * C) : *(const bf16x8*)(pkl[s] + yj * ROWSTEP);
+            };
+            load_step(0, bfr[0]);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) load_step(s + 1, bfr[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[xt][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][m], bfr[s & 1][xt], acc[xt][m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
 #pragma unroll
             for (int xt = 0; xt < XT; ++xt) epi(xt, 8 * yj, y, acc[xt]);
         }
@@ -1575,6 +1735,10 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     bf16_t* bufA = (bf16_t*)smem;              // block input region (later overwritten in place by the block output)
     bf16_t* bufB = bufA + SZ_A;                // intermediate of the current block
     bf16_t* s_wt = bufB + SZ_B;                // weights: L slots (resident) or one rotating slot
+    // RESIDENT: the convs' biases and the follower's fragment + bias live in LDS too (BB_MISC_BYTES behind the weights).  Fetched
+    // from global memory inside the tile loop they were loads BEHIND the next tile's prefetch in the in-order vector-memory queue:
+    // their wait (s_waitcnt vmcnt(0)) held every conv's first MFMA until the whole prefetch had landed (round 5)
+    float* s_misc = (float*)(s_wt + (RESIDENT ? 2 * NB * W_UNITS * 8 : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row tests and row addresses on the scalar unit
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
@@ -1612,11 +1776,19 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         for (int cv = 0; cv < 2 * NB; ++cv)
 #pragma unroll
             for (int k = 0; k < W_PT; ++k) { const int u = tid + k * 512; if (u < W_UNITS) ((u32x4*)(s_wt + cv * W_UNITS * 8))[u] = pw2[cv][k]; }
+        // floats [0, C) bias of conv 0, [C, 2C) bias of conv 1, [2C, 2C+16) follower bias, then the follower's 64 x 16-byte fragment
+        if (tid < C) { s_misc[tid] = a.bias[0][tid]; s_misc[C + tid] = a.bias[1][tid]; }
+        if (a.yf) {
+            if (tid < 16) s_misc[2 * C + tid] = a.bf[tid];
+            if (tid >= 64 && tid < 128) ((u32x4*)(s_misc + 2 * C + 16))[tid - 64] = ((const u32x4*)a.wf)[tid - 64];
+        }
     } else {
         if (!WGLOBAL && my_tiles > 0) load_wt(0);
         if (my_tiles > 0) issue_in(0);
     }
 
+    if (my_tiles <= 0) return;          // (workgroup-uniform)
+    if (RESIDENT) prefetch_arrived(pin);          // every path into the loop has the prefetch registers complete (see prefetch_arrived)
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
@@ -1637,12 +1809,18 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
         const bf16_t* w0 = WGLOBAL ? a.w[0] : s_wt;
         const bf16_t* w1 = WGLOBAL ? a.w[1] : (RESIDENT ? s_wt + W_UNITS * 8 : s_wt);
         if (NB == 1) {
-            bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
+            const float* bias0 = RESIDENT ? s_misc : a.bias[0];
+            const float* bias1 = RESIDENT ? s_misc + C : a.bias[1];
+            const bf16_t* wfl = RESIDENT ? (const bf16_t*)(s_misc + 2 * C + 16) : a.wf;
+            const float* bfl = RESIDENT ? s_misc + 2 * C : a.bf;
+            bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, bias0, nullptr, oy0 - 1, ox0 - 1, a.H, a.W, b, wave, lane);
             if (C == 32) TTUP_STAMP_IT(2, it, 3);
             __syncthreads();
             if (C == 32) TTUP_STAMP_IT(2, it, 4);
             if (!WGLOBAL && !RESIDENT) { store_wt(0); __syncthreads(); if (it + 1 < my_tiles) load_wt(0); }
-            bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, a.bias[1], a.y, oy0, ox0, a.H, a.W, b, wave, lane, a.wf, a.bf, a.yf);
+            // the next tile's input (requested before the first conv) is waited for HERE, in front of the second conv's stores
+            if (RESIDENT) prefetch_arrived(pin);
+            bb_conv<C, R0W - 2, 0, TH, TW, true, R0W, 2, true, 1, 0>(bufB, nullptr, bufA, w1, bias1, a.y, oy0, ox0, a.H, a.W, b, wave, lane, wfl, bfl, a.yf);
         } else {
             static_assert(NB == 1 || WGLOBAL, "two-block chains read their weights from global memory");
             bb_conv<C, R0W, 0, R0H - 2, R0W - 2, false, 1, 0, false, R0W - 2, 0>(bufA, bufB, nullptr, w0, a.bias[0], nullptr, oy0 - 3, ox0 - 3, a.H, a.W, b, wave, lane);
@@ -1859,12 +2037,13 @@ static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
 }
 
 constexpr int BB_WT_SLOTS = 2;          // C=32: the weights of both convs of the block are LDS-resident
+constexpr int BB_MISC_BYTES = (2 * 32 + 16) * 4 + 1024;      // ... and so are their biases and the follower's bias + fragment (bb_chain_kernel: s_misc)
 template <int C, int NB, int TH, int TW>
 static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr int L = 2 * NB;
     constexpr int KSTEPS = (C == 16) ? 5 : 9, MT = C / 16;
     constexpr size_t SMEM = (size_t)((TH + 2 * L) * (TW + 2 * L) + (TH + 2 * L - 2) * (TW + 2 * L - 2)) * C * 2 +
-                            (size_t)(C == 16 ? 0 : BB_WT_SLOTS) * KSTEPS * MT * 1024;
+                            (size_t)(C == 16 ? 0 : BB_WT_SLOTS) * KSTEPS * MT * 1024 + (C == 16 ? 0 : BB_MISC_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     if (int rc = ensure_max_lds((const void*)bb_chain_kernel<C, NB, TH, TW>, SMEM)) return rc;
     BBArgs k = a;
