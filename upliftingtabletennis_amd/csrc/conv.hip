@@ -581,11 +581,6 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
                 pin[k] = *(const u32x4*)(a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * 64 + c8 * 8);
         }
     };
-    // The tile image of tile it+1 is committed to LDS in the MIDDLE of iteration it -- behind the barrier that ends the MFMA loop,
-    // BEFORE the epilogue's stores are issued: the wait for its loads (requested a whole tile earlier) then finds nothing recent in
-    // the vector-memory queue.  Committed at the loop top, behind the epilogue, the same wait was an s_waitcnt vmcnt(0) that also
-    // drained the stores just issued (the counter retires in order and the compiler cannot count stores behind a branch): every
-    // wave of the workgroup sat out a store round trip per tile with the matrix pipe idle (round 5).
     auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
@@ -596,22 +591,26 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
     issue(0);
     stage_store_512<W_U>(s_w, wregs, tid);
-    commit();                           // unconditional: its wait also retires every older load (bias, follower fragments) on EVERY path into the
-    if (my_tiles > 1) issue(1);         // loop -- otherwise the first use of such a register inside the loop gets an s_waitcnt vmcnt(0) per tile
+    // every path into the tile loop has the prefetch registers (and every older load: biases, follower fragments) COMPLETE -- a path on
+    // which one might be pending puts an s_waitcnt vmcnt(0) in front of its first use inside the loop, per tile (prefetch_arrived)
+    prefetch_arrived(pin);
     for (int it = 0; it < my_tiles; ++it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        __syncthreads();                      // this tile's image (and, on the first pass, the weights) visible
+        __syncthreads();                      // previous tile fully consumed (weights visible on the first pass)
+        commit();
+        __syncthreads();
+        if (it + 1 < my_tiles) issue(it + 1);
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
         conv64_tile_mfma(acc, bB, s_w, wave, lane);
-        __syncthreads();                      // every wave is done reading this tile's image
-        // UNCONDITIONAL (on the last tile it re-writes a stale image nobody reads): behind a branch the compiler could not tell that
-        // the prefetch registers have been consumed and would put an s_waitcnt vmcnt(0) in front of the next issue() -- behind the
-        // epilogue's stores, i.e. the very drain this order is there to avoid
-        commit();
+        // the next tile's image (requested before the MFMA loop) is waited for HERE, in front of the epilogue's stores: at the loop top,
+        // behind them, the same wait is an s_waitcnt vmcnt(0) that drains the stores as well (prefetch_arrived; unconditional).
+        // (Round 5 also tried committing the next image here, behind a barrier, and requesting tile it+2 behind the epilogue: it kept the
+        // vector-memory queue clean in the same way but ran 9 % slower -- 0.391 against 0.358 ms for the eight launches.)
+        prefetch_arrived(pin);
         // the block input (residual) of BOTH pixel groups is requested before the first group's stores: a load behind a store would
         // make its wait drain that store too
         u32x4 rres[2][2];
@@ -673,7 +672,6 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
                 if (ok) *(u32x4*)(a.dl32 + opix * 32 + g * 8) = u32x4{pack2(c[0][0], c[0][1]), pack2(c[0][2], c[0][3]), pack2(c[1][0], c[1][1]), pack2(c[1][2], c[1][3])};
             }
         }
-        if (it + 2 < my_tiles) issue(it + 2);       // behind the epilogue's own (residual) loads: their wait does not wait for these
     }
 }
 
@@ -1036,16 +1034,38 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         // ---------------- phase 1: layer1 halo tile.  Output-channel pairs outermost: a weight fragment read from LDS serves all
         // (up to three) pixel groups of the wave -- 24 fragment reads per wave and tile instead of 72 (the kernel is LDS-bound);
         // every accumulator still sums its three K chunks in the same order
+        // (pipelined like conv64_tile_mfma: the two weight fragments of step (q, chunk) + 1 -- and the next pair's bias -- are requested
+        // before the MFMAs of step (q, chunk); -DTTUP_NO_FRAG_PIPELINE: each step reads its own)
+        bf16x8 afp[2][2];
+        f32x4 bqp[2][2];
+        auto load_w1 = [&](int st, bf16x8 (&a2)[2]) __attribute__((always_inline)) {          // st = q * 3 + chunk
+            const int q = st / 3, chunk = st % 3;
+            a2[0] = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q) * 64 + lane) * 8);
+            a2[1] = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q + 1) * 64 + lane) * 8);
+        };
+        auto load_bq = [&](int q, f32x4 (&b2)[2]) __attribute__((always_inline)) {
+            b2[0] = *(const f32x4*)(s_b1 + g * 32 + q * 8); b2[1] = *(const f32x4*)(s_b1 + g * 32 + q * 8 + 4);
+        };
+        load_w1(0, afp[0]);
+        load_bq(0, bqp[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 acc[3][2];
-            const f32x4 bq0 = *(const f32x4*)(s_b1 + g * 32 + q * 8), bq1 = *(const f32x4*)(s_b1 + g * 32 + q * 8 + 4);
+            const f32x4 bq0 = bqp[q & 1][0], bq1 = bqp[q & 1][1];
 #pragma unroll
             for (int t = 0; t < 3; ++t) { acc[t][0] = bq0; acc[t][1] = bq1; }
 #pragma unroll
             for (int chunk = 0; chunk < 3; ++chunk) {
-                const bf16x8 af0 = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q) * 64 + lane) * 8);
-                const bf16x8 af1 = *(const bf16x8*)(s_w1 + ((chunk * 8 + 2 * q + 1) * 64 + lane) * 8);
+                const int st = q * 3 + chunk;
+#ifdef TTUP_NO_FRAG_PIPELINE
+                load_w1(st, afp[st & 1]);
+                if (chunk == 0) load_bq(q, bqp[q & 1]);
+#else
+                if (st + 1 < 12) load_w1(st + 1, afp[(st + 1) & 1]);
+                if (chunk == 0 && q + 1 < 4) load_bq(q + 1, bqp[(q + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                const bf16x8 af0 = afp[st & 1][0], af1 = afp[st & 1][1];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     if (wave + 8 * t >= NT1) continue;             // wave-uniform: waves 6 and 7 own two groups
@@ -1053,6 +1073,9 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr, acc[t][0], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr, acc[t][1], 0, 0, 0);
                 }
+#ifndef TTUP_NO_FRAG_PIPELINE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -1071,40 +1094,57 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         TTUP_STAMP_IT(1, it, 2);
         __syncthreads();
         TTUP_STAMP_IT(1, it, 3);
-#ifndef TTUP_BNECK_PIPELINE
-        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phase 2a
-#endif
+        if (it + 1 < my_tiles) issue_pix(it + 1);               // next tile's pixel fragments: in flight during phases 2a and 2b
         // ---------------- phase 2a: 3x3 s1 128 -> 16 on the LDS tile.  A wave owns two VERTICALLY adjacent 16-pixel groups
         // (rows 2q, 2q+1 of column half ch): the four input rows they touch are read once per (chunk, tap column) and
         // shared by both outputs -- 4 fragment reads instead of 6.
         {
             const int q2 = wave >> 1, ch = wave & 1;
             f32x4 acc[2] = {b5, b5};
-#ifndef TTUP_BNECK_PIPELINE
-            // (the pipelined form below needs 28 more registers than this kernel has: at 256 it spills lane constants of issue_pix, whose
-            // reloads -- scratch loads -- put an s_waitcnt vmcnt(0) behind the tile's stores; experiment: -DTTUP_BNECK_PIPELINE)
+#if defined(TTUP_NO_FRAG_PIPELINE) || defined(TTUP_ABL_2A_NOMFMA) || defined(TTUP_ABL_2A_NOLOAD)
 #pragma unroll 2
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     bf16x8 brow[4];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) brow[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n + dx, c * 4 + g));
+                    for (int rr = 0; rr < 4; ++rr) {
+#ifdef TTUP_ABL_2A_NOLOAD
+                        brow[rr] = __builtin_bit_cast(bf16x8, pb[rr % 3][dx]);          // (timing ablation: registers instead of LDS reads)
+#else
+                        brow[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n + dx, c * 4 + g));
+#endif
+                    }
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
+#ifdef TTUP_ABL_2A_NOLOAD
+                        const bf16x8 af = af6[dy * 3 + dx];
+#else
                         const bf16x8 af = *(const bf16x8*)(s_w5 + ((c * 9 + dy * 3 + dx) * 64 + lane) * 8);
+#endif
+#ifdef TTUP_ABL_2A_NOMFMA
+                        asm volatile("" :: "v"(af), "v"(brow[dy]), "v"(brow[dy + 1]));
+#else
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, brow[dy], acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, brow[dy + 1], acc[1], 0, 0, 0);
+#endif
                     }
                 }
 #else
             // pipelined like conv64_tile_mfma: the seven fragments of (chunk, tap column) group j+1 are requested before the six MFMAs
-            // of group j, and a scheduling barrier keeps the requests there (same k order per accumulator)
+            // of group j, and a scheduling barrier keeps the requests there (same k order per accumulator): phase 2a 5.2 k -> 4.7 k cycles,
+            // the kernel -3 % (round 5).  It needs 28 more registers than the plain loop: with the 48 swizzled fragment addresses hoisted out
+            // of the tile loop the kernel spilled lane constants of issue_pix, whose reloads (scratch loads) put an s_waitcnt vmcnt(0)
+            // behind the tile's stores -- hence the opaque column below
             bf16x8 brow[2][4], af[2][3];
+            // the lane's column as an OPAQUE per-tile value: the 48 swizzled fragment addresses of the unrolled groups are then computed
+            // where they are used (a few integer instructions each) instead of being hoisted out of the tile loop into 48 registers
+            int n_t = n;
+            asm volatile("" : "+v"(n_t));
             auto load_group = [&](int j, bf16x8 (&br)[4], bf16x8 (&a3)[3]) __attribute__((always_inline)) {
                 const int c = j / 3, dx = j % 3;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n + dx, c * 4 + g));
+                for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n_t + dx, c * 4 + g));
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) a3[dy] = *(const bf16x8*)(s_w5 + ((c * 9 + dy * 3 + dx) * 64 + lane) * 8);
             };
@@ -1121,12 +1161,6 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-#ifndef TTUP_BNECK_PIPELINE
-            // the next tile's pixel fragments (requested behind the barrier above) have had phase 2a to arrive: waited for HERE, in front
-            // of this tile's stores, not at the top of the next tile behind them (prefetch_arrived; unconditional: behind a branch the
-            // compiler would wait again at the top)
-            prefetch_arrived(pb[0]); prefetch_arrived(pb[1]); prefetch_arrived(pb[2]);
-#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int oy = oy0 + 2 * q2 + t, ox = ox0 + ch * 16 + n;
@@ -1135,11 +1169,6 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
                         u32x2{relu_pk(pack2(acc[t][0], acc[t][1])), relu_pk(pack2(acc[t][2], acc[t][3]))};
             }
         }
-#ifdef TTUP_BNECK_PIPELINE
-        // next tile's pixel fragments: requested behind phase 2a (whose pipelined fragment reads need the 36 registers) and its
-        // stores, in flight during phase 2b and the reduction, waited for in front of the reduction's stores (prefetch_arrived)
-        if (it + 1 < my_tiles) issue_pix(it + 1);
-#endif
         TTUP_STAMP_IT(1, it, 4);
         // ---------------- phase 2b: 3x3 s2 128 -> 32, K-chunk cc / m-tile m6 of all four output rows
         f32x4 part[4];
@@ -1175,9 +1204,12 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             for (int c = 1; c < 4; ++c) v += *(const f32x4*)(s_part + (((mr * 4 + c) * 4 + rr) * 64 + lane) * 4);
             const int OH = (a.H + 1) >> 1, OW = (a.W + 1) >> 1;
             const int oy = (oy0 >> 1) + rr, ox = (ox0 >> 1) + n;
-#ifdef TTUP_BNECK_PIPELINE
+            // The next tile's pixel fragments (requested at the start of phase 2a) are waited for HERE, in front of the tile's LAST stores:
+            // at the top of the next tile, behind them, the wait is an s_waitcnt vmcnt(0) that drains those stores as well
+            // (prefetch_arrived; unconditional: behind a branch the compiler would wait again at the top).  Not earlier: under load a
+            // read takes ~5 k cycles to come back (phase stamps, round 5: phase 2a lasted 5.2 k cycles with or without its MFMAs and LDS
+            // reads while the wait stood at its end) -- phases 2a, 2b and the two barriers together cover that, phase 2a alone does not.
             prefetch_arrived(pb[0]); prefetch_arrived(pb[1]); prefetch_arrived(pb[2]);
-#endif
             if (oy < OH && ox < OW)
                 *(u32x2*)(a.b1o + ((size_t)(b * OH + oy) * OW + ox) * 32 + g * 8 + mr * 4) = u32x2{relu_pk(pack2(v[0], v[1])), relu_pk(pack2(v[2], v[3]))};
         }
