@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
     };
 
     f32x4 pin[IN_PT][2];
+    unsigned pin_ok = 0u;                              // bit k: unit k of the prefetched item lies inside the image (the others are written as zeros)
     u32x4 pw[W_PT];
     bool w_loaded = false, w_stored = false;          // single-chunk convs: the weights are staged with the first item the workgroup runs
     auto issue = [&](int item) {
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
             // branch-free: an invalid unit reads the tensor's first bytes and is zeroed (a branch around the load would serialise the loads)
             const bool ok = u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             const float* p = ok ? src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8 : a.src0;
-            const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            pin[k][0] = ok ? lo : z; pin[k][1] = ok ? hi : z;
+            // the zeroing happens when the unit is committed to LDS: a select HERE makes the compiler wait for the load at once -- the
+            // "prefetch" then sits out a whole memory round trip in front of every item's MFMA loop (round 5)
+            pin[k][0] = *(const f32x4*)p; pin[k][1] = *(const f32x4*)(p + 4);
+            pin_ok = ok ? pin_ok | (1u << k) : pin_ok & ~(1u << k);
         }
         if (nchunk > 1 || !w_loaded) {
             const u32x4* wsrc = (const u32x4*)(wblk + (size_t)chunk * 3 * W_ELEMS);
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
             if (u < IN_UNITS) {
                 const int c8 = u % (CK / 8), pix = u / (CK / 8);
                 u32x4 p0, p1, p2;
-                x3_split8(pin[k][0], pin[k][1], p0, p1, p2);
+                const bool okk = (pin_ok >> k) & 1u;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                x3_split8(okk ? pin[k][0] : z, okk ? pin[k][1] : z, p0, p1, p2);
                 bf16_t* d = s_in + x3_off<CK, IW>(pix / IW, pix % IW, c8);
                 *(u32x4*)d = p0; *(u32x4*)(d + IN_ELEMS) = p1; *(u32x4*)(d + 2 * IN_ELEMS) = p2;
             }
@@ -187,7 +191,18 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
 
     f32x4 acc[MT][NT];
     int item = next_item(0);
-    if (item < n_items) issue(item);
+    if (item >= n_items) return;          // (workgroup-uniform)
+    issue(item);
+    // every path into the item loop has the prefetch registers complete; inside the loop they are waited for right behind the MFMA loop,
+    // in front of the epilogue's stores (at the top of the next item, behind the stores, the wait would be an s_waitcnt vmcnt(0) that
+    // drains them too: csrc/conv.hip prefetch_arrived)
+    auto arrived = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) asm volatile("" :: "v"(pin[k][0]), "v"(pin[k][1]));
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) asm volatile("" :: "v"(pw[k]));
+    };
+    arrived();
     bool first = true;
     for (; item < n_items;) {
         const int nxt = next_item(item + 1);
@@ -203,16 +218,14 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[m][t] = bias[m];
         }
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            bf16x8 af[3][MT];
+        // the fragments of one k-step: 3 planes x (MT weight + NT pixel) 16-byte reads
+        auto load_step = [&](int s, bf16x8 (&af)[3][MT], bf16x8 (&bfr)[3][NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) af[p][m] = *(const bf16x8*)(s_w + p * W_ELEMS + ((s * MT + m) * 64 + lane) * 8);
             const bf16_t* bp = (CK == 32) ? bB[s % KS] : bB[s];
             const int dyc = (CK == 32) ? s / KS : 0;
-            bf16x8 bfr[3][NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int nt = wave * NT + t;        // wave-uniform
@@ -220,7 +233,9 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bfr[p][t] = *(const bf16x8*)(bp + p * IN_ELEMS + ((r * S + dyc) * IW + cg * 16 * S) * CK);
             }
-            // six partial products, smallest first; the MT x NT accumulators are independent chains between two dependent MFMAs
+        };
+        // six partial products, smallest first; the MT x NT accumulators are independent chains between two dependent MFMAs
+        auto mfma_step = [&](const bf16x8 (&af)[3][MT], const bf16x8 (&bfr)[3][NT]) __attribute__((always_inline)) {
             constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
@@ -228,7 +243,35 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[q]][m], bfr[PB[q]][t], acc[m][t], 0, 0, 0);
+        };
+#ifdef TTUP_X3_FRAG_PIPELINE
+        constexpr bool PIPE = MT == 1;          // two fragment sets are 24 (MT + NT) registers: only the 16-cout blocks have them to spare
+#else
+        // measured (round 5, full frame and 256 / 384-pixel crops): the pipelined form is 2-3 % SLOWER here (3.50 against 3.39 ms per
+        // frame) -- it costs the 16-channel kernels an occupancy step (116 -> 132 registers: one workgroup per CU instead of two)
+        constexpr bool PIPE = false;
+#endif
+        if constexpr (PIPE) {
+            // pipelined like conv64_tile_mfma (csrc/conv.hip): the fragments of k-step s+1 are requested before the MFMAs of step s and a
+            // scheduling barrier keeps the requests there -- same summation order per accumulator
+            bf16x8 af[2][3][MT], bfr[2][3][NT];
+            load_step(0, af[0], bfr[0]);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) load_step(s + 1, af[(s + 1) & 1], bfr[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(af[s & 1], bfr[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                bf16x8 af[3][MT], bfr[3][NT];
+                load_step(s, af, bfr);
+                mfma_step(af, bfr);
+            }
         }
+        arrived();
         if (chunk != nchunk - 1) { item = nxt; continue; }
         // ---- epilogue: lane holds couts co_base + [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
