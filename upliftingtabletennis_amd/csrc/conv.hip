@@ -118,8 +118,8 @@ __device__ __forceinline__ void stage_store_512(bf16_t* dst, const StageRegs<UNI
 // issues its stores: the vector-memory counter retires in order and the compiler cannot count stores that sit behind a branch, so a
 // wait for prefetched loads that comes AFTER the stores is an s_waitcnt vmcnt(0) -- it drains the stores just issued, with every wave
 // of the workgroup parked for a store round trip per tile (round 5: the stem spent 2.7 k of its 11.9 k cycles per tile there).
-template <int N>
-__device__ __forceinline__ void prefetch_arrived(const u32x4 (&r)[N]) {
+template <typename T, int N>
+__device__ __forceinline__ void prefetch_arrived(const T (&r)[N]) {
 #pragma unroll
     for (int k = 0; k < N; ++k) asm volatile("" :: "v"(r[k]));
 }
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
 #ifdef TTUP_ABLATE_EPILOGUE
         if (chunk != nchunk - 1 || a.H > 0) continue;
 #endif
-        // the next item's tile and weights (requested before the MFMA loop) are waited for HERE, in front of the epilogue's stores
-        // (on every path through the item: behind a branch the compiler would wait again at the top, prefetch_arrived)
-        prefetch_arrived(pin); prefetch_arrived(pw);
+        // (no prefetch_arrived in front of the epilogue here: this kernel runs two to four workgroups per CU, another workgroup's MFMAs
+        // cover a store drain at the top of the next item, and the HBM-bound 32 -> 32 conv at full resolution measured 4 % SLOWER with
+        // the wait moved in front of its stores -- 0.204 against 0.196 ms, round 5)
         if (chunk != nchunk - 1) continue;
         // ---- epilogue: lane holds couts [g*4*MT, (g+1)*4*MT) of pixel n of each of its N-tiles
         const int tl0 = blockIdx.x + (item / nchunk) * gridDim.x;
@@ -1137,14 +1137,22 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
             // of the tile loop the kernel spilled lane constants of issue_pix, whose reloads (scratch loads) put an s_waitcnt vmcnt(0)
             // behind the tile's stores -- hence the opaque column below
             bf16x8 brow[2][4], af[2][3];
-            // the lane's column as an OPAQUE per-tile value: the 48 swizzled fragment addresses of the unrolled groups are then computed
-            // where they are used (a few integer instructions each) instead of being hoisted out of the tile loop into 48 registers
-            int n_t = n;
-            asm volatile("" : "+v"(n_t));
+            // Swizzled fragment addresses from NINE lane constants instead of 48: pixel P0 + rr * 34 + dx has (pixel & 15) = (P0 + t) & 15
+            // with t = 2 rr + dx (34 = 2 mod 16), and chunk (4 c + g) ^ (pixel & 15) = (g ^ (pixel & 15)) ^ (c << 2): the byte address is
+            // (bt[t] ^ (c << 6)) + (rr * 34 + dx) * 256 with bt[t] = P0 * 256 + ((g ^ ((P0 + t) & 15)) << 4) -- one v_xor per read, the
+            // rest an instruction immediate.  (Written out through l1_off the compiler either hoists 48 addresses out of the tile loop,
+            // which spills, or recomputes each with five integer instructions: +240 vector instructions per tile in a kernel whose
+            // vector issue port is as busy as its matrix pipe.)
+            unsigned bt[9];
+            {
+                const int P0 = (2 * q2) * IW + ch * 16 + n;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bt[t] = (unsigned)(P0 * 256) + (unsigned)(((g ^ ((P0 + t) & 15)) & 15) << 4);
+            }
             auto load_group = [&](int j, bf16x8 (&br)[4], bf16x8 (&a3)[3]) __attribute__((always_inline)) {
                 const int c = j / 3, dx = j % 3;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)(s_l1 + l1_off((2 * q2 + rr) * IW + ch * 16 + n_t + dx, c * 4 + g));
+                for (int rr = 0; rr < 4; ++rr) br[rr] = *(const bf16x8*)((const char*)s_l1 + (bt[2 * rr + dx] ^ (unsigned)(c << 6)) + (rr * IW + dx) * 256);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) a3[dy] = *(const bf16x8*)(s_w5 + ((c * 9 + dy * 3 + dx) * 64 + lane) * 8);
             };
@@ -1349,18 +1357,26 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // 7 = stage-4 tail (3 terms, nothing stored but the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
 // a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
 template <int R> struct BBRow { static constexpr int value = R; };
-template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0>
+// NWV (C=32 only): waves that share the conv's rows -- `wave` is the wave's index among them (rows wave, wave + NWV, ...).  af32: the C=32
+// conv's 18 weight fragments already in registers (bb32_duo_kernel keeps them there for the life of the workgroup).
+template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0, int NWV = 8>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
                                         const BBArgs* ex = nullptr, BBBest* best = nullptr, const BBFrag16* pre = nullptr,
-                                        const BBTermLds* tl = nullptr, bf16x8 idm_pre = bf16x8{}) {
+                                        const BBTermLds* tl = nullptr, bf16x8 idm_pre = bf16x8{}, const bf16x8* af32 = nullptr) {
     constexpr int MT = C / 16;
     constexpr int KSTEPS = (C == 16) ? 5 : 9;
     constexpr int XT = (RWO + 15) / 16;
+    static_assert(NWV == 8 || C == 32, "only the 32-channel row loop takes a wave count");
     const int n = lane & 15, g = lane >> 4;
     bf16x8 af[KSTEPS][MT];
-    if (C == 16 && pre) {
+    if (C == 32 && af32) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[s][m] = af32[s * MT + m];
+    } else if (C == 16 && pre) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) af[s][0] = pre->af[s < 5 ? s : 4];
     } else {
@@ -1418,7 +1434,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { pk0[s] = row0 + n * C + koff[s]; pkl[s] = row0 + (XLAST + nl) * C + koff[s]; }
     }
-    constexpr int ROWSTEP = 8 * RWI * C;
+    constexpr int ROWSTEP = NWV * RWI * C;
     int tx[3] = {0, 0, 0};
     if constexpr (CAN_SUM && MODE > 0 && MODE != 4) {
 #pragma unroll
@@ -1566,10 +1582,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     };
     if constexpr (!BAND) {
         // (the run-time epilogue form, MODE 0 with the fuse sum, is a cross-check path and stays rolled: unrolled it spills)
-        constexpr int ROW_UNROLL = (RHO + 7) / 8;
+        constexpr int ROW_UNROLL = (RHO + NWV - 1) / NWV;
 #pragma unroll ROW_UNROLL
-        for (int yj = 0; yj < (RHO + 7) / 8; ++yj) {
-            const int y = wave + 8 * yj;
+        for (int yj = 0; yj < (RHO + NWV - 1) / NWV; ++yj) {
+            const int y = wave + NWV * yj;
             if (y >= RHO) break;
             f32x4 acc[XT][MT];
 #pragma unroll
@@ -1609,7 +1625,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
             }
 #endif
 #pragma unroll
-            for (int xt = 0; xt < XT; ++xt) epi(xt, 8 * yj, y, acc[xt]);
+            for (int xt = 0; xt < XT; ++xt) epi(xt, NWV * yj, y, acc[xt]);
         }
     } else {
         const int h = g >> 1, c8 = g & 1;
@@ -1864,6 +1880,128 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
             bb_conv<C, R0W - 6, 0, TH, TW, true, R0W, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane);
         }
     }
+}
+
+// ------------------------------------------------------------------ 32-channel BasicBlock, two wave groups in opposite phases (round 5)
+// bb_chain_kernel<32> runs its eight waves in lockstep: stage the tile, conv1, barrier, conv2 + stores -- both waves of a SIMD wait
+// for LDS, sit at the barriers and pack their outputs AT THE SAME TIME, and the matrix pipe is busy 47 % of the tile (phase stamps:
+// 2.4 k of 15 k cycles in commit + barrier + issue alone).  Here the workgroup is a two-stage pipeline over half-height tiles:
+//   group A (waves 0-3) : conv1 of tile t        -> bufB[t & 1];  then commits tile t+1 (prefetched) -> bufA[(t+1) % 3], requests tile t+2
+//   group B (waves 4-7) : conv2 of tile t-1      <- bufB[(t-1) & 1] + block input bufA[(t-1) % 3]     -> global stores (+ 1x1 follower)
+// with ONE workgroup barrier per tile.  Every SIMD holds one wave of each group, so one wave's LDS round trips, packing, stores and
+// barrier skew run under the other wave's MFMAs instead of beside its own copies of the same stalls.  Each wave keeps the 18 weight
+// fragments of ITS conv in registers for the life of the workgroup (no weights in LDS: three input buffers fit instead -- the block
+// input of tile t is still the residual of conv2 while tile t+1 is being committed).  Group A issues no stores and group B no loads of
+// its own, so neither group's vector-memory waits see the other's traffic.  Same arithmetic per output pixel as bb_chain_kernel<32>
+// (same k order, same roundings): bit-identical results.
+// MEASURED (round 5): 1.5 % slower than bb_chain_kernel<32> -- a phase still takes 7.8 k cycles for 3.55 k cycles of MFMAs per SIMD.  The
+// stalls it was built to overlap are not what limits these kernels: both waves of a SIMD share ONE vector issue port, every vector
+// instruction costs ~4 of its cycles and an MFMA holds it for 8 of its 16, and the two groups issue ~600 + ~500 vector instructions
+// around their 117 + 105 MFMAs per phase -- 6.1 k cycles of issue whichever way the waves are staggered.  What helps is fewer vector
+// instructions per MFMA (the Bottleneck tail's address diet: -8 %).  Selected by TTUP_BB32_DUO=1; the default is the one-phase kernel.
+template <int TH, int TW>
+__global__ __launch_bounds__(512) void bb32_duo_kernel(BBArgs a) {
+    constexpr int C = 32;
+    constexpr int R0H = TH + 4, R0W = TW + 4, R1H = TH + 2, R1W = TW + 2;
+    constexpr int SZ_A = R0H * R0W * C, SZ_B = R1H * R1W * C;
+    constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* bufA = (bf16_t*)smem;                    // [3][SZ_A]
+    bf16_t* bufB = bufA + 3 * SZ_A;                  // [2][SZ_B]
+    float* s_misc = (float*)(bufB + 2 * SZ_B);       // floats [0,32) bias of conv 0, [32,64) bias of conv 1, [64,80) follower bias, then its 64 x 16-byte fragment
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
+    if (tid < C) { s_misc[tid] = a.bias[0][tid]; s_misc[C + tid] = a.bias[1][tid]; }
+    if (a.yf) {
+        if (tid < 16) s_misc[2 * C + tid] = a.bf[tid];
+        if (tid >= 64 && tid < 128) ((u32x4*)(s_misc + 2 * C + 16))[tid - 64] = ((const u32x4*)a.wf)[tid - 64];
+    }
+    // the wave's own conv: its 18 weight fragments stay in registers
+    bf16x8 afr[18];
+    {
+        const bf16_t* wsrc = grp ? a.w[1] : a.w[0];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) afr[k] = *(const bf16x8*)(wsrc + (k * 64 + lane) * 8);
+    }
+    u32x4 pin[IN_PT];
+    unsigned pin_ok = 0u;
+    auto tile_origin = [&](int it, int& b, int& oy0, int& ox0) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        b = tl / a.tiles_per_img;
+        const int tt = tl % a.tiles_per_img;
+        oy0 = (tt / a.tiles_x) * TH; ox0 = (tt % a.tiles_x) * TW;
+    };
+    auto issue_in = [&](int it) {          // group A: branch-free (the loads go out together); zeroed when the unit is written to LDS
+        int b, oy0, ox0;
+        tile_origin(it, b, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = gtid + k * 256;
+            const int c8 = u & 3, pix = u >> 2;
+            const int gy = oy0 - 2 + pix / R0W, gx = ox0 - 2 + pix % R0W;
+            const bool ok = u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pin[k] = *(const u32x4*)(ok ? a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8 : a.x);
+            pin_ok = ok ? pin_ok | (1u << k) : pin_ok & ~(1u << k);
+        }
+    };
+    auto commit_in = [&](bf16_t* dstbuf) {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = gtid + k * 256;
+            const bool okk = (pin_ok >> k) & 1u;
+            if (u < IN_UNITS) { const int c8 = u & 3, pix = u >> 2; *(u32x4*)(dstbuf + bb_off<C>(pix, pix % R0W, c8)) = u32x4{okk ? pin[k].x : 0u, okk ? pin[k].y : 0u, okk ? pin[k].z : 0u, okk ? pin[k].w : 0u}; }
+        }
+    };
+    prefetch_arrived(afr);          // complete on EVERY path into the tile loop: a fragment pending on one of them would be waited for inside
+                                    // the loop with s_waitcnt vmcnt(0), i.e. behind group A's freshly requested prefetch, per tile
+    if (grp == 0) {
+        issue_in(0);
+        commit_in(bufA);
+        if (my_tiles > 1) issue_in(1);
+    }
+    __syncthreads();
+    const float* bias0 = s_misc;
+    const float* bias1 = s_misc + C;
+    const bf16_t* wfl = (const bf16_t*)(s_misc + 2 * C + 16);
+    const float* bfl = s_misc + 2 * C;
+    for (int p = 0; p <= my_tiles; ++p) {
+        if (grp == 0) {
+            if (p < my_tiles) {
+                int b, oy0, ox0;
+                tile_origin(p, b, oy0, ox0);
+                bb_conv<C, R0W, 0, R1H, R1W, false, 1, 0, false, R1W, 0, 0, 4>(bufA + (p % 3) * SZ_A, bufB + (p & 1) * SZ_B, nullptr, nullptr, bias0, nullptr,
+                                                                                 oy0 - 1, ox0 - 1, a.H, a.W, b, gw, lane,
+                                                                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bf16x8{}, afr);
+            }
+            if (p + 1 < my_tiles) {
+                commit_in(bufA + ((p + 1) % 3) * SZ_A);          // last read (as conv2's block input) two phases ago
+                if (p + 2 < my_tiles) issue_in(p + 2);
+            }
+        } else if (p >= 1) {
+            int b, oy0, ox0;
+            tile_origin(p - 1, b, oy0, ox0);
+            bb_conv<C, R1W, 0, TH, TW, true, R0W, 2, true, 1, 0, 0, 4>(bufB + ((p - 1) & 1) * SZ_B, nullptr, bufA + ((p - 1) % 3) * SZ_A, nullptr, bias1, a.y,
+                                                                         oy0, ox0, a.H, a.W, b, gw, lane, wfl, bfl, a.yf,
+                                                                         nullptr, nullptr, nullptr, nullptr, bf16x8{}, afr);
+        }
+        __syncthreads();
+    }
+}
+
+template <int TH, int TW>
+static int launch_bb32_duo(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
+    constexpr size_t SMEM = (size_t)(3 * (TH + 4) * (TW + 4) + 2 * (TH + 2) * (TW + 2)) * 32 * 2 + (2 * 32 + 16) * 4 + 1024;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    if (int rc = ensure_max_lds((const void*)bb32_duo_kernel<TH, TW>, SMEM)) return rc;
+    BBArgs k = a;
+    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
+    const int grid = k.total_tiles < 256 ? k.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL((bb32_duo_kernel<TH, TW>), dim3(grid), dim3(512), SMEM, st, k);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
 }
 
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
@@ -2139,7 +2277,13 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         return launch_bb2_t<16, BB2_TH, BB2_TW, 0>(a, batch, h, w, st);
     }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
-    if (c == 32 && n_convs == 2) return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);       // conv regions 24x32 / 22x30
+    if (c == 32 && n_convs == 2) {
+        // TTUP_BB32_DUO=1: the two-wave-group pipeline (bb32_duo_kernel), bit-identical and 1.5 % SLOWER than the one-phase kernel (round 5,
+        // same box: 0.571-0.575 against 0.563-0.569 ms for the six launches) -- kept as the measured experiment it is
+        static const bool duo = getenv("TTUP_BB32_DUO") != nullptr;
+        if (duo) return launch_bb32_duo<11, 30>(a, batch, h, w, st);            // two wave groups in opposite phases: conv regions 13x32 / 11x30
+        return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);                   // conv regions 24x32 / 22x30
+    }
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
     return TTUP_EINVAL;
 }
