@@ -726,17 +726,27 @@ struct StemArgs {
 // (3 colours + 0) and a sample's X0 pixel is assembled in LDS from the NF frames it spans (slot f*4 + c; conv1's weights are
 // packed in that channel order): the 16-channel per-triple tensor -- 3 copies of every frame plus 7 zero channels -- is never
 // written or read (28.8 -> 7.2 MB of pre-processing output per frame, 28.8 -> 21.6 MB of stem input).
-template <int NF>
+// K4 (NF = 3 only, round 5): conv1 in FOUR k-steps instead of five.  The X0 pixel record is the three frames' (B, G, R, 0) slots back to
+// back -- 12 slots, 24 bytes -- so the three pixels under a tap row are 36 CONTIGUOUS slots of LDS: conv1's K dimension becomes
+// 3 tap rows x 40 slots (36 + 4 that carry zero weights) = 120 -> 128 = 4 k-steps of 32, a fragment = 8 consecutive slots of one row
+// (two 8-byte LDS reads: the records are 8-byte aligned).  The 16-slot records (each frame's 4 slots + 4 zero slots, two taps per
+// k-step) need 5 k-steps for the 81 real products: 20 % of conv1's MFMAs and 4 KB of its weights gone.  Weights: StemArgs::w1 packed
+// as a "1x1 conv with 128 inputs" in that slot order (csrc/wasb_net.hip).  Another fp32 summation order than the 5-step form (and
+// than the layer-wise conv): results agree to bf16 rounding flips, like the other fused kernels (tests/test_gpu_parity.py).
+template <int NF, bool K4 = false>
 __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
+    static_assert(!K4 || NF == 3, "the 4-step conv1 is the three-frame form");
     constexpr int XH = 12, XW = 36, TH1 = 10, TW1 = 34, NP1 = TH1 * TW1;       // X0 region, conv1 output region
-    constexpr int W1_U = 5 * 4 * 64, W2_U = 2 * 9 * 4 * 64;                      // 16-byte units
+    constexpr int KS1 = K4 ? 4 : 5;                                              // conv1 k-steps
+    constexpr int XS = K4 ? 12 : 16;                                             // slots per X0 pixel record
+    constexpr int W1_U = KS1 * 4 * 64, W2_U = 2 * 9 * 4 * 64;                    // 16-byte units
     constexpr int X_UNITS = NF ? XH * XW * NF : XH * XW * 2;                    // 8-byte (frames mode) or 16-byte units
     constexpr int X_PT = (X_UNITS + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* s_w1 = (bf16_t*)smem;                     // 20,480 B
+    bf16_t* s_w1 = (bf16_t*)smem;                     // 20,480 B (16,384 B with K4)
     bf16_t* s_w2 = s_w1 + W1_U * 8;                   // 73,728 B
     bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2 chunks][340 px][32 ch]  43,520 B
-    bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 ch]            13,824 B
+    bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 slots] 13,824 B; K4: [432 px][12 slots] + 16 B of pad (the last fragment of the last pixel reads 4 slots past it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     StageRegs<W1_U> w1regs; StageRegs<W2_U> w2regs;
@@ -757,9 +767,16 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) b3[m] = *(const f32x4*)(a.b3 + g * 8 + m * 4);
     // conv1 per-lane tap offsets inside the X0 tile (CK=16: k-step s covers taps 2s and 2s+1)
-    int koff1[5];
+    int koff1[KS1];
 #pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5) { int tap = 2 * s5 + (g >> 1); tap = tap > 8 ? 8 : tap; koff1[s5] = ((tap / 3) * XW + tap % 3) * 16 + (g & 1) * 8; }
+    for (int s5 = 0; s5 < KS1; ++s5) {
+        if (K4) {          // k = 32 s + 8 g + j = 40 * (tap row) + slot: fragment (s, g) = slots o0 .. o0+7 of row r; k >= 120 carries zero weights (any valid address)
+            const int kk0 = 32 * s5 + 8 * g, r = kk0 / 40, o0 = kk0 % 40;
+            koff1[s5] = r < 3 ? r * XW * XS + o0 : 0;
+        } else {
+            int tap = 2 * s5 + (g >> 1); tap = tap > 8 ? 8 : tap; koff1[s5] = ((tap / 3) * XW + tap % 3) * 16 + (g & 1) * 8;
+        }
+    }
     // conv2 per-lane fragment bases inside one chunk plane of the T1 tile, one per tap column
     const bf16_t* bB[3];
 #pragma unroll
@@ -768,8 +785,8 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     u32x4 px[NF ? 1 : 2];
     u32x2 pf[NF ? X_PT : 1];
-    if (NF) {         // slots no frame writes (the fourth record of a triple, three of four for a single frame) stay zero
-        for (int u = tid; u < XH * XW * 2; u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};
+    if (NF) {         // slots no frame writes (the fourth record of a triple, three of four for a single frame; K4: the pad behind the tile) stay zero
+        for (int u = tid; u < (K4 ? (XH * XW * XS * 2 + 16) / 16 : XH * XW * 2); u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
     auto issue = [&](int it) {
@@ -808,7 +825,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 #pragma unroll
             for (int k = 0; k < X_PT; ++k) {
                 const int u = tid + k * 512;
-                if (u < X_UNITS) *(u32x2*)(s_x + (u / (NF ? NF : 1)) * 16 + (u % (NF ? NF : 1)) * 4) = pf[k];
+                if (u < X_UNITS) *(u32x2*)(s_x + (u / (NF ? NF : 1)) * XS + (u % (NF ? NF : 1)) * 4) = pf[k];
             }
         } else {
 #pragma unroll
@@ -838,12 +855,16 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             if (j >= 22) continue;
             const int p = j * 16 + n, pc = p < NP1 ? p : NP1 - 1;
             const int y = pc / TW1, x = pc % TW1;
-            const bf16_t* xb = s_x + (y * XW + x) * 16;
+            const bf16_t* xb = s_x + (y * XW + x) * XS;
             f32x4 acc[4] = {b1[0], b1[1], b1[2], b1[3]};
 #ifndef TTUP_ABLATE_S1
 #pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                const bf16x8 bfr = *(const bf16x8*)(xb + koff1[s5]);
+            for (int s5 = 0; s5 < KS1; ++s5) {
+                bf16x8 bfr;
+                if (K4) {          // 8-byte aligned: two ds_read_b64
+                    const u32x2 lo = *(const u32x2*)(xb + koff1[s5]), hi = *(const u32x2*)(xb + koff1[s5] + 4);
+                    bfr = __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
+                } else bfr = *(const bf16x8*)(xb + koff1[s5]);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const bf16x8 af = *(const bf16x8*)(s_w1 + ((s5 * 4 + m) * 64 + lane) * 8);
@@ -915,21 +936,25 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
 
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
                 int batch, int h, int w, hipStream_t st, int frames_per_sample) {
-    TTUP_REQUIRE(p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16, TTUP_EINVAL, "stem: unexpected conv1 shape");
+    TTUP_REQUIRE((p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16) ||
+                 (p1.cout == 64 && p1.cin_total == 128 && p1.k == 1 && p1.ck == 32), TTUP_EINVAL, "stem: unexpected conv1 shape");
     TTUP_REQUIRE(p2.cout == 64 && p2.cin_total == 64 && p2.k == 3 && p2.stride == 1 && p2.ck == 32, TTUP_EINVAL, "stem: unexpected conv2 shape");
     TTUP_REQUIRE(p3.cout == 32 && p3.cin_total == 64 && p3.k == 1 && p3.ck == 32, TTUP_EINVAL, "stem: unexpected follower shape");
     StemArgs a;
     a.x0 = (const bf16_t*)x0; a.w1 = (const bf16_t*)p1.w_dev; a.b1 = p1.bias_dev; a.w2 = (const bf16_t*)p2.w_dev; a.b2 = p2.bias_dev;
     a.w3 = (const bf16_t*)p3.w_dev; a.b3 = p3.bias_dev; a.t2 = (bf16_t*)t2; a.a1 = (bf16_t*)a1;
     a.H = h; a.W = w; a.tiles_x = cdiv(w, 32); a.tiles_per_img = a.tiles_x * cdiv(h, 8); a.total_tiles = a.tiles_per_img * batch;
-    constexpr size_t SMEM = (size_t)(5 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * 340 * 32 + 432 * 16) * 2;
+    constexpr size_t SMEM = (size_t)(5 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * 340 * 32 + 432 * 16) * 2;          // (the 4-step form needs 7.5 KB less; one size for all)
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     TTUP_REQUIRE(frames_per_sample == 0 || frames_per_sample == 1 || frames_per_sample == 3, TTUP_EINVAL, "stem: frames per sample must be 0 (X0 records), 1 or 3");
-    const void* kfn = frames_per_sample == 3 ? (const void*)stem_kernel<3> : frames_per_sample == 1 ? (const void*)stem_kernel<1> : (const void*)stem_kernel<0>;
+    const bool k4 = p1.k == 1;          // conv1 packed as 128 slots x 1 tap: the 4-step three-frame form (csrc/wasb_net.hip)
+    TTUP_REQUIRE(!k4 || frames_per_sample == 3, TTUP_EINVAL, "stem: the 4-step conv1 packing is the three-frame form");
+    const void* kfn = k4 ? (const void*)stem_kernel<3, true> : frames_per_sample == 3 ? (const void*)stem_kernel<3> : frames_per_sample == 1 ? (const void*)stem_kernel<1> : (const void*)stem_kernel<0>;
     if (int rc = ensure_max_lds(kfn, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
-    if (frames_per_sample == 3) hipLaunchKernelGGL(stem_kernel<3>, dim3(grid), dim3(512), SMEM, st, a);
+    if (k4) hipLaunchKernelGGL((stem_kernel<3, true>), dim3(grid), dim3(512), SMEM, st, a);
+    else if (frames_per_sample == 3) hipLaunchKernelGGL(stem_kernel<3>, dim3(grid), dim3(512), SMEM, st, a);
     else if (frames_per_sample == 1) hipLaunchKernelGGL(stem_kernel<1>, dim3(grid), dim3(512), SMEM, st, a);
     else hipLaunchKernelGGL(stem_kernel<0>, dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();

@@ -320,7 +320,21 @@ int build(ttup_wasb* net, const std::vector<FoldedConv>& folded) {
         for (int co = 0; co < 64 && b.rc == TTUP_OK; ++co)
             for (int ci = 0; ci < net->in_ch; ++ci)
                 for (int t = 0; t < 9; ++t) c1f.w[((size_t)co * 16 + (ci / 3) * 4 + ci % 3) * 9 + t] = c1.w[((size_t)co * net->in_ch + ci) * 9 + t];
-        const int p1f = b.pack(c1f, nullptr, 16);
+        int p1f = b.pack(c1f, nullptr, 16);
+        // ... and, for triples, the 4-k-step form of that conv (csrc/conv.hip stem_kernel<3, true>): K = 3 tap rows x 40 slots, slot
+        // o of a row = pixel dx = o / 12, frame (o % 12) / 4, colour o % 4 (colour 3 and o >= 36: zero weights), packed as a
+        // "1x1 conv with 128 inputs" so that k-step s, lane group g, element j holds k = 32 s + 8 g + j
+        if (net->in_ch == 9 && !getenv("TTUP_STEM_K5")) {
+            FoldedConv c1k = c1;
+            c1k.cin = 128; c1k.k = 1; c1k.w.assign((size_t)64 * 128, 0.f);
+            for (int co = 0; co < 64; ++co)
+                for (int r = 0; r < 3; ++r)
+                    for (int o = 0; o < 36; ++o) {
+                        const int dx = o / 12, f = (o % 12) / 4, col = o % 4;
+                        if (col < 3) c1k.w[(size_t)co * 128 + r * 40 + o] = c1.w[((size_t)co * net->in_ch + f * 3 + col) * 9 + r * 3 + dx];
+                    }
+            p1f = b.pack(c1k, nullptr, 0);
+        }
         const int p2 = b.pack(b.next(64, 64, 3, 1), nullptr, 0);
         const int p3 = b.pack(b.next(32, 64, 1, 1), nullptr, 0);
         x = b.new_tensor(64, H, W); net->taps["stem2"] = x;
