@@ -489,8 +489,9 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
 // PIPELINED (round 5): the fragments of step s+1 are requested BEFORE the MFMAs of step s, and a scheduling barrier keeps the
 // requests where they are (the compiler otherwise sinks every ds_read to just in front of its first use: rrrr M wait M wait M ...,
 // i.e. four reads covered by one MFMA, then the LDS latency in the open, 18 times per tile with only two waves per SIMD to hide it).
+template <int NPIX = 340>          // pixels per 32-channel plane of the halo tile (rows x 34): 340 for the 8-row tile, 204 for the stem's 4-row half tile
 __device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_t* const (&bB)[3], const bf16_t* s_w, int wave, int lane) {
-    constexpr int IW = 34, NPIX = 340;
+    constexpr int IW = 34;
     bf16x8 brow[2][4], af[2][4];
     auto load_b = [&](bf16x8 (&br)[4], int c, int dx) __attribute__((always_inline)) {
 #pragma unroll
@@ -934,6 +935,183 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ stem, two wave groups in opposite phases (round 5)
+// stem_kernel runs its eight waves in lockstep (X0 commit, conv1, barrier, conv2 + stores): the matrix pipe is 63 % busy, the rest
+// is conv1's packing and LDS stores, conv2's epilogue and the skew at two barriers per tile -- all of it on both waves of a SIMD at
+// the same time.  The stem issues only ~1.3 vector instructions per MFMA (the SIMD's issue port has room for two), so unlike the
+// 32-channel block (bb32_duo_kernel) it has something to gain from taking its two phases apart:
+//   group A (waves 0-3): conv1 of half tile t (4 output rows: 6x34 region, 13 pixel groups) X[t & 1] -> T1[t & 1]; then commits the
+//                        prefetched X0 of half tile t+1 -> X[(t+1) & 1] and requests half tile t+2
+//   group B (waves 4-7): conv2 of half tile t-1 from T1[(t-1) & 1] + T2 store + Bottleneck conv1 follower + A1 store
+// with ONE workgroup barrier per half tile; every SIMD holds one wave of each group.  Triples with the 4-k-step conv1 only.  All weights
+// LDS-resident as before (16 + 72 KB), two T1 half tiles (2 x 25.5 KB), two X0 half tiles (2 x 6.8 KB).  Same arithmetic per output
+// as stem_kernel<3, true> (same k order, same roundings): bit-identical.
+// MEASURED (round 5, same box): 0.692 against 0.608 ms per micro-batch -- 14 % SLOWER.  A half-tile phase needs 216 MFMAs per SIMD
+// (3.46 k cycles) but lasts ~5.7 k: the conv2 wave's loop + epilogue is one serial chain (152 MFMAs, then ~1 k cycles of packing,
+// stores and follower with nothing of its own to overlap), and its SIMD partner -- the conv1 wave, 48-64 MFMAs -- has too little
+// matrix work to fill that time.  In the one-phase kernel BOTH waves of a SIMD carry 200 MFMAs per tile and cover each other.
+// Opt-in: TTUP_STEM_DUO=1 (kept as the measured experiment; the default is stem_kernel<3, true>).
+__global__ __launch_bounds__(512) void stem_duo_kernel(StemArgs a) {
+    constexpr int XH = 8, XW = 36, TH1 = 6, TW1 = 34, NP1 = TH1 * TW1, XS = 12;       // X0 region, conv1 output region of a 4x32 half tile
+    constexpr int W1_U = 4 * 4 * 64, W2_U = 2 * 9 * 4 * 64;
+    constexpr int X_UNITS = XH * XW * 3, X_PT = (X_UNITS + 255) / 256;                 // 8-byte units, staged by group A's 256 threads
+    constexpr int T1_ELEMS = 2 * NP1 * 32, X_ELEMS = XH * XW * XS + 8;                 // (+ 16 B: the last fragment of the last pixel reads 4 slots past it)
+    constexpr int NG1 = (NP1 + 15) / 16;                                               // 13 pixel groups of conv1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_w1 = (bf16_t*)smem;
+    bf16_t* s_w2 = s_w1 + W1_U * 8;
+    bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2][T1_ELEMS]
+    bf16_t* s_x = s_t1 + 2 * T1_ELEMS;                // [2][X_ELEMS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
+    const int n = lane & 15, g = lane >> 4;
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;          // (workgroup-uniform)
+    StageRegs<W1_U> w1regs; StageRegs<W2_U> w2regs;
+    stage_load_512<W1_U>(w1regs, a.w1, tid);
+    stage_load_512<W2_U>(w2regs, a.w2, tid);
+    bf16x8 af3[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + (((g >> 1) * 2 + m) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
+    f32x4 b1[4], b2[4], b3[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { b1[m] = *(const f32x4*)(a.b1 + g * 16 + m * 4); b2[m] = *(const f32x4*)(a.b2 + g * 16 + m * 4); }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) b3[m] = *(const f32x4*)(a.b3 + g * 8 + m * 4);
+    int koff1[4];
+#pragma unroll
+    for (int s5 = 0; s5 < 4; ++s5) { const int kk0 = 32 * s5 + 8 * g, r = kk0 / 40, o0 = kk0 % 40; koff1[s5] = r < 3 ? r * XW * XS + o0 : 0; }
+    const bf16_t* bB0[3];          // conv2 fragment bases inside T1[0]
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bB0[dx] = s_t1 + lds_off<32, TW1>(0, n + dx, g);
+    u32x2 pf[X_PT];
+    unsigned pf_ok = 0u;
+    for (int u = tid; u < 2 * X_ELEMS / 8; u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};          // the pads (and everything else) start as zeros
+    auto tile_origin = [&](int it, int& b, int& oy0, int& ox0) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        b = tl / a.tiles_per_img;
+        const int tt = tl % a.tiles_per_img;
+        oy0 = (tt / a.tiles_x) * 4; ox0 = (tt % a.tiles_x) * 32;
+    };
+    auto issue = [&](int it) {          // group A; branch-free, the zeroing happens at the commit
+        int b, oy0, ox0;
+        tile_origin(it, b, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < X_PT; ++k) {
+            const int u = gtid + k * 256;
+            const int f = u % 3, pix = u / 3;
+            const int gy = oy0 - 2 + pix / XW, gx = ox0 - 2 + pix % XW;
+            const bool ok = u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pf[k] = *(const u32x2*)(ok ? a.x0 + (((size_t)(b + f) * a.H + gy) * a.W + gx) * 4 : a.x0);
+            pf_ok = ok ? pf_ok | (1u << k) : pf_ok & ~(1u << k);
+        }
+    };
+    auto commit = [&](bf16_t* xbuf) {
+#pragma unroll
+        for (int k = 0; k < X_PT; ++k) {
+            const int u = gtid + k * 256;
+            const bool okk = (pf_ok >> k) & 1u;
+            if (u < X_UNITS) *(u32x2*)(xbuf + (u / 3) * XS + (u % 3) * 4) = u32x2{okk ? pf[k].x : 0u, okk ? pf[k].y : 0u};
+        }
+    };
+    stage_store_512<W1_U>(s_w1, w1regs, tid);
+    stage_store_512<W2_U>(s_w2, w2regs, tid);
+    // kernel-lifetime registers complete on every path into the loop (prefetch_arrived)
+    prefetch_arrived(af3[0]); prefetch_arrived(af3[1]); prefetch_arrived(b1); prefetch_arrived(b2); prefetch_arrived(b3);
+    __syncthreads();          // s_x zeroed before group A's first commit
+    if (grp == 0) {
+        issue(0);
+        commit(s_x);
+        if (my_tiles > 1) issue(1);
+    }
+    __syncthreads();
+    for (int p = 0; p <= my_tiles; ++p) {
+        if (grp == 0) {
+            if (p < my_tiles) {
+                // ---------------- conv1 of half tile p on the 6x34 region (13 groups of 16 pixels, linear pixel index)
+                int b, oy0, ox0;
+                tile_origin(p, b, oy0, ox0);
+                const bf16_t* xs = s_x + (p & 1) * X_ELEMS;
+                bf16_t* t1 = s_t1 + (p & 1) * T1_ELEMS;
+#pragma unroll
+                for (int t = 0; t < (NG1 + 3) / 4; ++t) {
+                    const int j = gw + 4 * t;
+                    if (j >= NG1) continue;
+                    const int pidx = j * 16 + n, pc = pidx < NP1 ? pidx : NP1 - 1;
+                    const int y = pc / TW1, x = pc % TW1;
+                    const bf16_t* xb = xs + (y * XW + x) * XS;
+                    f32x4 acc[4] = {b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                    for (int s5 = 0; s5 < 4; ++s5) {
+                        const u32x2 lo = *(const u32x2*)(xb + koff1[s5]), hi = *(const u32x2*)(xb + koff1[s5] + 4);
+                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const bf16x8 af = *(const bf16x8*)(s_w1 + ((s5 * 4 + m) * 64 + lane) * 8);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
+                        }
+                    }
+                    if (pidx < NP1) {
+                        const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
+                        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
+                                pk[i] = inside ? w : 0u;
+                            }
+                            *(u32x4*)(t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) = pk;
+                        }
+                    }
+                }
+            }
+            if (p + 1 < my_tiles) {
+                commit(s_x + ((p + 1) & 1) * X_ELEMS);          // last read by this group's own conv1 of half tile p-1
+                if (p + 2 < my_tiles) issue(p + 2);
+            }
+        } else if (p >= 1) {
+            // ---------------- conv2 of half tile p-1: 4x32 outputs, both 32-channel planes straight from LDS
+            int b, oy0, ox0;
+            tile_origin(p - 1, b, oy0, ox0);
+            const int toff = ((p - 1) & 1) * T1_ELEMS;
+            const bf16_t* bB[3] = {bB0[0] + toff, bB0[1] + toff, bB0[2] + toff};
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
+            conv64_tile_mfma<NP1>(acc, bB, s_w2, gw, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = 2 * (gw >> 1) + t, cg = gw & 1;
+                const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
+                const bool ok = oy < a.H && ox < a.W;
+                u32x4 pk[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk[q][i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
+                    if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk[q];
+                }
+                f32x4 c3[2] = {b3[0], b3[1]};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], __builtin_bit_cast(bf16x8, pk[k]), c3[m], 0, 0, 0);
+                if (ok) {
+                    u32x4 po;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) po[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
+                    *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = po;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
                 int batch, int h, int w, hipStream_t st, int frames_per_sample) {
     TTUP_REQUIRE((p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16) ||
@@ -953,6 +1131,19 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
     if (int rc = ensure_max_lds(kfn, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
+    static const bool duo = getenv("TTUP_STEM_DUO") != nullptr;          // measured 14 % slower than the one-phase kernel: see stem_duo_kernel
+    if (k4 && duo && h % 4 == 0) {
+        // two wave groups in opposite phases over 4-row half tiles (stem_duo_kernel)
+        constexpr size_t SMEM2 = (size_t)(4 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * (2 * 204 * 32) + 2 * (8 * 36 * 12 + 8)) * 2;
+        static_assert(SMEM2 <= 160 * 1024, "LDS budget");
+        if (int rc = ensure_max_lds((const void*)stem_duo_kernel, SMEM2)) return rc;
+        StemArgs a2 = a;
+        a2.tiles_per_img = a.tiles_x * cdiv(h, 4); a2.total_tiles = a2.tiles_per_img * batch;
+        const int grid2 = a2.total_tiles < 256 ? a2.total_tiles : 256;
+        hipLaunchKernelGGL(stem_duo_kernel, dim3(grid2), dim3(512), SMEM2, st, a2);
+        TTUP_LAUNCH_CHECK();
+        return TTUP_OK;
+    }
     if (k4) hipLaunchKernelGGL((stem_kernel<3, true>), dim3(grid), dim3(512), SMEM, st, a);
     else if (frames_per_sample == 3) hipLaunchKernelGGL(stem_kernel<3>, dim3(grid), dim3(512), SMEM, st, a);
     else if (frames_per_sample == 1) hipLaunchKernelGGL(stem_kernel<1>, dim3(grid), dim3(512), SMEM, st, a);
