@@ -833,6 +833,46 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             for (int k = 0; k < 2; ++k) { const int u = tid + k * 512; if (u < X_UNITS) ((u32x4*)s_x)[u] = px[k & (NF ? 0 : 1)]; }
         }
     };
+    // T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
+    auto epilogue = [&](const f32x4 (&acc)[4][2], int b, int oy0, int ox0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = 2 * (wave >> 1) + t, cg = wave & 1;
+            const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
+            const bool ok = oy < a.H && ox < a.W;
+            u32x4 pk[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pk[q][i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
+#ifndef TTUP_ABLATE_SG
+                if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk[q];
+#endif
+            }
+#ifndef TTUP_ABLATE_S3
+            f32x4 c3[2] = {b3[0], b3[1]};
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], __builtin_bit_cast(bf16x8, pk[k]), c3[m], 0, 0, 0);
+            if (ok) {
+                u32x4 po;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) po[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
+                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = po;
+            }
+#endif
+        }
+    };
+#ifdef TTUP_NO_STAGGER
+    constexpr bool STAGGER = false;
+#else
+    constexpr bool STAGGER = K4;
+#endif
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    f32x4 acc[4][2];
+    int eb = 0, eoy0 = 0, eox0 = 0;
+    bool pending = false;
     if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
     issue(0);
     stage_store_512<W1_U>(s_w1, w1regs, tid);
@@ -895,7 +935,10 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         if (it + 2 < my_tiles) issue(it + 2);
         TTUP_STAMP_IT(0, it, 4);
         // ---------------- conv2 on the 8x32 tile, both 32-channel planes straight from LDS
-        f32x4 acc[4][2];
+        // STAGGER (waves 4-7, the second wave of every SIMD): the epilogue of a tile is deferred to the start of the NEXT tile's conv2
+        // phase, so it runs under the partner wave's MFMA loop instead of beside the partner's own epilogue (both waves of a SIMD
+        // otherwise leave the matrix pipe idle together); the accumulators stay in registers across the tile boundary
+        if (STAGGER && late && pending) epilogue(acc, eb, eoy0, eox0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
 #ifndef TTUP_ABLATE_S2
@@ -903,36 +946,10 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         conv64_tile_mfma(acc, bB, s_w2, wave, lane);
 #endif
         TTUP_STAMP_IT(0, it, 5);
-        // ---------------- T2 tile to HBM; follower A1 = relu(W3 . T2 + b3), 64 -> 32, straight from the packed registers
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int r = 2 * (wave >> 1) + t, cg = wave & 1;
-            const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
-            const bool ok = oy < a.H && ox < a.W;
-            u32x4 pk[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pk[q][i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
-#ifndef TTUP_ABLATE_SG
-                if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk[q];
-#endif
-            }
-#ifndef TTUP_ABLATE_S3
-            f32x4 c3[2] = {b3[0], b3[1]};
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], __builtin_bit_cast(bf16x8, pk[k]), c3[m], 0, 0, 0);
-            if (ok) {
-                u32x4 po;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) po[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
-                *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = po;
-            }
-#endif
-        }
+        if (STAGGER && late) { eb = b; eoy0 = oy0; eox0 = ox0; pending = true; }
+        else epilogue(acc, b, oy0, ox0);
     }
+    if (STAGGER && late && pending) epilogue(acc, eb, eoy0, eox0);
 }
 
 // ------------------------------------------------------------------ stem, two wave groups in opposite phases (round 5)
