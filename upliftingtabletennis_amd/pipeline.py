@@ -237,8 +237,8 @@ class StreamWorker:
         if net.eps_violated(err):
             self.certify_eps = net.widen_eps(err)
             widened = True
-            self.widen_sources[source] += 1
-        self._quiet_clips = 0 if widened else self._quiet_clips + 1
+            self.__dict__.setdefault('widen_sources', {'strip': 0, 'candidates': 0})[source] += 1
+        self._quiet_clips = 0 if widened else self.__dict__.get('_quiet_clips', 0) + 1
         # crop budget of the next clips (it sizes the number of fp32 passes a call provisions; an unused pass still costs its launches):
         # one and a half times the most any of the last eight clips asked for (+ slack) -- content that alternates between easy and
         # hard clips keeps the hard clips' budget (twice the LAST clip's count sent 40 % of a hard clip that followed an easy one to
