@@ -687,6 +687,161 @@ static int launch_conv64_t(const ConvKArgs& a, hipStream_t st) {
     return TTUP_OK;
 }
 
+// ------------------------------------------------------------------ 3x3 64 -> 64 on v_mfma_f32_32x32x16_bf16 (round 5)
+// The same conv as conv64_kernel<false, false> (no followers) with the 32x32x16 MFMA: a wave's 64 couts x (2 rows x 16 px) tile is two
+// 32x32 accumulators (M = 32 couts each, N = the 32 pixels: lane & 31 = 16 * row + column), K = 16 channels of one tap per MFMA.
+//   A (weights)  lane (r = lane & 31, h = lane >> 5) holds W[cout C(r)][16-channel slice: channels 8h .. 8h+7] with the row permutation
+//                C(M2, r) = 32 M2 + 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3), so that after the MFMA lane (px, h) holds the 16 CONSECUTIVE
+//                channels 32 M2 + 16 h + q of its pixel in accumulator registers q = 0..15 (32-byte stores).  The LDS image
+//                [tap/slice step 36][M2][lane][8] is gathered from the standard packing while the weights are staged (no second packing).
+//   B (pixels)   lane (px, h): channels 8h .. 8h+7 of the slice of pixel (row px >> 4, column px & 15) shifted by the tap: one 16-byte
+//                read of the same swizzled halo tile as conv64_kernel (conflict-free: the two rows of a lane group fall on opposite halves of
+//                the bank row and the column swizzle separates the four pixels that share a slot group).
+// Per (plane, tap column): 6 pixel-fragment reads (the two output rows are the lane halves of ONE fragment, so the three tap rows cannot
+// share registers as in the 16x16x32 form: 6 instead of 4) + 12 weight-fragment reads for 12 MFMAs of 32 cycles -- 9 LDS reads per
+// 192 MFMA cycles against 8, HALF the MFMA instructions.  Another fp32 summation order (K = 16 per MFMA): results agree with
+// conv64_kernel to bf16 rounding flips.  Opt-in (TTUP_CONV64_32=1): measured 0.8 % slower than the 16x16x32 form (launch_conv64).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(512) void conv64_32_kernel(ConvKArgs a) {
+    constexpr int IH = 10, IW = 34, NPIX = IH * IW;
+    constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units = 36 steps x 2 M-tiles x 64 lanes
+    constexpr int IN_UNITS = NPIX * 8, IN_PT = (IN_UNITS + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_w = (bf16_t*)smem;                                // 73,728 B
+    bf16_t* s_in = s_w + W_U * 8;                               // [2 planes][340 px][32 ch]  43,520 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    // weights: destination unit d = (step * 2 + M2) * 64 + lane  <-  source unit of the standard packing ((plane * 9 + tap) * 4 + m) * 64 + i + 16 G
+    u32x4 wreg[W_U / 512];
+#pragma unroll
+    for (int k = 0; k < W_U / 512; ++k) {
+        const int d = tid + k * 512;
+        const int dl = d & 63, M2 = (d >> 6) & 1, st = d >> 7;                 // st = (plane * 9 + tap) * 2 + slice
+        const int r = dl & 31, hh = dl >> 5, slice = st & 1, pt = st >> 1;     // pt = plane * 9 + tap
+        const int C = 32 * M2 + 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
+        const int m = (C >> 2) & 3, i = ((C >> 4) << 2) | (C & 3), G = 2 * slice + hh;
+        wreg[k] = ((const u32x4*)a.wpack)[(pt * 4 + m) * 64 + i + 16 * G];
+    }
+    f32x16 bias[2];          // lane's channels 32 M2 + 16 h + q
+#pragma unroll
+    for (int M2 = 0; M2 < 2; ++M2)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + 32 * M2 + 16 * h + 4 * q4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias[M2][4 * q4 + j] = b4[j];
+        }
+    // per-lane pixel-fragment bases: tap column dx, slice sl -> chunk 2 sl + h of pixel (row px >> 4, column (wave & 1) * 16 + (px & 15) + dx)
+    const bf16_t* bB[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            bB[dx][sl] = s_in + lds_off<32, IW>(2 * (wave >> 1) + (px >> 4), (wave & 1) * 16 + (px & 15) + dx, 2 * sl + h);
+    u32x4 pin[IN_PT];
+    auto issue = [&](int it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
+        const int gy0 = (t / a.tiles_x) * 8 - 1, gx0 = (t % a.tiles_x) * 32 - 1;
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            const int c8 = u & 7, pix = u >> 3;
+            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+            pin[k] = u32x4{0u, 0u, 0u, 0u};
+            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                pin[k] = *(const u32x4*)(a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * 64 + c8 * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * 512;
+            if (u < IN_UNITS) { const int c8 = u & 7, pix = u >> 3; *(u32x4*)(s_in + (c8 >> 2) * (NPIX * 32) + lds_off<32, IW>(pix / IW, pix % IW, c8 & 3)) = pin[k]; }
+        }
+    };
+    issue(0);
+#pragma unroll
+    for (int k = 0; k < W_U / 512; ++k) ((u32x4*)s_w)[tid + k * 512] = wreg[k];
+    prefetch_arrived(pin);
+    prefetch_arrived(bias);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (it + 1 < my_tiles) issue(it + 1);
+        f32x16 acc[2] = {bias[0], bias[1]};
+        // 36 steps (plane c, tap column dx, tap row dy, slice sl), 2 MFMAs each; fragments of step s+1 requested before the MFMAs of step s
+        bf16x8 bf[2], af[2][2];
+        auto load_step = [&](int s, bf16x8& b1, bf16x8 (&a2)[2]) __attribute__((always_inline)) {
+            const int sl = s & 1, dy = (s >> 1) % 3, dx = (s / 6) % 3, c = s / 18;
+            b1 = *(const bf16x8*)(bB[dx][sl] + c * (NPIX * 32) + dy * IW * 32);
+            const int st = ((c * 9 + dy * 3 + dx) * 2 + sl);
+#pragma unroll
+            for (int M2 = 0; M2 < 2; ++M2) a2[M2] = *(const bf16x8*)(s_w + ((st * 2 + M2) * 64 + lane) * 8);
+        };
+        load_step(0, bf[0], af[0]);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 1 < 36) load_step(s + 1, bf[(s + 1) & 1], af[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int M2 = 0; M2 < 2; ++M2) acc[M2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][M2], bf[s & 1], acc[M2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prefetch_arrived(pin);
+        // ---- epilogue: lane (px, h) holds channels 32 M2 + 16 h + q of pixel (2 (wave >> 1) + (px >> 4), (wave & 1) * 16 + (px & 15))
+        const int oy = oy0 + 2 * (wave >> 1) + (px >> 4), ox = ox0 + (wave & 1) * 16 + (px & 15);
+        const bool ok = oy < a.H && ox < a.W;
+        const size_t o = ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + 16 * h : 0;
+        u32x4 rres[2][2];
+        if (a.residual) {
+#pragma unroll
+            for (int M2 = 0; M2 < 2; ++M2) { rres[M2][0] = *(const u32x4*)(a.residual + o + 32 * M2); rres[M2][1] = *(const u32x4*)(a.residual + o + 32 * M2 + 8); }
+        }
+        u32x4 pk[2][2];          // every residual value is consumed before the first store (a wait behind a store would drain it)
+#pragma unroll
+        for (int M2 = 0; M2 < 2; ++M2) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = acc[M2][q];
+            if (a.residual) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const unsigned w4[4] = {rres[M2][q2].x, rres[M2][q2].y, rres[M2][q2].z, rres[M2][q2].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[q2 * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q2 * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+                }
+            }
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q2 * 8 + 2 * i], v[q2 * 8 + 2 * i + 1]); pk[M2][q2][i] = a.relu ? relu_pk(w) : w; }
+        }
+        if (ok) {
+#pragma unroll
+            for (int M2 = 0; M2 < 2; ++M2)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) *(u32x4*)(a.dst + o + 32 * M2 + q2 * 8) = pk[M2][q2];
+        }
+    }
+}
+
+static int launch_conv64_32(const ConvKArgs& a, hipStream_t st) {
+    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
+    if (int rc = ensure_max_lds((const void*)conv64_32_kernel, SMEM)) return rc;
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL(conv64_32_kernel, dim3(grid), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     ConvKArgs a;
     memset(&a, 0, sizeof a);
@@ -704,6 +859,11 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     if (l.lin16 && l.lin32) return launch_conv64_t<true, true>(a, st);
     if (l.lin16) return launch_conv64_t<true, false>(a, st);
     if (l.lin32) return launch_conv64_t<false, true>(a, st);
+    // TTUP_CONV64_32=1: the 32x32x16 form of the plain conv (conv64_32_kernel).  MEASURED (round 5, same box, the eight launches of a
+    // micro-batch with six of them on this kernel): 0.3625 / 0.3584 / 0.3605 ms against 0.3569 / 0.3601 / 0.3571 for the 16x16x32 form --
+    // 0.8 % slower; parity tests green in both.  Half the MFMA instructions do not pay for 12 % more LDS reads here.
+    static const bool k32 = getenv("TTUP_CONV64_32") != nullptr;
+    if (k32) return launch_conv64_32(a, st);
     return launch_conv64_t<false, false>(a, st);
 }
 
