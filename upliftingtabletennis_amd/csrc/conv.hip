@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        const bool t1_inside = oy0 >= 1 && oy0 + 9 <= a.H && ox0 >= 1 && ox0 + 33 <= a.W;          // the whole 10x34 conv1 region lies inside the image
         TTUP_STAMP_IT(0, it, 0);
         TTUP_STAMP_IT(0, it, 1);
         // ONE barrier covers "X0 tile complete" (committed in the middle of the previous iteration) and "previous conv2 done reading
@@ -1074,15 +1075,19 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
             }
 #endif
             if (p < NP1) {
+                // conv2's zero padding: conv1 outputs outside the image are zeros.  Only border tiles have any (wave-uniform test on the
+                // scalar unit): interior tiles skip the per-lane position test and the eight selects per pixel group (round 5: the
+                // vector issue port is what these kernels run out of)
                 const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     u32x4 pk;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
-                        pk[i] = inside ? w : 0u;
+                    for (int i = 0; i < 4; ++i) pk[i] = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
+                    if (!t1_inside) {
+                        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk[i] = inside ? pk[i] : 0u;
                     }
                     // lane's channels g*16 + q*8 .. +7  ->  chunk plane (g>>1), 16-byte chunk (g&1)*2+q
                     *(u32x4*)(s_t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) = pk;
@@ -1479,7 +1484,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned w = relu_pk(pack2(acc[t][i >> 1][2 * (i & 1)], acc[t][i >> 1][2 * (i & 1) + 1]));
-                    pk[i] = inside ? w : 0u;
+                    pk[i] = inside ? w : 0u;          // (a wave-uniform "interior tile" branch around these selects measured +1 % here, -2 % in the stem)
                 }
                 *(u32x4*)(s_l1 + l1_off(pix, g * 4 + q)) = pk;
             }
