@@ -118,6 +118,11 @@ __device__ __forceinline__ void stage_store_512(bf16_t* dst, const StageRegs<UNI
 // issues its stores: the vector-memory counter retires in order and the compiler cannot count stores that sit behind a branch, so a
 // wait for prefetched loads that comes AFTER the stores is an s_waitcnt vmcnt(0) -- it drains the stores just issued, with every wave
 // of the workgroup parked for a store round trip per tile (round 5: the stem spent 2.7 k of its 11.9 k cycles per tile there).
+// A 32-bit per-lane offset the compiler must treat as unknown HERE: its zero-extension then happens next to the load that uses it, and
+// "uniform 64-bit base + zext(32-bit lane offset)" is selected as ONE global_load with a scalar base (saddr) and a 32-bit vector
+// offset.  Without it the extension is hoisted out of the tile loop (a register PAIR per offset) and every load gets a 64-bit add.
+__device__ __forceinline__ unsigned opaque_u32(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
 template <typename T, int N>
 __device__ __forceinline__ void prefetch_arrived(const T (&r)[N]) {
 #pragma unroll
@@ -148,13 +153,27 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
     bf16_t* s_in = (bf16_t*)smem;
     bf16_t* s_w = s_in + ((IN_ELEMS + 7) & ~7);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: row tests and row addresses on the scalar unit
     const int n = lane & 15, g = lane >> 4;
     const int nchunk = a.nchunk;
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int n_items = my_tiles * nchunk;
+    const unsigned st_c = (unsigned)((n * COUT + g * 4 * MT) * 2);          // lane's byte offset inside a 16-pixel group of COUT-channel records
 
     u32x4 pin[IN_PT], pw[W_PT];
+    // byte offsets of the thread's units from the tile's first halo pixel in src0 (see bb_chain_kernel).  Register budget: the 128-cout
+    // variant sits at 252 of 256 with them and the stride-2 16 -> 64 conv at exactly 128 (two workgroups per CU; at 131 it was one
+    // and 20 % slower) -- both only since the wave index is a scalar (readfirstlane) and the epilogue addresses take a scalar base
+    constexpr bool FASTP = true;
+    unsigned voff[FASTP ? IN_PT : 1];
+    if constexpr (FASTP) {
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int u = tid + k * NTHR;
+            const int c8 = u % (CK / 8), pix = u / (CK / 8);
+            voff[k] = u < IN_UNITS ? (unsigned)((((pix / IW) * a.W + pix % IW) * a.c0 + c8 * 8) * 2) : 0u;
+        }
+    }
     auto issue = [&](int item) {
         const int tl0 = blockIdx.x + (item / nchunk) * gridDim.x, chunk = item % nchunk;
         const int tl = a.xcd ? xcd_tile(tl0, a.total_tiles) : tl0;
@@ -164,16 +183,25 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
         const bf16_t* src = first ? a.src0 : a.src1;
         const int csrc = first ? a.c0 : a.c1;
         const int ch0 = (first ? chunk : chunk - a.nchunk0) * CK;
+#if !defined(TTUP_NO_FAST_PREFETCH) && !defined(TTUP_ABLATE_LOADS)
+        if (FASTP && first && gy0 >= 0 && gy0 + IH <= a.H && gx0 >= 0 && gx0 + IW <= a.W) {          // halo tile inside the image: scalar base + lane constants
+            const char* base = (const char*)(a.src0 + ((size_t)(b * a.H + gy0) * a.W + gx0) * a.c0 + ch0);
 #pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * NTHR;
-            const int c8 = u % (CK / 8), pix = u / (CK / 8);
-            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
-            pin[k] = u32x4{0u, 0u, 0u, 0u};
-#ifndef TTUP_ABLATE_LOADS
-            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                pin[k] = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
+            for (int k = 0; k < IN_PT; ++k) pin[k] = *(const u32x4*)(base + opaque_u32(voff[FASTP ? k : 0]));
+        } else
 #endif
+        {
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) {
+                const int u = tid + k * NTHR;
+                const int c8 = u % (CK / 8), pix = u / (CK / 8);
+                const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
+                pin[k] = u32x4{0u, 0u, 0u, 0u};
+#ifndef TTUP_ABLATE_LOADS
+                if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    pin[k] = *(const u32x4*)(src + ((size_t)(b * a.H + gy) * a.W + gx) * csrc + ch0 + c8 * 8);
+#endif
+            }
         }
         if (nchunk > 1 || item == 0) {
             const u32x4* wsrc = (const u32x4*)(a.wpack + (size_t)chunk * W_ELEMS);
@@ -280,7 +308,11 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             const int nt = wave * NT + t;
             const int oy = oy0 + nt / NTW, ox = ox0 + (nt % NTW) * 16 + n;
             if (oy >= a.OH || ox >= a.OW) continue;
-            const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + g * 4 * MT;
+            // element offset of the lane's first output channel: a wave-uniform part (scalar registers) + the lane constant -- the
+            // loads and stores below then take a scalar base and a 32-bit lane offset instead of a 64-bit per-lane address chain
+            const size_t ou = ((size_t)(b * a.OH + oy) * a.OW + ox0 + (nt % NTW) * 16) * COUT;
+            const unsigned lc = opaque_u32(st_c);
+            auto at = [&](const bf16_t* base) { return (bf16_t*)((char*)const_cast<bf16_t*>(base + ou) + lc); };
             float v[4 * MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -307,12 +339,12 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
             };
             const bf16_t* t3 = a.res3 ? a.res3 + ((size_t)(b * (a.OH >> a.sh3) + (oy >> a.sh3)) * (a.OW >> a.sh3) + (ox >> a.sh3)) * COUT + g * 4 * MT : nullptr;
             if (MT <= 4) {
-                if (a.residual) load_term(0, a.residual + o);
-                if (a.res2) load_term(1, a.res2 + o);
+                if (a.residual) load_term(0, at(a.residual));
+                if (a.res2) load_term(1, at(a.res2));
                 if (a.res3) load_term(2, t3);
             }
-            if (a.residual) add_term(0, a.residual + o);
-            if (a.res2) add_term(1, a.res2 + o);
+            if (a.residual) add_term(0, at(a.residual));
+            if (a.res2) add_term(1, at(a.res2));
             if (a.res3) add_term(2, t3);
             unsigned pk[2 * MT];
 #pragma unroll
@@ -322,10 +354,10 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvKArgs a) {
                 for (int i = 0; i < 2 * MT; ++i) pk[i] = relu_pk(pk[i]);
             }
             if (MT == 1) {
-                *(u32x2*)(a.dst + o) = u32x2{pk[0], pk[1]};
+                *(u32x2*)at(a.dst) = u32x2{pk[0], pk[1]};
             } else {
 #pragma unroll
-                for (int q = 0; q < MT / 2; ++q) *(u32x4*)(a.dst + o + q * 8) = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+                for (int q = 0; q < MT / 2; ++q) *(u32x4*)(at(a.dst) + q * 8) = u32x4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
             }
         }
         if (F11) {
@@ -539,7 +571,7 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* s_w = (bf16_t*)smem;                                // 73,728 B
     bf16_t* s_in = s_w + W_U * 8;                               // [2 chunks][340 px][32 ch]  43,520 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     StageRegs<W_U> wregs;
     stage_load_512<W_U>(wregs, a.wpack, tid);           // weights and the first tile travel together: one round trip before the loop
@@ -568,10 +600,25 @@ __global__ __launch_bounds__(512) void conv64_kernel(ConvKArgs a) {
     for (int dx = 0; dx < 3; ++dx) bB[dx] = s_in + lds_off<32, IW>(0, n + dx, g);
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     u32x4 pin[IN_PT];
+    unsigned voff[IN_PT];          // byte offsets of the thread's units from the tile's first halo pixel (see bb_chain_kernel)
+#pragma unroll
+    for (int k = 0; k < IN_PT; ++k) {
+        const int u = tid + k * 512;
+        const int c8 = u & 7, pix = u >> 3;
+        voff[k] = u < IN_UNITS ? (unsigned)((((pix / IW) * a.W + pix % IW) * 64 + c8 * 8) * 2) : 0u;
+    }
     auto issue = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
         const int gy0 = (t / a.tiles_x) * 8 - 1, gx0 = (t % a.tiles_x) * 32 - 1;
+#ifndef TTUP_NO_FAST_PREFETCH
+        if (gy0 >= 0 && gy0 + IH <= a.H && gx0 >= 0 && gx0 + IW <= a.W) {          // halo tile inside the image: scalar base + lane constants
+            const char* base = (const char*)(a.src0 + ((size_t)(b * a.H + gy0) * a.W + gx0) * 64);
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) pin[k] = *(const u32x4*)(base + opaque_u32(voff[k]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
             const int u = tid + k * 512;
@@ -908,7 +955,7 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     bf16_t* s_w2 = s_w1 + W1_U * 8;                   // 73,728 B
     bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2 chunks][340 px][32 ch]  43,520 B
     bf16_t* s_x = s_t1 + 2 * NP1 * 32;                // [432 px][16 slots] 13,824 B; K4: [432 px][12 slots] + 16 B of pad (the last fragment of the last pixel reads 4 slots past it)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // (as a scalar -- readfirstlane -- the wave-dependent loops become branches: measured +3 ... 5 %)
     const int n = lane & 15, g = lane >> 4;
     StageRegs<W1_U> w1regs; StageRegs<W2_U> w2regs;
     stage_load_512<W1_U>(w1regs, a.w1, tid);            // stored to LDS after the first tile's loads have been issued (below)
@@ -950,11 +997,29 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
         for (int u = tid; u < (K4 ? (XH * XW * XS * 2 + 16) / 16 : XH * XW * 2); u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
+    // NF: byte offsets of the thread's (pixel, frame) records from the tile's first halo pixel in the triple's first frame (see bb_chain_kernel)
+    unsigned xoff[NF ? X_PT : 1];
+    if constexpr (NF != 0) {
+#pragma unroll
+        for (int k = 0; k < X_PT; ++k) {
+            const int u = tid + k * 512;
+            const int f = u % (NF ? NF : 1), pix = u / (NF ? NF : 1);
+            xoff[k] = u < X_UNITS ? (unsigned)(((f * a.H + pix / XW) * a.W + pix % XW) * 8) : 0u;
+        }
+    }
     auto issue = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
         const int gy0 = (t / a.tiles_x) * 8 - 2, gx0 = (t % a.tiles_x) * 32 - 2;
         if (NF) {
+#ifndef TTUP_NO_FAST_PREFETCH
+            if (gy0 >= 0 && gy0 + XH <= a.H && gx0 >= 0 && gx0 + XW <= a.W) {          // halo tile inside the image: scalar base + lane constants
+                const char* base = (const char*)(a.x0 + (((size_t)b * a.H + gy0) * a.W + gx0) * 4);
+#pragma unroll
+                for (int k = 0; k < X_PT; ++k) pf[k] = *(const u32x2*)(base + opaque_u32(xoff[k]));
+                return;
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < X_PT; ++k) {
                 const int u = tid + k * 512;
@@ -1368,7 +1433,7 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
     bf16_t* s_w1 = s_l1 + NPIX * 128;                           // 24,576 B resident
     bf16_t* s_w5 = s_w1 + W1_U * 8;                             // 36,864 B resident
     float* s_b1 = (float*)(s_w5 + W5_U * 8);                    // 512 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // (as a scalar -- readfirstlane -- the wave-dependent loops become branches: measured +3 ... 5 %)
     const int n = lane & 15, g = lane >> 4;
     StageRegs<W1_U> w1regs; StageRegs<W5_U> w5regs;
     stage_load_512<W1_U>(w1regs, a.w1, tid);            // stored to LDS after the first tile's loads have been issued (below)
@@ -1394,10 +1459,31 @@ __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
         pix = pix < NPIX ? pix : NPIX - 1;
         pyx[t] = (unsigned)((pix / IW) << 8 | (pix % IW));
     }
+    // byte offset of the lane's 16-byte unit of pixel group t from the tile's first halo pixel in the 32-channel source (twice that, plus
+    // 64 per chunk, in the 64-channel one): the same for every tile (see bb_chain_kernel)
+    unsigned poff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) poff[t] = (unsigned)(((pyx[t] >> 8) * a.W + (pyx[t] & 255u)) * 64 + g * 16);
     auto issue_pix = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int gy0 = (tt / a.tiles_x) * 8 - 1, gx0 = (tt % a.tiles_x) * 32 - 1;
+#ifndef TTUP_NO_FAST_PREFETCH
+        if (gy0 >= 0 && gy0 + IH <= a.H && gx0 >= 0 && gx0 + IW <= a.W) {          // halo tile inside the image: scalar bases + lane constants
+            const size_t gp0 = (size_t)(b * a.H + gy0) * a.W + gx0;
+            const char* base_a = (const char*)(a.a2 + gp0 * 32);
+            const char* base_t = (const char*)(a.t2 + gp0 * 64);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                p_in[t] = wave + 8 * t < NT1;          // (groups past the tile: clamped to its last pixel, loaded and never used)
+                const unsigned o = opaque_u32(poff[t]), o2 = o * 2u - (unsigned)(g * 16);
+                pb[t][0] = *(const u32x4*)(base_a + o);
+                pb[t][1] = *(const u32x4*)(base_t + o2);
+                pb[t][2] = *(const u32x4*)(base_t + o2 + 64);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int j = wave + 8 * t;
@@ -1843,6 +1929,9 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         }
     }
     bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((yb + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
+    // global stores: wave-uniform row base (scalar registers) + the lane's byte offset inside a 16-pixel group (one register for C-channel
+    // records, one for 16-channel records) + the group as an immediate -- instead of a 64-bit per-lane address chain per store
+    const unsigned st_c = (unsigned)((n * C + g * 4 * MT) * 2), st_16 = (unsigned)((n * 16 + g * 4) * 2);
     // epilogue of one 16-pixel group of row y (orow = its row offset from the wave's first row): bias/ReLU/rounding, zero padding
     // of the next conv, stores, and whatever rides in the last conv's epilogue
     auto epi = [&](int xt, int orow, int y, const f32x4 (&accx)[MT]) __attribute__((always_inline)) {
@@ -1872,9 +1961,10 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 #pragma unroll
             for (int i = 0; i < 2 * MT; ++i) pk[i] = inside ? pk[i] : 0u;
         }
+        const size_t rowpix = (size_t)(b * H + gy) * W + gx0;          // (wave-uniform) first pixel of the region's row in the image
         if (GLOBAL_OUT) {
             if (MODE != 7 && inside && valid && gout) {
-                bf16_t* o = gout + ((size_t)(b * H + gy) * W + gx) * C + g * 4 * MT;
+                char* o = (char*)(gout + rowpix * C) + (opaque_u32(st_c) + (unsigned)(xt * 16 * C * 2));
                 if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                 else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
@@ -1903,7 +1993,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 }
                 if (!HEAD) {
                     const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
-                    if (live) *(u32x2*)(ex->ysum + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{q0, q1};
+                    if (live) *(u32x2*)((char*)(ex->ysum + rowpix * 16) + (opaque_u32(st_16) + (unsigned)(xt * 16 * 32))) = u32x2{q0, q1};
                 } else {
                     float part = relu_f32(ys[0]) * hw4[0];
                     part = fmaf(relu_f32(ys[1]), hw4[1], part);
@@ -1969,7 +2059,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 if (yf) {          // lane (n, g) holds channels 8g..8g+7 of its pixel = k-group g of the follower's only k-step
                     const u32x4 bq = u32x4{pk[0], pk[1], pk[2], pk[3]};
                     const f32x4 cf = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_f, __builtin_bit_cast(bf16x8, bq), bias_f, 0, 0, 0);
-                    if (inside && valid) *(u32x2*)(yf + ((size_t)(b * H + gy) * W + gx) * 16 + g * 4) = u32x2{pack2(cf[0], cf[1]), pack2(cf[2], cf[3])};
+                    if (inside && valid) *(u32x2*)((char*)(yf + rowpix * 16) + (opaque_u32(st_16) + (unsigned)(xt * 16 * 32))) = u32x2{pack2(cf[0], cf[1]), pack2(cf[2], cf[3])};
                 }
             }
         } else if (valid) {
@@ -2189,10 +2279,30 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
     u32x4 pin[IN_PT], pwt[W_PT];
+    // byte offset of each of the thread's units from its tile's first halo pixel: the same for every tile (unused units of the last
+    // round point at the first pixel, loaded and never committed)
+    unsigned voff[IN_PT];
+#pragma unroll
+    for (int k = 0; k < IN_PT; ++k) {
+        const int u = tid + k * 512;
+        const int c8 = u % (C / 8), pix = u / (C / 8);
+        voff[k] = u < IN_UNITS ? (unsigned)((((pix / R0W) * a.W + pix % R0W) * C + c8 * 8) * 2) : 0u;
+    }
     auto issue_in = [&](int it) {
         const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
         const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
         const int gy0 = (tt / a.tiles_x) * TH - L, gx0 = (tt % a.tiles_x) * TW - L;
+#ifndef TTUP_NO_FAST_PREFETCH
+        if (gy0 >= 0 && gy0 + R0H <= a.H && gx0 >= 0 && gx0 + R0W <= a.W) {
+            // the whole halo region lies inside the image (wave-uniform): a scalar base + the per-lane constants -- no coordinates, no
+            // bounds tests, no 64-bit per-lane address arithmetic (round 5: the general form below is ~25 vector instructions per load,
+            // issued while the matrix pipe has nothing to do)
+            const char* base = (const char*)(a.x + ((size_t)(b * a.H + gy0) * a.W + gx0) * C);
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) pin[k] = *(const u32x4*)(base + opaque_u32(voff[k]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < IN_PT; ++k) {
             const int u = tid + k * 512;
