@@ -528,6 +528,38 @@ def test_chain_runtime_epilogue_form_matches_compiled_forms(tmp_path):
     assert np.array_equal(outs['compiled']['idx'], outs['runtime']['idx'])
 
 
+def test_conv64_lds_dma_staging_is_bit_identical(tmp_path):
+    """conv64_dma_kernel (default: halo tile staged by global_load_lds into one of two LDS buffers, the swizzle folded into the source
+    address, border tiles fetched clamped and zeroed in place) against the register-staged conv64_kernel (TTUP_CONV64_DMA=0; read once
+    per process, hence the child processes): same arithmetic, so heatmaps and indices are bit-identical -- on a size whose 1/4-resolution
+    plane is all border tiles and ragged (104 x 168 -> 26 x 42), one with interior tiles (288 x 512 -> 72 x 128) and one with a
+    ragged last tile column (200 x 296 -> 50 x 74)."""
+    import subprocess, sys
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from upliftingtabletennis_amd import wasb, weights\n"
+        "sd = weights.random_wasb_state_dict(43)\n"
+        "out = {}\n"
+        "for k, (h, w, b) in enumerate(((104, 168, 3), (288, 512, 9), (200, 296, 2))):\n"
+        "    x = torch.from_numpy(np.random.default_rng(43 + k).standard_normal((b, 9, h, w)).astype(np.float32))\n"
+        "    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')\n"
+        "    heat, idx, _ = net.forward(x, want_peaks=True)\n"
+        "    out['heat%%d' %% k] = heat.cpu().numpy(); out['idx%%d' %% k] = idx.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for tag, env in (('dma', {}), ('regs', {'TTUP_CONV64_DMA': '0'})):
+        out = str(tmp_path / (tag + '.npz'))
+        e = dict(os.environ); e.pop('TTUP_CONV64_DMA', None); e.update(env)
+        r = subprocess.run([sys.executable, '-c', script, out], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    for k in range(3):
+        assert np.array_equal(outs['dma']['heat%d' % k], outs['regs']['heat%d' % k]), k
+        assert np.array_equal(outs['dma']['idx%d' % k], outs['regs']['idx%d' % k]), k
+
+
 def test_frame_record_fast_path_is_bit_identical(tmp_path):
     """preprocess_frames4_kernel (equal source / network width: four pixels per thread, table in LDS) writes the records the
     general kernel writes: heatmaps, indices and windows of `forward_frames` are bit-identical with TTUP_NO_PRE4=1 (read once per

@@ -521,8 +521,10 @@ __global__ __launch_bounds__(512) void conv_s2_pair_kernel(ConvKArgs a) {
 // PIPELINED (round 5): the fragments of step s+1 are requested BEFORE the MFMAs of step s, and a scheduling barrier keeps the
 // requests where they are (the compiler otherwise sinks every ds_read to just in front of its first use: rrrr M wait M wait M ...,
 // i.e. four reads covered by one MFMA, then the LDS latency in the open, 18 times per tile with only two waves per SIMD to hide it).
-template <int NPIX = 340>          // pixels per 32-channel plane of the halo tile (rows x 34): 340 for the 8-row tile, 204 for the stem's 4-row half tile
-__device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_t* const (&bB)[3], const bf16_t* s_w, int wave, int lane) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// hook(s): called in front of the MFMAs of k-step s (conv64_dma_kernel issues the next tile's DMA pieces there, under the matrix work)
+template <int NPIX = 340, typename Hook = NoHook>          // NPIX: pixels per 32-channel plane of the halo tile (rows x 34): 340 for the 8-row tile, 204 for the stem's 4-row half tile
+__device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_t* const (&bB)[3], const bf16_t* s_w, int wave, int lane, Hook hook = Hook()) {
     constexpr int IW = 34;
     bf16x8 brow[2][4], af[2][4];
     auto load_b = [&](bf16x8 (&br)[4], int c, int dx) __attribute__((always_inline)) {
@@ -543,6 +545,7 @@ __device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_
             if (dy1 == 0) load_b(brow[g1 & 1], c1, dx1);
             load_a(af[s1 & 1], c1 * 9 + dy1 * 3 + dx1);
         }
+        hook(s);
 #ifndef TTUP_NO_FRAG_PIPELINE
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -734,6 +737,206 @@ static int launch_conv64_t(const ConvKArgs& a, hipStream_t st) {
     return TTUP_OK;
 }
 
+// ------------------------------------------------------------------ conv64 with LDS-DMA staging (round 5)
+// The same conv as conv64_kernel (same k order, same epilogue: bit-identical results) with the halo tile staged by the DMA path
+// (global_load_lds_dwordx4: memory -> LDS without passing through registers) into one of TWO tile buffers -- this kernel is the one
+// persistent kernel with room for a second buffer (73.7 KB weights + 2 x 43.5 KB = 160,768 B of the 163,840).  Per tile: NO register
+// staging (24 registers fewer), no commit pass, ONE barrier instead of two, the next tile in flight for a whole tile:
+//     MFMA loop on buffer it & 1            (tile it+1 is landing in the other buffer)
+//     wait for tile it+1 + barrier          -- in FRONT of this tile's stores (a wait behind them would drain them, prefetch_arrived)
+//     request tile it+2 into buffer it & 1  (every wave is done reading it)
+//     epilogue of tile it (stores)
+// The DMA writes a wave's 64 x 16 bytes to CONSECUTIVE LDS addresses, so the swizzle of the tile image moves into the SOURCE address:
+// the lane that fills slot j of pixel (iy, ix) fetches channel chunk j ^ ((ix >> 1) & 3).  Interior tiles: scalar tile base + six
+// per-lane byte offsets computed once.  Border tiles (27 % at 1/4 resolution): the lane fetches the clamped pixel (always a valid
+// address) and overwrites its slot with zeros once its own pieces have landed, before the barrier publishes the buffer.
+template <bool L16, bool L32>
+__global__ __launch_bounds__(512) void conv64_dma_kernel(ConvKArgs a) {
+    constexpr int IH = 10, IW = 34, NPIX = IH * IW;
+    constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units
+    constexpr int IN_UNITS = NPIX * 8, IN_PT = (IN_UNITS + 511) / 512;
+    constexpr int BUF_ELEMS = 2 * NPIX * 32;                    // one tile image: [2 planes][340 px][32 ch]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* s_w = (bf16_t*)smem;                                // 73,728 B
+    bf16_t* s_in = s_w + W_U * 8;                               // two tile images, 43,520 B each
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    StageRegs<W_U> wregs;
+    stage_load_512<W_U>(wregs, a.wpack, tid);
+    f32x4 bias[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bias[m] = *(const f32x4*)(a.bias + g * 16 + m * 4);
+    // follower fragments: a lane owns channels g*16 .. g*16+15 of its pixel, k-step k takes channels 16g + 8k + j from lane group
+    // g; in the standard packing those sit at k-step g>>1, lane group 2(g&1)+k
+    bf16x8 al16[2], al32[2][2];
+    f32x4 bl16 = {0.f, 0.f, 0.f, 0.f}, bl32[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (L16) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) al16[k] = *(const bf16x8*)(a.wl16 + ((g >> 1) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
+        bl16 = *(const f32x4*)(a.bl16 + g * 4);
+    }
+    if (L32) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) al32[k][m] = *(const bf16x8*)(a.wl32 + (((g >> 1) * 2 + m) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) bl32[m] = *(const f32x4*)(a.bl32 + g * 8 + m * 4);
+    }
+    const bf16_t* bB[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bB[dx] = s_in + lds_off<32, IW>(0, n + dx, g);
+    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // the thread's six units (16 bytes each) of a tile image: LDS slot u = k * 512 + tid, i.e. plane u / 1360, pixel (u % 1360) / 4, slot
+    // j = u % 4 -- filled from channel chunk j ^ swizzle of that pixel.  voff: byte offset from the tile's first halo pixel (interior
+    // tiles); pyxc: (iy << 16 | ix << 8 | first channel / 8) for the clamped addresses and the zero test of border tiles
+    unsigned voff[IN_PT], pyxc[IN_PT];
+#pragma unroll
+    for (int k = 0; k < IN_PT; ++k) {
+        const int u = tid + k * 512;
+        const int uu = u < IN_UNITS ? u : 0;
+        const int plane = uu / (NPIX * 4), r = uu % (NPIX * 4), pix = r >> 2, j = r & 3;
+        const int iy = pix / IW, ix = pix % IW, c8 = plane * 4 + (j ^ ((ix >> 1) & 3));
+        voff[k] = (unsigned)(((iy * a.W + ix) * 64 + c8 * 8) * 2);
+        pyxc[k] = (unsigned)(iy << 16 | ix << 8 | c8);
+    }
+    unsigned zmask = 0;          // border tile in flight: bit k = the thread's unit k lies outside the image (zeroed once it has landed)
+    // per-tile scalars of the tile being requested, then its pieces one at a time (piece k = units k * 512 .. + 511: one DMA per wave)
+    int q_b = 0, q_gy0 = 0, q_gx0 = 0; bool q_in = false; const char* q_base = nullptr; char* q_dst = nullptr;
+    auto issue_begin = [&](int it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int t = tl % a.tiles_per_img;
+        q_b = tl / a.tiles_per_img; q_gy0 = (t / a.tiles_x) * 8 - 1; q_gx0 = (t % a.tiles_x) * 32 - 1;
+        q_in = q_gy0 >= 0 && q_gy0 + IH <= a.H && q_gx0 >= 0 && q_gx0 + IW <= a.W;
+        q_base = (const char*)(a.src0 + ((size_t)(q_b * a.H + q_gy0) * a.W + q_gx0) * 64);
+        q_dst = (char*)(s_in + (it & 1) * BUF_ELEMS);
+        zmask = 0;
+    };
+    auto issue_piece = [&](int k) __attribute__((always_inline)) {
+        if (k * 512 + wave * 64 >= IN_UNITS) return;          // (wave-uniform; the last piece is half a wave: lanes past the image stay out)
+        auto* ldst = (__attribute__((address_space(3))) void*)(q_dst + (k * 512 + wave * 64) * 16);
+        if (q_in) {
+            if (k * 512 + tid < IN_UNITS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q_base + opaque_u32(voff[k])), ldst, 16, 0, 0);
+        } else {
+            const unsigned q = opaque_u32(pyxc[k]);
+            const int gy = q_gy0 + (int)(q >> 16), gx = q_gx0 + (int)((q >> 8) & 255u);
+            const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+            if (cy != gy || cx != gx) zmask |= 1u << k;
+            if (k * 512 + tid < IN_UNITS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.src0 + ((size_t)(q_b * a.H + cy) * a.W + cx) * 64 + (q & 255u) * 8), ldst, 16, 0, 0);
+        }
+    };
+    // zero padding of a border tile: the thread overwrites ITS OWN out-of-image slots once its pieces have landed (the caller has waited
+    // vmcnt(0): the DMA write of a slot and this write must not swap), before the barrier that publishes the buffer
+    auto zero_fix = [&](int it) {
+        if (__builtin_amdgcn_ballot_w64(zmask != 0) != 0) {          // (wave-uniform)
+            char* dst = (char*)(s_in + (it & 1) * BUF_ELEMS);
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k)
+                if ((zmask >> k & 1u) && k * 512 + tid < IN_UNITS) *(u32x4*)(dst + (k * 512 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
+    issue_begin(0);
+#pragma unroll
+    for (int k = 0; k < IN_PT; ++k) issue_piece(k);
+    stage_store_512<W_U>(s_w, wregs, tid);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile 0 are in LDS
+    zero_fix(0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();                      // tile it visible (every wave waited for its own pieces); every wave is done with the other buffer
+        // the block input (residual) of both pixel groups travels during the MFMA loop (the registers the staged tile no longer needs)
+        u32x4 rres[2][2];
+        if (a.residual) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
+                const bool ok = oy < a.H && ox < a.W;
+                const bf16_t* rp = a.residual + (ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 : 0);      // branch-free: masked lanes read the tensor's first bytes
+                rres[t][0] = *(const u32x4*)rp; rres[t][1] = *(const u32x4*)(rp + 8);
+            }
+        }
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
+        const int sel = (it & 1) * BUF_ELEMS;
+        const bf16_t* const bBc[3] = {bB[0] + sel, bB[1] + sel, bB[2] + sel};
+        const bool more = it + 1 < my_tiles;
+        if (more) issue_begin(it + 1);
+        // the six pieces of tile it+1 go out UNDER this tile's matrix work, one every third k-step (an LDS-DMA instruction costs 60-180
+        // cycles of issue, MI355X_MICROARCH.md: in one block in front of the epilogue they were 10 % of the kernel)
+                // (placement measured: every third k-step from the first, second or third -- equal within noise; all six in the first six k-steps: 2 % slower)
+        conv64_tile_mfma<NPIX>(acc, bBc, s_w, wave, lane, [&](int s) __attribute__((always_inline)) { if (more && s % 3 == 1) issue_piece(s / 3); });
+        // tile it+1 and the block input have landed -- waited for HERE, in front of this tile's stores (behind them the same wait drains them)
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+        if (more) zero_fix(it + 1);
+        // pass 1: both groups' outputs (bias + block input, ReLU, rounding) -- every residual value is consumed before the first store
+        u32x4 pk[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[16];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m * 4 + r] = acc[m][t][r];
+            if (a.residual) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x4 rv = rres[t][q];
+                    const unsigned w4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[q * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]); pk[t][q][i] = a.relu ? relu_pk(w) : w; }
+        }
+        // pass 2: stores and the fuse-layer followers
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
+            const bool ok = oy < a.H && ox < a.W;
+            if (!(L16 || L32) && !ok) continue;           // with followers every lane stays for the MFMAs; only the stores are masked
+            const size_t opix = ok ? (size_t)(b * a.H + oy) * a.W + ox : 0;
+            const size_t o = opix * 64 + g * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (ok) *(u32x4*)(a.dst + o + q * 8) = pk[t][q];
+            if (L16) {
+                f32x4 c = bl16;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al16[k], __builtin_bit_cast(bf16x8, pk[t][k]), c, 0, 0, 0);
+                if (ok) *(u32x2*)(a.dl16 + opix * 16 + g * 4) = u32x2{pack2(c[0], c[1]), pack2(c[2], c[3])};
+            }
+            if (L32) {
+                f32x4 c[2] = {bl32[0], bl32[1]};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al32[k][m], __builtin_bit_cast(bf16x8, pk[t][k]), c[m], 0, 0, 0);
+                if (ok) *(u32x4*)(a.dl32 + opix * 32 + g * 8) = u32x4{pack2(c[0][0], c[0][1]), pack2(c[0][2], c[0][3]), pack2(c[1][0], c[1][1]), pack2(c[1][2], c[1][3])};
+            }
+        }
+    }
+}
+
+template <bool L16, bool L32>
+static int launch_conv64_dma_t(const ConvKArgs& a, hipStream_t st) {
+    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 2 * 340 * 32) * 2;
+    if (int rc = ensure_max_lds((const void*)conv64_dma_kernel<L16, L32>, SMEM)) return rc;
+    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
+    if (grid == 0) return TTUP_OK;
+    hipLaunchKernelGGL((conv64_dma_kernel<L16, L32>), dim3(grid), dim3(512), SMEM, st, a);
+    TTUP_LAUNCH_CHECK();
+    return TTUP_OK;
+}
+
 // ------------------------------------------------------------------ 3x3 64 -> 64 on v_mfma_f32_32x32x16_bf16 (round 5)
 // The same conv as conv64_kernel<false, false> (no followers) with the 32x32x16 MFMA: a wave's 64 couts x (2 rows x 16 px) tile is two
 // 32x32 accumulators (M = 32 couts each, N = the 32 pixels: lane & 31 = 16 * row + column), K = 16 channels of one tap per MFMA.
@@ -902,6 +1105,15 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     if (l.lin32) {
         TTUP_REQUIRE(l.lin32->cout == 32 && l.lin32->cin_total == 64 && l.lin32->k == 1 && l.lin32->ck == 32 && l.lin32_dst, TTUP_EINVAL, "conv64: bad 64->32 follower");
         a.wl32 = (const bf16_t*)l.lin32->w_dev; a.bl32 = l.lin32->bias_dev; a.dl32 = (bf16_t*)l.lin32_dst;
+    }
+    // default: the LDS-DMA form (conv64_dma_kernel), bit-identical to the register-staged conv64_kernel and 4-5 % faster (round 5, same
+    // box, the eight launches of a micro-batch: 0.3405 against 0.3565 ms); TTUP_CONV64_DMA=0 selects the register-staged kernel
+    static const bool dma = !(getenv("TTUP_CONV64_DMA") && getenv("TTUP_CONV64_DMA")[0] == '0');
+    if (dma && !getenv("TTUP_CONV64_32")) {
+        if (l.lin16 && l.lin32) return launch_conv64_dma_t<true, true>(a, st);
+        if (l.lin16) return launch_conv64_dma_t<true, false>(a, st);
+        if (l.lin32) return launch_conv64_dma_t<false, true>(a, st);
+        return launch_conv64_dma_t<false, false>(a, st);
     }
     if (l.lin16 && l.lin32) return launch_conv64_t<true, true>(a, st);
     if (l.lin16) return launch_conv64_t<true, false>(a, st);
