@@ -844,36 +844,8 @@ __global__ __launch_bounds__(512) void conv64_dma_kernel(ConvKArgs a) {
     stage_store_512<W_U>(s_w, wregs, tid);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of tile 0 are in LDS
     zero_fix(0);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        __syncthreads();                      // tile it visible (every wave waited for its own pieces); every wave is done with the other buffer
-        // the block input (residual) of both pixel groups travels during the MFMA loop (the registers the staged tile no longer needs)
-        u32x4 rres[2][2];
-        if (a.residual) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
-                const bool ok = oy < a.H && ox < a.W;
-                const bf16_t* rp = a.residual + (ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 : 0);      // branch-free: masked lanes read the tensor's first bytes
-                rres[t][0] = *(const u32x4*)rp; rres[t][1] = *(const u32x4*)(rp + 8);
-            }
-        }
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
-        const int sel = (it & 1) * BUF_ELEMS;
-        const bf16_t* const bBc[3] = {bB[0] + sel, bB[1] + sel, bB[2] + sel};
-        const bool more = it + 1 < my_tiles;
-        if (more) issue_begin(it + 1);
-        // the six pieces of tile it+1 go out UNDER this tile's matrix work, one every third k-step (an LDS-DMA instruction costs 60-180
-        // cycles of issue, MI355X_MICROARCH.md: in one block in front of the epilogue they were 10 % of the kernel)
-                // (placement measured: every third k-step from the first, second or third -- equal within noise; all six in the first six k-steps: 2 % slower)
-        conv64_tile_mfma<NPIX>(acc, bBc, s_w, wave, lane, [&](int s) __attribute__((always_inline)) { if (more && s % 3 == 1) issue_piece(s / 3); });
-        // tile it+1 and the block input have landed -- waited for HERE, in front of this tile's stores (behind them the same wait drains them)
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-        if (more) zero_fix(it + 1);
+    // epilogue of one tile: bias + block input, ReLU, rounding, stores, fuse-layer followers (conv64_kernel's, verbatim)
+    auto epilogue = [&](const f32x4 (&acc)[4][2], const u32x4 (&rres)[2][2], int b, int oy0, int ox0) __attribute__((always_inline)) {
         // pass 1: both groups' outputs (bias + block input, ReLU, rounding) -- every residual value is consumed before the first store
         u32x4 pk[2][2];
 #pragma unroll
@@ -923,7 +895,54 @@ __global__ __launch_bounds__(512) void conv64_dma_kernel(ConvKArgs a) {
                 if (ok) *(u32x4*)(a.dl32 + opix * 32 + g * 8) = u32x4{pack2(c[0][0], c[0][1]), pack2(c[0][2], c[0][3]), pack2(c[1][0], c[1][1]), pack2(c[1][2], c[1][3])};
             }
         }
+    };
+    // STAGGER (as in the stem; -DTTUP_CONV64_STAGGER): waves 4-7 -- the second wave of every SIMD -- run the epilogue of a tile at the
+    // START of the next iteration, under the partner wave's MFMA loop, instead of beside the partner's own epilogue with the matrix pipe
+    // idle; the accumulators and the block input stay in registers across the barrier.  MEASURED here (round 5): 0.340 against 0.3375 ms
+    // for the eight launches -- no gain (the epilogue's vector work competes for the issue port the partner's MFMA loop needs): off
+#ifdef TTUP_CONV64_STAGGER
+    constexpr bool STAGGER = true;
+#else
+    constexpr bool STAGGER = false;
+#endif
+    const bool late = STAGGER && wave >= 4;
+    f32x4 acc[4][2];
+    u32x4 rres[2][2] = {};
+    int eb = 0, eoy0 = 0, eox0 = 0;
+    bool pending = false;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
+        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
+        __syncthreads();                      // tile it visible (every wave waited for its own pieces); every wave is done with the other buffer
+        if (late && pending) epilogue(acc, rres, eb, eoy0, eox0);
+        // the block input (residual) of both pixel groups travels during the MFMA loop (the registers the staged tile no longer needs)
+        if (a.residual) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oy = oy0 + 2 * (wave >> 1) + t, ox = ox0 + (wave & 1) * 16 + n;
+                const bool ok = oy < a.H && ox < a.W;
+                const bf16_t* rp = a.residual + (ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 : 0);      // branch-free: masked lanes read the tensor's first bytes
+                rres[t][0] = *(const u32x4*)rp; rres[t][1] = *(const u32x4*)(rp + 8);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
+        const int sel = (it & 1) * BUF_ELEMS;
+        const bf16_t* const bBc[3] = {bB[0] + sel, bB[1] + sel, bB[2] + sel};
+        const bool more = it + 1 < my_tiles;
+        if (more) issue_begin(it + 1);
+        // the six pieces of tile it+1 go out UNDER this tile's matrix work, one every third k-step (an LDS-DMA instruction costs 60-180
+        // cycles of issue, MI355X_MICROARCH.md: in one block in front of the epilogue they were 10 % of the kernel)
+        // (placement measured: every third k-step from the first, second or third -- equal within noise; all six in the first six k-steps: 2 % slower)
+        conv64_tile_mfma<NPIX>(acc, bBc, s_w, wave, lane, [&](int s) __attribute__((always_inline)) { if (more && s % 3 == 1) issue_piece(s / 3); });
+        // tile it+1 and the block input have landed -- waited for HERE, in front of this tile's stores (behind them the same wait drains them)
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+        if (more) zero_fix(it + 1);
+        if (late) { eb = b; eoy0 = oy0; eox0 = ox0; pending = true; }
+        else epilogue(acc, rres, b, oy0, ox0);
     }
+    if (late && pending) epilogue(acc, rres, eb, eoy0, eox0);
 }
 
 template <bool L16, bool L32>
