@@ -27,7 +27,12 @@ __device__ unsigned long long ttup_tbuf[8192 * 8];
 __device__ unsigned long long ttup_tbuf_it[3 * 32 * 64 * 8];
 #define TTUP_BID ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
 #define TTUP_STAMP(k) do { if (tid == 0 && TTUP_BID < 8192) ttup_tbuf[TTUP_BID * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef TTUP_TIMING_WAVES
+// ... of EVERY wave of ONE kernel (id == TTUP_TIMING_WAVES): the buffer is read as [8 waves][12 workgroups][64 iterations][8 slots] (tools/wave_timing.py)
+#define TTUP_STAMP_IT(id, it, k) do { if ((id) == TTUP_TIMING_WAVES && (tid & 63) == 0 && blockIdx.x < 12 && (it) < 64) ttup_tbuf_it[((((tid >> 6)) * 12 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define TTUP_STAMP_IT(id, it, k) do { if (tid == 0 && blockIdx.x < 32 && (it) < 64) ttup_tbuf_it[(((id) * 32 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define TTUP_STAMP(k) do { } while (0)
 #define TTUP_STAMP_IT(id, it, k) do { } while (0)
@@ -127,6 +132,14 @@ template <typename T, int N>
 __device__ __forceinline__ void prefetch_arrived(const T (&r)[N]) {
 #pragma unroll
     for (int k = 0; k < N; ++k) asm volatile("" :: "v"(r[k]));
+}
+
+// -DTTUP_PRIO_YOUNG (experiment, MI355X_MICROARCH.md "Static priority for the younger half"): waves 4-7 of an 8-wave workgroup lose
+// the SIMD's issue arbitration to waves 0-3 (priority, then age); one s_setprio 1 for them at kernel start hands them the older half's timing
+__device__ __forceinline__ void prio_young_half() {
+#ifdef TTUP_PRIO_YOUNG
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 }
 
 // Persistent, software-pipelined version: a workgroup walks work items (tile, channel chunk); the global loads of
@@ -752,6 +765,7 @@ static int launch_conv64_t(const ConvKArgs& a, hipStream_t st) {
 // address) and overwrites its slot with zeros once its own pieces have landed, before the barrier publishes the buffer.
 template <bool L16, bool L32>
 __global__ __launch_bounds__(512) void conv64_dma_kernel(ConvKArgs a) {
+    prio_young_half();
     constexpr int IH = 10, IW = 34, NPIX = IH * IW;
     constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units
     constexpr int IN_UNITS = NPIX * 8, IN_PT = (IN_UNITS + 511) / 512;
@@ -1174,6 +1188,7 @@ struct StemArgs {
 // than the layer-wise conv): results agree to bf16 rounding flips, like the other fused kernels (tests/test_gpu_parity.py).
 template <int NF, bool K4 = false>
 __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
+    prio_young_half();
     static_assert(!K4 || NF == 3, "the 4-step conv1 is the three-frame form");
     constexpr int XH = 12, XW = 36, TH1 = 10, TW1 = 34, NP1 = TH1 * TW1;       // X0 region, conv1 output region
     constexpr int KS1 = K4 ? 4 : 5;                                              // conv1 k-steps
@@ -1656,6 +1671,7 @@ __device__ __forceinline__ int st_off(int pix, int c8) { return pix * 32 + ((c8 
 // reduces row r.  Four barriers per tile.  The fp32 summation order of phase 2b (four partial sums) differs from the
 // layer-wise kernel's, everything else is the same arithmetic.
 __global__ __launch_bounds__(512) void bneck_trans_kernel(FusedArgs a) {
+    prio_young_half();
     constexpr int IH = 10, IW = 34, NPIX = IH * IW;            // 340 halo pixels
     constexpr int NT1 = 22;
     constexpr int W1_U = 3 * 8 * 64, W5_U = 4 * 9 * 64;         // 16-byte units
@@ -2489,6 +2505,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
 // per workgroup with its 5 weight fragments per conv straight from L2 (persistent variants measured slower there).
 template <int C, int NB, int TH, int TW>
 __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
+    prio_young_half();
     constexpr int L = 2 * NB;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
     constexpr int SZ_A = R0H * R0W * C, SZ_B = (R0H - 2) * (R0W - 2) * C;
