@@ -3184,6 +3184,10 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
 template <int CK, int KS, int S, int TH, int TW>
 static int dispatch_cout(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
     static const int nw = getenv("TTUP_CONV_WAVES") ? atoi(getenv("TTUP_CONV_WAVES")) : 8;
+    // the stride-2 32 -> 64 conv alone is faster with four-wave workgroups (0.107 against 0.113 ms for its two launches, round 5: twice the
+    // workgroups per CU behind its 52-KB staging); every other variant is 5-26 % slower that way
+    static const bool nw_forced = getenv("TTUP_CONV_WAVES") != nullptr;
+    if (!nw_forced && CK == 32 && S == 2 && p.cout == 64) return launch_mfma<CK, 64, KS, S, TH, TW, 4>(p, l, st);
     if (nw == 8) {
         switch (p.cout) {
             case 16: return launch_mfma<CK, 16, KS, S, TH, TW, 8>(p, l, st);
