@@ -1141,8 +1141,8 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     }
     // default: the LDS-DMA form (conv64_dma_kernel), bit-identical to the register-staged conv64_kernel and 4-5 % faster (round 5, same
     // box, the eight launches of a micro-batch: 0.3405 against 0.3565 ms); TTUP_CONV64_DMA=0 selects the register-staged kernel
-    static const bool dma = !(getenv("TTUP_CONV64_DMA") && getenv("TTUP_CONV64_DMA")[0] == '0');
-    if (dma && !getenv("TTUP_CONV64_32")) {
+    static const bool dma = !(getenv("TTUP_CONV64_DMA") && getenv("TTUP_CONV64_DMA")[0] == '0') && !getenv("TTUP_CONV64_32");
+    if (dma) {
         if (l.lin16 && l.lin32) return launch_conv64_dma_t<true, true>(a, st);
         if (l.lin16) return launch_conv64_dma_t<true, false>(a, st);
         if (l.lin32) return launch_conv64_dma_t<false, true>(a, st);
