@@ -26,7 +26,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ unsigned long long ttup_tbuf[8192 * 8];
 __device__ unsigned long long ttup_tbuf_it[3 * 32 * 64 * 8];
 #define TTUP_BID ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#ifdef TTUP_TIMING_C16W
+#define TTUP_STAMP(k) do { } while (0)          // (the per-wave stamps of csrc/chain16.h own the buffer)
+#else
 #define TTUP_STAMP(k) do { if (tid == 0 && TTUP_BID < 8192) ttup_tbuf[TTUP_BID * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #ifdef TTUP_TIMING_WAVES
 // ... of EVERY wave of ONE kernel (id == TTUP_TIMING_WAVES): the buffer is read as [8 waves][12 workgroups][64 iterations][8 slots] (tools/wave_timing.py)
 #define TTUP_STAMP_IT(id, it, k) do { if ((id) == TTUP_TIMING_WAVES && (tid & 63) == 0 && blockIdx.x < 12 && (it) < 64) ttup_tbuf_it[((((tid >> 6)) * 12 + blockIdx.x) * 64 + (it)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -2140,7 +2144,11 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     const int res_ch = (C == 32) ? ((g ^ (((n + ROFF) >> 1) & 3)) << 3) : ((((g >> 1) ^ (((n + ROFF) >> 2) & 1)) << 3) + (g & 1) * 4);
     const int out_ch = (C == 32) ? ((g ^ (((n + OOFF) >> 1) & 3)) << 3) : ((((g >> 1) ^ (((n + OOFF) >> 2) & 1)) << 3) + (g & 1) * 4);
     // zero padding of the next conv: outputs outside the image must be 0; only border tiles have any (wave-uniform test)
+#ifdef TTUP_ABL_NOPAD
+    const bool interior = true;
+#else
     const bool interior = gy0 >= 0 && gy0 + RHO <= H && gx0 >= 0 && gx0 + RWO <= W;
+#endif
     constexpr bool CAN_FOLLOW = GLOBAL_OUT && C == 32;
     bf16x8 af_f = {};
     f32x4 bias_f = {0.f, 0.f, 0.f, 0.f};
@@ -2490,12 +2498,14 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
                 }
                 if (valid) *(u32x2*)(s_out + ((row + OOFF) * ORW + col + OOFF) * C + ((((g >> 1) ^ (((col + OOFF) >> 2) & 1)) << 3) + (g & 1) * 4)) = u32x2{q0, q1};
             };
+#ifndef TTUP_ABL_NOSTRIPWORK
             if (wave == 7) {
 #pragma unroll
                 for (int j = 0; j < K0; ++j) strip(j);
             }
             if (K0 + wave < NSG) strip(K0 + wave);
             if (NSG - K0 > 8 && K0 + 8 + wave < NSG) strip(K0 + 8 + wave);
+#endif
         }
     }
 }
@@ -2811,8 +2821,13 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
             const int gy = gyb + k * RL;
             // branch-free: an invalid unit reads the tensor's first bytes and is zeroed afterwards (a branch around the load
             // would make every load wait for the one before it)
+#ifdef TTUP_ABL_NOSTAGE
+            const bool ok = false; (void)col_ok; (void)gy;
+            const u32x4 t = u32x4{0u, 0u, 0u, 0u};
+#else
             const bool ok = col_ok && rl + k * RL < R0H && gy >= 0 && gy < a.H;
             const u32x4 t = *(const u32x4*)(ok ? src + k * row_step : a.x);
+#endif
             v[k] = u32x4{ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u};
         }
         bf16_t* dst = bufA + bb_off<C>(rl * SA + col, col, c8);
@@ -2962,6 +2977,8 @@ static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
     return TTUP_OK;
 }
 
+#include "chain16.h"
+
 constexpr int BB_WT_SLOTS = 2;          // C=32: the weights of both convs of the block are LDS-resident
 constexpr int BB_MISC_BYTES = (2 * 32 + 16) * 4 + 1024;      // ... and so are their biases and the follower's bias + fragment (bb_chain_kernel: s_misc)
 template <int C, int NB, int TH, int TW>
@@ -3021,11 +3038,24 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
     if (c == 16 && n_convs == 4) {
         // the epilogue forms the network uses are compiled out (MODE of bb_conv); anything else takes the run-time form
         static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
+#ifdef TTUP_ABL_EPI4
+        return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
+#endif
         bool shifts_ok = true;          // the compiled-out forms assume term k at 1/2^(k+1) resolution (HRNet's fuse layers)
         for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
         const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.ysum && !a.heat;      // a.y (the pre-fuse tensor) optional
         const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
-        if (!generic && a.nsum == 0 && !a.heat && !a.ysum && a.y) return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
+        // TTUP_CHAIN16_OLD=1 (read once per process): the round-2..5 kernel with the same compiled-out epilogues, kept for A/B runs
+        static const bool old16 = getenv("TTUP_CHAIN16_OLD") != nullptr;
+        const bool plain = !generic && a.nsum == 0 && !a.heat && !a.ysum && a.y;
+        if (!old16) {
+            if (plain) return launch_c16_t<BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
+            if (tail) return launch_c16_t<BB2_TH, BB2_TW, 7>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 1) return launch_c16_t<BB2_TH, BB2_TW, 1>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 2) return launch_c16_t<BB2_TH, BB2_TW, 2>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 3) return launch_c16_t<BB2_TH, BB2_TW, 3>(a, batch, h, w, st);
+        }
+        if (plain) return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
         if (tail) return launch_bb2_t<16, BB2_TH, BB2_TW, 7>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 1) return launch_bb2_t<16, BB2_TH, BB2_TW, 1>(a, batch, h, w, st);
         if (sum_stored && a.nsum == 2) return launch_bb2_t<16, BB2_TH, BB2_TW, 2>(a, batch, h, w, st);
