@@ -91,17 +91,36 @@ class Pipeline:
 TRAFFIC_FILE = 'r5_traffic.json'      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round (tools/pmc_traffic.py)
 
 
-def _traffic(kernel_base):
-    """HBM bytes per launch of a kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
-    runs; MI355X_MICROARCH.md, HBM).  None when the profile does not hold the kernel."""
-    try:
-        # a kernel's epilogue variants are separate template instances in the profile: launch-weighted mean over all of them
-        path = os.path.join(ROOT, 'profiles', TRAFFIC_FILE)
-        hits = [e for e in json.load(open(path)) if kernel_base in e['kernel']]
-        if hits:
-            return int(sum(e['hbm_bytes'] * e['launches'] for e in hits) / sum(e['launches'] for e in hits))
-    except Exception:
-        pass
+def _family(kernel):
+    """Kernel family of an op's device kernel ("c16_chain_kernel<24, 32, 7>+sum+head" -> "c16_chain_kernel"): the epilogue variants of
+    the 16-channel chain are one kernel compiled three ways; every other kernel is its own family (template arguments kept)."""
+    exact = kernel.split('+')[0]
+    base = exact.split('<')[0]
+    return base if base in ('c16_chain_kernel', 'bb_chain2_kernel') else exact
+
+
+_TRAFFIC_CACHE = None
+
+
+def _traffic(kernel_exact):
+    """HBM bytes per launch of ONE device kernel (template arguments included, as rocprofv3 prints them) from the committed PMC passes
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate runs; MI355X_MICROARCH.md, HBM).  None when the profile does not hold that kernel --
+    round 5 matched by substring and silently dropped every launch whose op label differed from the kernel's name."""
+    global _TRAFFIC_CACHE
+    if _TRAFFIC_CACHE is None:
+        try:
+            _TRAFFIC_CACHE = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)))
+        except Exception:
+            _TRAFFIC_CACHE = []
+    want = kernel_exact.split('+')[0].replace(' ', '')
+    hits = []
+    for e in _TRAFFIC_CACHE:
+        name = e['kernel'].replace('void ', '').replace('ttup::', '').replace('(anonymous namespace)::', '')
+        name = name.split('(')[0].replace(' ', '')
+        if name == want:
+            hits.append(e)
+    if hits:
+        return int(sum(e['hbm_bytes'] * e['launches'] for e in hits) / sum(e['launches'] for e in hits))
     return None
 
 
@@ -113,22 +132,29 @@ def roofline(pipe):
     from upliftingtabletennis_amd import wasb
     ops = wasb.time_ops(pipe.net, reps=5, in_graph=True)
     groups = {}
+    missing = []          # ops whose device kernel the traffic profile does not hold
     for o in ops:
-        # group by the HIP kernel that runs (the '+sum', '+sum+head', '+1x1' suffixes name epilogue variants of the same kernel)
-        name = o['kernel'].split('+')[0]
-        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'shape': (o['h'], o['w'])})
+        # group by kernel family; HBM traffic is looked up per op by the exact device kernel it launched
+        name = _family(o['kernel'])
+        g = groups.setdefault(name, {'kernel': name, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'shape': (o['h'], o['w']), 'traffic': 0, 'traffic_ok': True})
         g['launches'] += 1; g['ms'] += o['ms']; g['flops'] += o['flops']
+        t = _traffic(o['kernel'])
+        if t is None:
+            g['traffic_ok'] = False
+            missing.append(o['kernel'].split('+')[0])
+        else:
+            g['traffic'] += t
     table = sorted(groups.values(), key=lambda g: -g['ms'])
     tot_ms = sum(o['ms'] for o in ops)
     tot_fl = sum(o['flops'] for o in ops)
     mb = ops[0]['batch']
 
     def entry(g):
-        base = g['kernel'].split('<')[0]
         tf = g['flops'] / (g['ms'] * 1e-3) / 1e12
         return {'kernel': '%s @%dx%d' % (g['kernel'], g['shape'][0], g['shape'][1]), 'launches': g['launches'], 'ms': round(g['ms'], 4),
                 'launch_ms': round(g['ms'] / g['launches'], 4), 'algorithmic_gflop_per_launch': round(g['flops'] / g['launches'] / 1e9, 2),
-                'achieved': round(tf, 2), 'frac': round(tf / PEAK_BF16_TFLOPS, 4), 'traffic': _traffic(base)}
+                'achieved': round(tf, 2), 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
+                'traffic': int(g['traffic'] / g['launches']) if g['traffic_ok'] else None}
     mfma = [g for g in table if g['flops'] > 0]          # the element-wise sums are HBM-bound: no FLOP figure
     longest = mfma[0]                                   # largest TOTAL time per micro-batch
     # lowest fraction among the kernels that matter (>= 5 % of the micro-batch): the small stride-2 / 1x1 convs are HBM- or latency-bound
@@ -136,8 +162,8 @@ def roofline(pipe):
     lowest = min(heavy, key=lambda g: g['flops'] / g['ms'])
     all_tf = tot_fl / (tot_ms * 1e-3) / 1e12
     # HBM bytes of the whole micro-batch from the committed PMC passes (every kernel's bytes per launch x its launches in the graph)
-    tr = [(_traffic(g['kernel'].split('<')[0]), g['launches']) for g in table]
-    traffic_all = int(sum(t * n for t, n in tr if t is not None)) if any(t is not None for t, _ in tr) else None
+    # (None -- not a partial sum -- when the profile lacks any kernel the graph launches: `traffic_missing` lists them)
+    traffic_all = int(sum(g['traffic'] for g in table)) if not missing else None
     # Headline fraction = ALL CNN kernels of one micro-batch (two kernels tie for "dominant" within 1 %, so a
     # dominant-kernel headline flips between 0.21 and 0.31 from box to box; the whole graph's fraction does not).  The dominant
     # kernel by total time and the least efficient heavy kernel are listed beside it, each with its own launch duration.
@@ -152,6 +178,8 @@ def roofline(pipe):
          'per_kernel': [{'kernel': g['kernel'], 'launches': g['launches'], 'ms': round(g['ms'], 4),
                          'tflops': round(g['flops'] / (g['ms'] * 1e-3) / 1e12, 1) if g['flops'] else None} for g in table],
          'cnn_all_ops': {'ms_per_microbatch': round(tot_ms, 3), 'tflops': round(all_tf, 2), 'frac': round(all_tf / PEAK_BF16_TFLOPS, 4)}}
+    if missing:
+        r['traffic_missing'] = sorted(set(missing))
     if r['traffic'] is not None:
         r['traffic_note'] = 'bytes per micro-batch / per launch from profiles/%s (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)' % TRAFFIC_FILE
     return r, ops
@@ -188,7 +216,7 @@ def heatmap_roofline(device, eps_abs):
     ms = timed(lambda: _lib.check(lib.ttup_refine(_lib.ptr(heat), n, H_NET, W_NET, 1920, 1080, 0, None, _lib.ptr(idx), _lib.ptr(win), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())))
     gbs = nbytes / (ms * 1e-3) / 1e9
     seam = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
-            'traffic': _traffic('argmax_partial_kernel'), 'kernel': 'argmax_partial_kernel + argmax_finish_kernel (the extract_position_* seam; not on the timed path)',
+            'traffic': _traffic('argmax_partial_kernel<true>'), 'kernel': 'argmax_partial_kernel + argmax_finish_kernel (the extract_position_* seam; not on the timed path)',
             'launch_ms': round(ms, 4), 'heatmaps': n, 'algorithmic_bytes_per_launch': nbytes}
     K = 32
     cidx = torch.empty((n, K), dtype=torch.int32, device=device)
@@ -208,35 +236,63 @@ def heatmap_roofline(device, eps_abs):
 
 
 def _cpu_child(style, n, threads):
-    """One CPU-oracle timing in a FRESH process (`python bench.py --cpu-child style n threads`): no GPU, its own thread pool.
-    Prints one JSON line {seconds, triples, threads}."""
+    """One CPU-oracle timing in a FRESH process (`python bench.py --cpu-child style n threads`): no GPU is touched, the OpenMP pool is this
+    process's own (OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES come from the caller's environment).  One FULL-SIZE warm-up triple first
+    (oneDNN creates its convolution primitives per shape: a 64-row strip warms nothing that the full frame uses), then n timed triples.
+    Prints one JSON line {seconds, triples, threads, per_triple, parts, torch, mkldnn, omp}."""
     torch.set_num_threads(threads)
     from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
     from upliftingtabletennis_amd import synth, weights
-    frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
+    frames, _ = synth.synth_frames(n + 3, H_SRC, W_SRC, seed=0)
     sd = weights.random_wasb_state_dict(0, planted=True)
+    parts = {'resize_normalise': 0.0, 'cnn': 0.0, 'refine': 0.0, 'uplift': 0.0}
+    per = []
     if style == 'b1':          # batch 1 per triple + table-variant fit, like interface.py:102-119, + one trajectory through the uplift net
         usd = weights.random_uplift_state_dict(0, 'large')
-        x0 = glue_ref.triple_to_tensor(frames[0], frames[1], frames[2], (W_NET, H_NET))[None, :, :64]
-        wasb_ref.wasb_forward(x0, sd)                      # warm the pool (thread creation, allocator) on a 64-row strip, outside the timing
+        t_w = time.time()
+        xw = glue_ref.triple_to_tensor(frames[n], frames[n + 1], frames[n + 2], (W_NET, H_NET))[None]
+        refine_ref.extract_position_table(wasb_ref.wasb_forward(xw, sd).numpy(), 1920, 1080)
+        warm = time.time() - t_w
         t0 = time.time()
         for i in range(n):
+            ta = time.time()
             x = glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET))[None]
+            tb = time.time()
             heat = wasb_ref.wasb_forward(x, sd).numpy()
+            tc = time.time()
             refine_ref.extract_position_table(heat, 1920, 1080)
+            td = time.time()
+            parts['resize_normalise'] += tb - ta; parts['cnn'] += tc - tb; parts['refine'] += td - tc
+            per.append(round(td - ta, 3))
+        tu = time.time()
         ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=1)
         rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
         uplift_ref.transform_rotationaxes(rot, p3)
+        parts['uplift'] = time.time() - tu
         dt = time.time() - t0
     else:                      # micro-batches of 4 + ball-variant fit, like inference/utils.py:51-59
         x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
-        wasb_ref.wasb_forward(x[:1, :, :64], sd)
+        t_w = time.time()
+        refine_ref.extract_position_ball(wasb_ref.wasb_forward(x[:4], sd).numpy(), 1920, 1080)
+        warm = time.time() - t_w
         t0 = time.time()
         for b0 in range(0, n, 4):
+            ta = time.time()
             heat = wasb_ref.wasb_forward(x[b0:b0 + 4], sd).numpy()
+            tb = time.time()
             refine_ref.extract_position_ball(heat, 1920, 1080)
+            tc = time.time()
+            parts['cnn'] += tb - ta; parts['refine'] += tc - tb
+            per.append(round(tc - ta, 3))
         dt = time.time() - t0
-    print(json.dumps({'seconds': dt, 'triples': n, 'threads': torch.get_num_threads()}), flush=True)
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count()
+    print(json.dumps({'seconds': dt, 'triples': n, 'threads': torch.get_num_threads(), 'warmup_seconds': round(warm, 3), 'per_triple': per,
+                      'parts': {k: round(v, 3) for k, v in parts.items()}, 'torch': torch.__version__,
+                      'mkldnn': bool(torch.backends.mkldnn.is_available() and torch.backends.mkldnn.enabled), 'affinity': aff,
+                      'omp': {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OMP_PROC_BIND', 'OMP_PLACES', 'GOMP_CPU_AFFINITY', 'KMP_AFFINITY') if os.environ.get(k)}}), flush=True)
 
 
 def _cpu_model():

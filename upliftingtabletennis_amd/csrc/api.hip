@@ -14,6 +14,17 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+static thread_local char g_kernel[64] = "";
+void kernel_note(const char* fmt, ...) {
+    if (g_kernel[0]) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof g_kernel, fmt, ap);
+    va_end(ap);
+}
+void kernel_note_reset() { g_kernel[0] = 0; }
+const char* kernel_noted() { return g_kernel; }
+
 int ensure_max_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return TTUP_OK;
     int dev = 0;

@@ -221,7 +221,9 @@ __device__ __forceinline__ void c16_conv_out(const char* s_in, const char* s_res
     tbx[0] = s_terms + (t2lane ? T2OFF + (n >> 2) * C16_PB : (n >> 1) * C16_PB) + c8 * 16;
     tbx[1] = tbx[0] + (t2lane ? 4 * C16_PB : 8 * C16_PB);
     const char* tb3 = s_terms + T3OFF + (n >> 3) * C16_PB + c8 * 16;
+#ifdef TTUP_C16_NARROW
     const unsigned st_16 = (unsigned)((n * 16 + g * 4) * 2);             // lane's 8 bytes inside a 16-pixel run of 16-channel records
+#endif
     const float head_one = (n == 0) ? 1.f : 0.f;          // A operand of the head's cross-lane sum (row 0 of a 16x4 matrix of ones)
     float hvs[2 * RB];
     bf16x8 fa[2][RB + 2];
@@ -369,15 +371,6 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
 #if defined(TTUP_TIMING) && defined(TTUP_TIMING_C16W)
     unsigned long long wst[16] = {};
 #endif
-#ifdef TTUP_C16_DEPHASE
-    // experiment: the two workgroups of a CU start together and, with identical work, stay in the same phase (both staging, both in
-    // MFMA phases, both in epilogues).  Half of the FIRST generation of workgroups waits half a tile time before it starts.
-    {
-        const int lid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const bool late = TTUP_C16_DEPHASE == 1 ? (lid >= 256 && lid < 512) : TTUP_C16_DEPHASE == 2 ? (lid < 512 && ((lid >> 3) & 1)) : (lid < 512 && (lid & 1));
-        if (late) { __builtin_amdgcn_s_sleep(96); __builtin_amdgcn_s_sleep(96); }      // 2 x 96 x 64 cycles = half of the 24-k-cycle tile
-    }
-#endif
     C16_WSTAMP(0);
     BBFrag16 fr;
     bf16x8 idm;
@@ -436,7 +429,9 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
     c16_conv_lds<SA, 0, R0H - 2, R0W - 2, false, 1, 0, SB, 0>(bufA, bufB, nullptr, fr, idm, oy0 - 3, ox0 - 3, a.H, a.W, wave, lane);
     TTUP_STAMP(2);
     C16_WSTAMP(3);
-    bb_load_frag16(fr, a.w[1], a.bias[1], lane);          // next conv's fragments: requested BEFORE the barrier, in flight across it
+    // next conv's fragments: requested BEFORE the barrier, in flight across it.  (Requested a whole conv earlier into a second register
+    // set -- 110-116 instead of 86-100 VGPRs -- the kernel is no faster: 0.7311 against 0.7310 ms for its three launches.)
+    bb_load_frag16(fr, a.w[1], a.bias[1], lane);
     __syncthreads();
     TTUP_STAMP(3);
     C16_WSTAMP(4);
@@ -529,6 +524,7 @@ static int launch_c16_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
+    kernel_note("c16_chain_kernel<%d, %d, %d>", TH, TW, MODE);
     hipLaunchKernelGGL((c16_chain_kernel<TH, TW, MODE>), dim3(k.tiles_x, cdiv(h, TH), batch), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;

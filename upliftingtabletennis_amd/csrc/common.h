@@ -11,6 +11,12 @@
 namespace ttup {
 
 void set_error(const char* fmt, ...);   // thread-local, returned by ttup_last_error()
+// Measurement aid (ttup_wasb_time_graph / time_ops -> bench.py's roofline and its lookup of PMC traffic by kernel): a launcher
+// leaves the template-id of the device kernel it launches exactly as rocprofv3 prints it ("conv_mfma_kernel<32, 128, 3, 1, 8, 32, 8, false>").
+// Thread-local; only the FIRST note after a reset is kept (an op's main kernel comes first, a tiny finishing kernel may follow).
+void kernel_note(const char* fmt, ...);
+void kernel_note_reset();
+const char* kernel_noted();
 
 #define TTUP_HIP_CHECK(expr)                                                                  \
     do {                                                                                      \

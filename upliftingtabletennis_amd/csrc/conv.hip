@@ -749,6 +749,7 @@ static int launch_conv64_t(const ConvKArgs& a, hipStream_t st) {
     if (int rc = ensure_max_lds((const void*)conv64_kernel<L16, L32>, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
+    kernel_note("conv64_kernel<%s, %s>", L16 ? "true" : "false", L32 ? "true" : "false");
     hipLaunchKernelGGL((conv64_kernel<L16, L32>), dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -969,162 +970,8 @@ static int launch_conv64_dma_t(const ConvKArgs& a, hipStream_t st) {
     if (int rc = ensure_max_lds((const void*)conv64_dma_kernel<L16, L32>, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
+    kernel_note("conv64_dma_kernel<%s, %s>", L16 ? "true" : "false", L32 ? "true" : "false");
     hipLaunchKernelGGL((conv64_dma_kernel<L16, L32>), dim3(grid), dim3(512), SMEM, st, a);
-    TTUP_LAUNCH_CHECK();
-    return TTUP_OK;
-}
-
-// ------------------------------------------------------------------ 3x3 64 -> 64 on v_mfma_f32_32x32x16_bf16 (round 5)
-// The same conv as conv64_kernel<false, false> (no followers) with the 32x32x16 MFMA: a wave's 64 couts x (2 rows x 16 px) tile is two
-// 32x32 accumulators (M = 32 couts each, N = the 32 pixels: lane & 31 = 16 * row + column), K = 16 channels of one tap per MFMA.
-//   A (weights)  lane (r = lane & 31, h = lane >> 5) holds W[cout C(r)][16-channel slice: channels 8h .. 8h+7] with the row permutation
-//                C(M2, r) = 32 M2 + 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3), so that after the MFMA lane (px, h) holds the 16 CONSECUTIVE
-//                channels 32 M2 + 16 h + q of its pixel in accumulator registers q = 0..15 (32-byte stores).  The LDS image
-//                [tap/slice step 36][M2][lane][8] is gathered from the standard packing while the weights are staged (no second packing).
-//   B (pixels)   lane (px, h): channels 8h .. 8h+7 of the slice of pixel (row px >> 4, column px & 15) shifted by the tap: one 16-byte
-//                read of the same swizzled halo tile as conv64_kernel (conflict-free: the two rows of a lane group fall on opposite halves of
-//                the bank row and the column swizzle separates the four pixels that share a slot group).
-// Per (plane, tap column): 6 pixel-fragment reads (the two output rows are the lane halves of ONE fragment, so the three tap rows cannot
-// share registers as in the 16x16x32 form: 6 instead of 4) + 12 weight-fragment reads for 12 MFMAs of 32 cycles -- 9 LDS reads per
-// 192 MFMA cycles against 8, HALF the MFMA instructions.  Another fp32 summation order (K = 16 per MFMA): results agree with
-// conv64_kernel to bf16 rounding flips.  Opt-in (TTUP_CONV64_32=1): measured 0.8 % slower than the 16x16x32 form (launch_conv64).
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-__global__ __launch_bounds__(512) void conv64_32_kernel(ConvKArgs a) {
-    constexpr int IH = 10, IW = 34, NPIX = IH * IW;
-    constexpr int W_U = 2 * 9 * 4 * 64;                         // 16-byte units = 36 steps x 2 M-tiles x 64 lanes
-    constexpr int IN_UNITS = NPIX * 8, IN_PT = (IN_UNITS + 511) / 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* s_w = (bf16_t*)smem;                                // 73,728 B
-    bf16_t* s_in = s_w + W_U * 8;                               // [2 planes][340 px][32 ch]  43,520 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = lane & 31, h = lane >> 5;
-    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (my_tiles <= 0) return;
-    // weights: destination unit d = (step * 2 + M2) * 64 + lane  <-  source unit of the standard packing ((plane * 9 + tap) * 4 + m) * 64 + i + 16 G
-    u32x4 wreg[W_U / 512];
-#pragma unroll
-    for (int k = 0; k < W_U / 512; ++k) {
-        const int d = tid + k * 512;
-        const int dl = d & 63, M2 = (d >> 6) & 1, st = d >> 7;                 // st = (plane * 9 + tap) * 2 + slice
-        const int r = dl & 31, hh = dl >> 5, slice = st & 1, pt = st >> 1;     // pt = plane * 9 + tap
-        const int C = 32 * M2 + 16 * ((r >> 2) & 1) + (r & 3) + 4 * (r >> 3);
-        const int m = (C >> 2) & 3, i = ((C >> 4) << 2) | (C & 3), G = 2 * slice + hh;
-        wreg[k] = ((const u32x4*)a.wpack)[(pt * 4 + m) * 64 + i + 16 * G];
-    }
-    f32x16 bias[2];          // lane's channels 32 M2 + 16 h + q
-#pragma unroll
-    for (int M2 = 0; M2 < 2; ++M2)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + 32 * M2 + 16 * h + 4 * q4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bias[M2][4 * q4 + j] = b4[j];
-        }
-    // per-lane pixel-fragment bases: tap column dx, slice sl -> chunk 2 sl + h of pixel (row px >> 4, column (wave & 1) * 16 + (px & 15) + dx)
-    const bf16_t* bB[3][2];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-            bB[dx][sl] = s_in + lds_off<32, IW>(2 * (wave >> 1) + (px >> 4), (wave & 1) * 16 + (px & 15) + dx, 2 * sl + h);
-    u32x4 pin[IN_PT];
-    auto issue = [&](int it) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        const int b = tl / a.tiles_per_img, t = tl % a.tiles_per_img;
-        const int gy0 = (t / a.tiles_x) * 8 - 1, gx0 = (t % a.tiles_x) * 32 - 1;
-#pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 512;
-            const int c8 = u & 7, pix = u >> 3;
-            const int gy = gy0 + pix / IW, gx = gx0 + pix % IW;
-            pin[k] = u32x4{0u, 0u, 0u, 0u};
-            if (u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                pin[k] = *(const u32x4*)(a.src0 + ((size_t)(b * a.H + gy) * a.W + gx) * 64 + c8 * 8);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = tid + k * 512;
-            if (u < IN_UNITS) { const int c8 = u & 7, pix = u >> 3; *(u32x4*)(s_in + (c8 >> 2) * (NPIX * 32) + lds_off<32, IW>(pix / IW, pix % IW, c8 & 3)) = pin[k]; }
-        }
-    };
-    issue(0);
-#pragma unroll
-    for (int k = 0; k < W_U / 512; ++k) ((u32x4*)s_w)[tid + k * 512] = wreg[k];
-    prefetch_arrived(pin);
-    prefetch_arrived(bias);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        const int b = tl / a.tiles_per_img, tt = tl % a.tiles_per_img;
-        const int oy0 = (tt / a.tiles_x) * 8, ox0 = (tt % a.tiles_x) * 32;
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (it + 1 < my_tiles) issue(it + 1);
-        f32x16 acc[2] = {bias[0], bias[1]};
-        // 36 steps (plane c, tap column dx, tap row dy, slice sl), 2 MFMAs each; fragments of step s+1 requested before the MFMAs of step s
-        bf16x8 bf[2], af[2][2];
-        auto load_step = [&](int s, bf16x8& b1, bf16x8 (&a2)[2]) __attribute__((always_inline)) {
-            const int sl = s & 1, dy = (s >> 1) % 3, dx = (s / 6) % 3, c = s / 18;
-            b1 = *(const bf16x8*)(bB[dx][sl] + c * (NPIX * 32) + dy * IW * 32);
-            const int st = ((c * 9 + dy * 3 + dx) * 2 + sl);
-#pragma unroll
-            for (int M2 = 0; M2 < 2; ++M2) a2[M2] = *(const bf16x8*)(s_w + ((st * 2 + M2) * 64 + lane) * 8);
-        };
-        load_step(0, bf[0], af[0]);
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
-            if (s + 1 < 36) load_step(s + 1, bf[(s + 1) & 1], af[(s + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int M2 = 0; M2 < 2; ++M2) acc[M2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][M2], bf[s & 1], acc[M2], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        prefetch_arrived(pin);
-        // ---- epilogue: lane (px, h) holds channels 32 M2 + 16 h + q of pixel (2 (wave >> 1) + (px >> 4), (wave & 1) * 16 + (px & 15))
-        const int oy = oy0 + 2 * (wave >> 1) + (px >> 4), ox = ox0 + (wave & 1) * 16 + (px & 15);
-        const bool ok = oy < a.H && ox < a.W;
-        const size_t o = ok ? ((size_t)(b * a.H + oy) * a.W + ox) * 64 + 16 * h : 0;
-        u32x4 rres[2][2];
-        if (a.residual) {
-#pragma unroll
-            for (int M2 = 0; M2 < 2; ++M2) { rres[M2][0] = *(const u32x4*)(a.residual + o + 32 * M2); rres[M2][1] = *(const u32x4*)(a.residual + o + 32 * M2 + 8); }
-        }
-        u32x4 pk[2][2];          // every residual value is consumed before the first store (a wait behind a store would drain it)
-#pragma unroll
-        for (int M2 = 0; M2 < 2; ++M2) {
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = acc[M2][q];
-            if (a.residual) {
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const unsigned w4[4] = {rres[M2][q2].x, rres[M2][q2].y, rres[M2][q2].z, rres[M2][q2].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[q2 * 8 + 2 * k] += bf16_to_f32((bf16_t)(w4[k] & 0xffff)); v[q2 * 8 + 2 * k + 1] += bf16_to_f32((bf16_t)(w4[k] >> 16)); }
-                }
-            }
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const unsigned w = pack2(v[q2 * 8 + 2 * i], v[q2 * 8 + 2 * i + 1]); pk[M2][q2][i] = a.relu ? relu_pk(w) : w; }
-        }
-        if (ok) {
-#pragma unroll
-            for (int M2 = 0; M2 < 2; ++M2)
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) *(u32x4*)(a.dst + o + 32 * M2 + q2 * 8) = pk[M2][q2];
-        }
-    }
-}
-
-static int launch_conv64_32(const ConvKArgs& a, hipStream_t st) {
-    constexpr size_t SMEM = (size_t)(2 * 9 * 4 * 64 * 8 + 2 * 340 * 32) * 2;
-    if (int rc = ensure_max_lds((const void*)conv64_32_kernel, SMEM)) return rc;
-    const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
-    if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL(conv64_32_kernel, dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -1145,7 +992,7 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     }
     // default: the LDS-DMA form (conv64_dma_kernel), bit-identical to the register-staged conv64_kernel and 4-5 % faster (round 5, same
     // box, the eight launches of a micro-batch: 0.3405 against 0.3565 ms); TTUP_CONV64_DMA=0 selects the register-staged kernel
-    static const bool dma = !(getenv("TTUP_CONV64_DMA") && getenv("TTUP_CONV64_DMA")[0] == '0') && !getenv("TTUP_CONV64_32");
+    static const bool dma = !(getenv("TTUP_CONV64_DMA") && getenv("TTUP_CONV64_DMA")[0] == '0');
     if (dma) {
         if (l.lin16 && l.lin32) return launch_conv64_dma_t<true, true>(a, st);
         if (l.lin16) return launch_conv64_dma_t<true, false>(a, st);
@@ -1155,11 +1002,7 @@ static int launch_conv64(const PackedConv& p, const ConvLaunch& l, hipStream_t s
     if (l.lin16 && l.lin32) return launch_conv64_t<true, true>(a, st);
     if (l.lin16) return launch_conv64_t<true, false>(a, st);
     if (l.lin32) return launch_conv64_t<false, true>(a, st);
-    // TTUP_CONV64_32=1: the 32x32x16 form of the plain conv (conv64_32_kernel).  MEASURED (round 5, same box, the eight launches of a
-    // micro-batch with six of them on this kernel): 0.3625 / 0.3584 / 0.3605 ms against 0.3569 / 0.3601 / 0.3571 for the 16x16x32 form --
-    // 0.8 % slower; parity tests green in both.  Half the MFMA instructions do not pay for 12 % more LDS reads here.
-    static const bool k32 = getenv("TTUP_CONV64_32") != nullptr;
-    if (k32) return launch_conv64_32(a, st);
+    // (the 32x32x16-MFMA form of this conv, round 5: 0.8 % slower -- csrc/experiments/rejected_kernels.hip.inc)
     return launch_conv64_t<false, false>(a, st);
 }
 
@@ -1432,183 +1275,6 @@ __global__ __launch_bounds__(512) void stem_kernel(StemArgs a) {
     if (STAGGER && late && pending) epilogue(acc, eb, eoy0, eox0);
 }
 
-// ------------------------------------------------------------------ stem, two wave groups in opposite phases (round 5)
-// stem_kernel runs its eight waves in lockstep (X0 commit, conv1, barrier, conv2 + stores): the matrix pipe is 63 % busy, the rest
-// is conv1's packing and LDS stores, conv2's epilogue and the skew at two barriers per tile -- all of it on both waves of a SIMD at
-// the same time.  The stem issues only ~1.3 vector instructions per MFMA (the SIMD's issue port has room for two), so unlike the
-// 32-channel block (bb32_duo_kernel) it has something to gain from taking its two phases apart:
-//   group A (waves 0-3): conv1 of half tile t (4 output rows: 6x34 region, 13 pixel groups) X[t & 1] -> T1[t & 1]; then commits the
-//                        prefetched X0 of half tile t+1 -> X[(t+1) & 1] and requests half tile t+2
-//   group B (waves 4-7): conv2 of half tile t-1 from T1[(t-1) & 1] + T2 store + Bottleneck conv1 follower + A1 store
-// with ONE workgroup barrier per half tile; every SIMD holds one wave of each group.  Triples with the 4-k-step conv1 only.  All weights
-// LDS-resident as before (16 + 72 KB), two T1 half tiles (2 x 25.5 KB), two X0 half tiles (2 x 6.8 KB).  Same arithmetic per output
-// as stem_kernel<3, true> (same k order, same roundings): bit-identical.
-// MEASURED (round 5, same box): 0.692 against 0.608 ms per micro-batch -- 14 % SLOWER.  A half-tile phase needs 216 MFMAs per SIMD
-// (3.46 k cycles) but lasts ~5.7 k: the conv2 wave's loop + epilogue is one serial chain (152 MFMAs, then ~1 k cycles of packing,
-// stores and follower with nothing of its own to overlap), and its SIMD partner -- the conv1 wave, 48-64 MFMAs -- has too little
-// matrix work to fill that time.  In the one-phase kernel BOTH waves of a SIMD carry 200 MFMAs per tile and cover each other.
-// Opt-in: TTUP_STEM_DUO=1 (kept as the measured experiment; the default is stem_kernel<3, true>).
-__global__ __launch_bounds__(512) void stem_duo_kernel(StemArgs a) {
-    constexpr int XH = 8, XW = 36, TH1 = 6, TW1 = 34, NP1 = TH1 * TW1, XS = 12;       // X0 region, conv1 output region of a 4x32 half tile
-    constexpr int W1_U = 4 * 4 * 64, W2_U = 2 * 9 * 4 * 64;
-    constexpr int X_UNITS = XH * XW * 3, X_PT = (X_UNITS + 255) / 256;                 // 8-byte units, staged by group A's 256 threads
-    constexpr int T1_ELEMS = 2 * NP1 * 32, X_ELEMS = XH * XW * XS + 8;                 // (+ 16 B: the last fragment of the last pixel reads 4 slots past it)
-    constexpr int NG1 = (NP1 + 15) / 16;                                               // 13 pixel groups of conv1
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* s_w1 = (bf16_t*)smem;
-    bf16_t* s_w2 = s_w1 + W1_U * 8;
-    bf16_t* s_t1 = s_w2 + W2_U * 8;                   // [2][T1_ELEMS]
-    bf16_t* s_x = s_t1 + 2 * T1_ELEMS;                // [2][X_ELEMS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
-    const int n = lane & 15, g = lane >> 4;
-    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (my_tiles <= 0) return;          // (workgroup-uniform)
-    StageRegs<W1_U> w1regs; StageRegs<W2_U> w2regs;
-    stage_load_512<W1_U>(w1regs, a.w1, tid);
-    stage_load_512<W2_U>(w2regs, a.w2, tid);
-    bf16x8 af3[2][2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) af3[k][m] = *(const bf16x8*)(a.w3 + (((g >> 1) * 2 + m) * 64 + n + 16 * ((g & 1) * 2 + k)) * 8);
-    f32x4 b1[4], b2[4], b3[2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { b1[m] = *(const f32x4*)(a.b1 + g * 16 + m * 4); b2[m] = *(const f32x4*)(a.b2 + g * 16 + m * 4); }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) b3[m] = *(const f32x4*)(a.b3 + g * 8 + m * 4);
-    int koff1[4];
-#pragma unroll
-    for (int s5 = 0; s5 < 4; ++s5) { const int kk0 = 32 * s5 + 8 * g, r = kk0 / 40, o0 = kk0 % 40; koff1[s5] = r < 3 ? r * XW * XS + o0 : 0; }
-    const bf16_t* bB0[3];          // conv2 fragment bases inside T1[0]
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) bB0[dx] = s_t1 + lds_off<32, TW1>(0, n + dx, g);
-    u32x2 pf[X_PT];
-    unsigned pf_ok = 0u;
-    for (int u = tid; u < 2 * X_ELEMS / 8; u += 512) ((u32x4*)s_x)[u] = u32x4{0u, 0u, 0u, 0u};          // the pads (and everything else) start as zeros
-    auto tile_origin = [&](int it, int& b, int& oy0, int& ox0) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        b = tl / a.tiles_per_img;
-        const int tt = tl % a.tiles_per_img;
-        oy0 = (tt / a.tiles_x) * 4; ox0 = (tt % a.tiles_x) * 32;
-    };
-    auto issue = [&](int it) {          // group A; branch-free, the zeroing happens at the commit
-        int b, oy0, ox0;
-        tile_origin(it, b, oy0, ox0);
-#pragma unroll
-        for (int k = 0; k < X_PT; ++k) {
-            const int u = gtid + k * 256;
-            const int f = u % 3, pix = u / 3;
-            const int gy = oy0 - 2 + pix / XW, gx = ox0 - 2 + pix % XW;
-            const bool ok = u < X_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pf[k] = *(const u32x2*)(ok ? a.x0 + (((size_t)(b + f) * a.H + gy) * a.W + gx) * 4 : a.x0);
-            pf_ok = ok ? pf_ok | (1u << k) : pf_ok & ~(1u << k);
-        }
-    };
-    auto commit = [&](bf16_t* xbuf) {
-#pragma unroll
-        for (int k = 0; k < X_PT; ++k) {
-            const int u = gtid + k * 256;
-            const bool okk = (pf_ok >> k) & 1u;
-            if (u < X_UNITS) *(u32x2*)(xbuf + (u / 3) * XS + (u % 3) * 4) = u32x2{okk ? pf[k].x : 0u, okk ? pf[k].y : 0u};
-        }
-    };
-    stage_store_512<W1_U>(s_w1, w1regs, tid);
-    stage_store_512<W2_U>(s_w2, w2regs, tid);
-    // kernel-lifetime registers complete on every path into the loop (prefetch_arrived)
-    prefetch_arrived(af3[0]); prefetch_arrived(af3[1]); prefetch_arrived(b1); prefetch_arrived(b2); prefetch_arrived(b3);
-    __syncthreads();          // s_x zeroed before group A's first commit
-    if (grp == 0) {
-        issue(0);
-        commit(s_x);
-        if (my_tiles > 1) issue(1);
-    }
-    __syncthreads();
-    for (int p = 0; p <= my_tiles; ++p) {
-        if (grp == 0) {
-            if (p < my_tiles) {
-                // ---------------- conv1 of half tile p on the 6x34 region (13 groups of 16 pixels, linear pixel index)
-                int b, oy0, ox0;
-                tile_origin(p, b, oy0, ox0);
-                const bf16_t* xs = s_x + (p & 1) * X_ELEMS;
-                bf16_t* t1 = s_t1 + (p & 1) * T1_ELEMS;
-#pragma unroll
-                for (int t = 0; t < (NG1 + 3) / 4; ++t) {
-                    const int j = gw + 4 * t;
-                    if (j >= NG1) continue;
-                    const int pidx = j * 16 + n, pc = pidx < NP1 ? pidx : NP1 - 1;
-                    const int y = pc / TW1, x = pc % TW1;
-                    const bf16_t* xb = xs + (y * XW + x) * XS;
-                    f32x4 acc[4] = {b1[0], b1[1], b1[2], b1[3]};
-#pragma unroll
-                    for (int s5 = 0; s5 < 4; ++s5) {
-                        const u32x2 lo = *(const u32x2*)(xb + koff1[s5]), hi = *(const u32x2*)(xb + koff1[s5] + 4);
-                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const bf16x8 af = *(const bf16x8*)(s_w1 + ((s5 * 4 + m) * 64 + lane) * 8);
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[m], 0, 0, 0);
-                        }
-                    }
-                    if (pidx < NP1) {
-                        const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-                        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            u32x4 pk;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const unsigned w = relu_pk(pack2(acc[2 * q + (i >> 1)][2 * (i & 1)], acc[2 * q + (i >> 1)][2 * (i & 1) + 1]));
-                                pk[i] = inside ? w : 0u;
-                            }
-                            *(u32x4*)(t1 + (g >> 1) * (NP1 * 32) + lds_off<32, TW1>(y, x, (g & 1) * 2 + q)) = pk;
-                        }
-                    }
-                }
-            }
-            if (p + 1 < my_tiles) {
-                commit(s_x + ((p + 1) & 1) * X_ELEMS);          // last read by this group's own conv1 of half tile p-1
-                if (p + 2 < my_tiles) issue(p + 2);
-            }
-        } else if (p >= 1) {
-            // ---------------- conv2 of half tile p-1: 4x32 outputs, both 32-channel planes straight from LDS
-            int b, oy0, ox0;
-            tile_origin(p - 1, b, oy0, ox0);
-            const int toff = ((p - 1) & 1) * T1_ELEMS;
-            const bf16_t* bB[3] = {bB0[0] + toff, bB0[1] + toff, bB0[2] + toff};
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { acc[m][0] = b2[m]; acc[m][1] = b2[m]; }
-            conv64_tile_mfma<NP1>(acc, bB, s_w2, gw, lane);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int r = 2 * (gw >> 1) + t, cg = gw & 1;
-                const int oy = oy0 + r, ox = ox0 + cg * 16 + n;
-                const bool ok = oy < a.H && ox < a.W;
-                u32x4 pk[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pk[q][i] = relu_pk(pack2(acc[2 * q + (i >> 1)][t][2 * (i & 1)], acc[2 * q + (i >> 1)][t][2 * (i & 1) + 1]));
-                    if (ok) *(u32x4*)(a.t2 + ((size_t)(b * a.H + oy) * a.W + ox) * 64 + g * 16 + q * 8) = pk[q];
-                }
-                f32x4 c3[2] = {b3[0], b3[1]};
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) c3[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[k][m], __builtin_bit_cast(bf16x8, pk[k]), c3[m], 0, 0, 0);
-                if (ok) {
-                    u32x4 po;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) po[i] = relu_pk(pack2(c3[i >> 1][2 * (i & 1)], c3[i >> 1][2 * (i & 1) + 1]));
-                    *(u32x4*)(a.a1 + ((size_t)(b * a.H + oy) * a.W + ox) * 32 + g * 8) = po;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3, const void* x0, void* t2, void* a1,
                 int batch, int h, int w, hipStream_t st, int frames_per_sample) {
     TTUP_REQUIRE((p1.cout == 64 && p1.cin_total == 16 && p1.k == 3 && p1.stride == 1 && p1.ck == 16) ||
@@ -1628,19 +1294,8 @@ int launch_stem(const PackedConv& p1, const PackedConv& p2, const PackedConv& p3
     if (int rc = ensure_max_lds(kfn, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
-    static const bool duo = getenv("TTUP_STEM_DUO") != nullptr;          // measured 14 % slower than the one-phase kernel: see stem_duo_kernel
-    if (k4 && duo && h % 4 == 0) {
-        // two wave groups in opposite phases over 4-row half tiles (stem_duo_kernel)
-        constexpr size_t SMEM2 = (size_t)(4 * 4 * 64 * 8 + 2 * 9 * 4 * 64 * 8 + 2 * (2 * 204 * 32) + 2 * (8 * 36 * 12 + 8)) * 2;
-        static_assert(SMEM2 <= 160 * 1024, "LDS budget");
-        if (int rc = ensure_max_lds((const void*)stem_duo_kernel, SMEM2)) return rc;
-        StemArgs a2 = a;
-        a2.tiles_per_img = a.tiles_x * cdiv(h, 4); a2.total_tiles = a2.tiles_per_img * batch;
-        const int grid2 = a2.total_tiles < 256 ? a2.total_tiles : 256;
-        hipLaunchKernelGGL(stem_duo_kernel, dim3(grid2), dim3(512), SMEM2, st, a2);
-        TTUP_LAUNCH_CHECK();
-        return TTUP_OK;
-    }
+    // (a two-wave-group pipeline of the stem, round 5: 14 % slower -- csrc/experiments/rejected_kernels.hip.inc)
+    kernel_note(k4 ? "stem_kernel<3, true>" : frames_per_sample == 3 ? "stem_kernel<3, false>" : frames_per_sample == 1 ? "stem_kernel<1, false>" : "stem_kernel<0, false>");
     if (k4) hipLaunchKernelGGL((stem_kernel<3, true>), dim3(grid), dim3(512), SMEM, st, a);
     else if (frames_per_sample == 3) hipLaunchKernelGGL(stem_kernel<3>, dim3(grid), dim3(512), SMEM, st, a);
     else if (frames_per_sample == 1) hipLaunchKernelGGL(stem_kernel<1>, dim3(grid), dim3(512), SMEM, st, a);
@@ -1974,6 +1629,7 @@ int launch_bneck_trans(const PackedConv& p1, const PackedConv& p5, const PackedC
     if (int rc = ensure_max_lds((const void*)bneck_trans_kernel, SMEM)) return rc;
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;
     if (grid == 0) return TTUP_OK;
+    kernel_note("bneck_trans_kernel");
     hipLaunchKernelGGL(bneck_trans_kernel, dim3(grid), dim3(512), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -2093,7 +1749,7 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
 template <int R> struct BBRow { static constexpr int value = R; };
 // NWV (C=32 only): waves that share the conv's rows -- `wave` is the wave's index among them (rows wave, wave + NWV, ...).  af32: the C=32
-// conv's 18 weight fragments already in registers (bb32_duo_kernel keeps them there for the life of the workgroup).
+// conv's 18 weight fragments already in registers (a two-group variant kept them there for the life of the workgroup: csrc/experiments).
 template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0, int NWV = 8>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
@@ -2648,128 +2304,6 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ 32-channel BasicBlock, two wave groups in opposite phases (round 5)
-// bb_chain_kernel<32> runs its eight waves in lockstep: stage the tile, conv1, barrier, conv2 + stores -- both waves of a SIMD wait
-// for LDS, sit at the barriers and pack their outputs AT THE SAME TIME, and the matrix pipe is busy 47 % of the tile (phase stamps:
-// 2.4 k of 15 k cycles in commit + barrier + issue alone).  Here the workgroup is a two-stage pipeline over half-height tiles:
-//   group A (waves 0-3) : conv1 of tile t        -> bufB[t & 1];  then commits tile t+1 (prefetched) -> bufA[(t+1) % 3], requests tile t+2
-//   group B (waves 4-7) : conv2 of tile t-1      <- bufB[(t-1) & 1] + block input bufA[(t-1) % 3]     -> global stores (+ 1x1 follower)
-// with ONE workgroup barrier per tile.  Every SIMD holds one wave of each group, so one wave's LDS round trips, packing, stores and
-// barrier skew run under the other wave's MFMAs instead of beside its own copies of the same stalls.  Each wave keeps the 18 weight
-// fragments of ITS conv in registers for the life of the workgroup (no weights in LDS: three input buffers fit instead -- the block
-// input of tile t is still the residual of conv2 while tile t+1 is being committed).  Group A issues no stores and group B no loads of
-// its own, so neither group's vector-memory waits see the other's traffic.  Same arithmetic per output pixel as bb_chain_kernel<32>
-// (same k order, same roundings): bit-identical results.
-// MEASURED (round 5): 1.5 % slower than bb_chain_kernel<32> -- a phase still takes 7.8 k cycles for 3.55 k cycles of MFMAs per SIMD.  The
-// stalls it was built to overlap are not what limits these kernels: both waves of a SIMD share ONE vector issue port, every vector
-// instruction costs ~4 of its cycles and an MFMA holds it for 8 of its 16, and the two groups issue ~600 + ~500 vector instructions
-// around their 117 + 105 MFMAs per phase -- 6.1 k cycles of issue whichever way the waves are staggered.  What helps is fewer vector
-// instructions per MFMA (the Bottleneck tail's address diet: -8 %).  Selected by TTUP_BB32_DUO=1; the default is the one-phase kernel.
-template <int TH, int TW>
-__global__ __launch_bounds__(512) void bb32_duo_kernel(BBArgs a) {
-    constexpr int C = 32;
-    constexpr int R0H = TH + 4, R0W = TW + 4, R1H = TH + 2, R1W = TW + 2;
-    constexpr int SZ_A = R0H * R0W * C, SZ_B = R1H * R1W * C;
-    constexpr int IN_UNITS = R0H * R0W * (C / 8), IN_PT = (IN_UNITS + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* bufA = (bf16_t*)smem;                    // [3][SZ_A]
-    bf16_t* bufB = bufA + 3 * SZ_A;                  // [2][SZ_B]
-    float* s_misc = (float*)(bufB + 2 * SZ_B);       // floats [0,32) bias of conv 0, [32,64) bias of conv 1, [64,80) follower bias, then its 64 x 16-byte fragment
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
-    const int my_tiles = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (my_tiles <= 0) return;          // (workgroup-uniform; the launcher never starts more workgroups than tiles)
-    if (tid < C) { s_misc[tid] = a.bias[0][tid]; s_misc[C + tid] = a.bias[1][tid]; }
-    if (a.yf) {
-        if (tid < 16) s_misc[2 * C + tid] = a.bf[tid];
-        if (tid >= 64 && tid < 128) ((u32x4*)(s_misc + 2 * C + 16))[tid - 64] = ((const u32x4*)a.wf)[tid - 64];
-    }
-    // the wave's own conv: its 18 weight fragments stay in registers
-    bf16x8 afr[18];
-    {
-        const bf16_t* wsrc = grp ? a.w[1] : a.w[0];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) afr[k] = *(const bf16x8*)(wsrc + (k * 64 + lane) * 8);
-    }
-    u32x4 pin[IN_PT];
-    unsigned pin_ok = 0u;
-    auto tile_origin = [&](int it, int& b, int& oy0, int& ox0) {
-        const int tl = xcd_tile(blockIdx.x + it * gridDim.x, a.total_tiles);
-        b = tl / a.tiles_per_img;
-        const int tt = tl % a.tiles_per_img;
-        oy0 = (tt / a.tiles_x) * TH; ox0 = (tt % a.tiles_x) * TW;
-    };
-    auto issue_in = [&](int it) {          // group A: branch-free (the loads go out together); zeroed when the unit is written to LDS
-        int b, oy0, ox0;
-        tile_origin(it, b, oy0, ox0);
-#pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = gtid + k * 256;
-            const int c8 = u & 3, pix = u >> 2;
-            const int gy = oy0 - 2 + pix / R0W, gx = ox0 - 2 + pix % R0W;
-            const bool ok = u < IN_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pin[k] = *(const u32x4*)(ok ? a.x + ((size_t)(b * a.H + gy) * a.W + gx) * C + c8 * 8 : a.x);
-            pin_ok = ok ? pin_ok | (1u << k) : pin_ok & ~(1u << k);
-        }
-    };
-    auto commit_in = [&](bf16_t* dstbuf) {
-#pragma unroll
-        for (int k = 0; k < IN_PT; ++k) {
-            const int u = gtid + k * 256;
-            const bool okk = (pin_ok >> k) & 1u;
-            if (u < IN_UNITS) { const int c8 = u & 3, pix = u >> 2; *(u32x4*)(dstbuf + bb_off<C>(pix, pix % R0W, c8)) = u32x4{okk ? pin[k].x : 0u, okk ? pin[k].y : 0u, okk ? pin[k].z : 0u, okk ? pin[k].w : 0u}; }
-        }
-    };
-    prefetch_arrived(afr);          // complete on EVERY path into the tile loop: a fragment pending on one of them would be waited for inside
-                                    // the loop with s_waitcnt vmcnt(0), i.e. behind group A's freshly requested prefetch, per tile
-    if (grp == 0) {
-        issue_in(0);
-        commit_in(bufA);
-        if (my_tiles > 1) issue_in(1);
-    }
-    __syncthreads();
-    const float* bias0 = s_misc;
-    const float* bias1 = s_misc + C;
-    const bf16_t* wfl = (const bf16_t*)(s_misc + 2 * C + 16);
-    const float* bfl = s_misc + 2 * C;
-    for (int p = 0; p <= my_tiles; ++p) {
-        if (grp == 0) {
-            if (p < my_tiles) {
-                int b, oy0, ox0;
-                tile_origin(p, b, oy0, ox0);
-                bb_conv<C, R0W, 0, R1H, R1W, false, 1, 0, false, R1W, 0, 0, 4>(bufA + (p % 3) * SZ_A, bufB + (p & 1) * SZ_B, nullptr, nullptr, bias0, nullptr,
-                                                                                 oy0 - 1, ox0 - 1, a.H, a.W, b, gw, lane,
-                                                                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, bf16x8{}, afr);
-            }
-            if (p + 1 < my_tiles) {
-                commit_in(bufA + ((p + 1) % 3) * SZ_A);          // last read (as conv2's block input) two phases ago
-                if (p + 2 < my_tiles) issue_in(p + 2);
-            }
-        } else if (p >= 1) {
-            int b, oy0, ox0;
-            tile_origin(p - 1, b, oy0, ox0);
-            bb_conv<C, R1W, 0, TH, TW, true, R0W, 2, true, 1, 0, 0, 4>(bufB + ((p - 1) & 1) * SZ_B, nullptr, bufA + ((p - 1) % 3) * SZ_A, nullptr, bias1, a.y,
-                                                                         oy0, ox0, a.H, a.W, b, gw, lane, wfl, bfl, a.yf,
-                                                                         nullptr, nullptr, nullptr, nullptr, bf16x8{}, afr);
-        }
-        __syncthreads();
-    }
-}
-
-template <int TH, int TW>
-static int launch_bb32_duo(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
-    constexpr size_t SMEM = (size_t)(3 * (TH + 4) * (TW + 4) + 2 * (TH + 2) * (TW + 2)) * 32 * 2 + (2 * 32 + 16) * 4 + 1024;
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    if (int rc = ensure_max_lds((const void*)bb32_duo_kernel<TH, TW>, SMEM)) return rc;
-    BBArgs k = a;
-    k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
-    const int grid = k.total_tiles < 256 ? k.total_tiles : 256;
-    if (grid == 0) return TTUP_OK;
-    hipLaunchKernelGGL((bb32_duo_kernel<TH, TW>), dim3(grid), dim3(512), SMEM, st, k);
-    TTUP_LAUNCH_CHECK();
-    return TTUP_OK;
-}
-
 // One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
 // Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
 template <int C, int TH, int TW, int MODE>
@@ -2972,6 +2506,7 @@ static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
+    kernel_note("bb_chain2_kernel<%d, %d, %d, %d>", C, TH, TW, MODE);
     hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW, MODE>), dim3(k.tiles_x, cdiv(h, TH), batch), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -2994,6 +2529,7 @@ static int launch_bb_t(const BBArgs& a, int batch, int h, int w, hipStream_t st)
     const int per_cu = (int)((160 * 1024) / SMEM) > 2 ? 2 : ((int)((160 * 1024) / SMEM) < 1 ? 1 : (int)((160 * 1024) / SMEM));
     const int grid = (C == 16 || k.total_tiles < 256 * per_cu) ? k.total_tiles : 256 * per_cu;      // C=16: one tile per workgroup
     if (grid == 0) return TTUP_OK;
+    kernel_note("bb_chain_kernel<%d, %d, %d, %d>", C, NB, TH, TW);
     hipLaunchKernelGGL((bb_chain_kernel<C, NB, TH, TW>), dim3(grid), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -3064,10 +2600,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
     }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) {
-        // TTUP_BB32_DUO=1: the two-wave-group pipeline (bb32_duo_kernel), bit-identical and 1.5 % SLOWER than the one-phase kernel (round 5,
-        // same box: 0.571-0.575 against 0.563-0.569 ms for the six launches) -- kept as the measured experiment it is
-        static const bool duo = getenv("TTUP_BB32_DUO") != nullptr;
-        if (duo) return launch_bb32_duo<11, 30>(a, batch, h, w, st);            // two wave groups in opposite phases: conv regions 13x32 / 11x30
+        // (a two-wave-group pipeline of this block, round 5: bit-identical and 1.5 % slower -- csrc/experiments/rejected_kernels.hip.inc)
         return launch_bb_t<32, 1, 22, 30>(a, batch, h, w, st);                   // conv regions 24x32 / 22x30
     }
     set_error("bb_chain: C=%d with %d convs unsupported", c, n_convs);
@@ -3206,6 +2739,7 @@ static int launch_mfma(const PackedConv& p, const ConvLaunch& l, hipStream_t st)
     const int grid = a.total_tiles < 256 * per_cu ? a.total_tiles : 256 * per_cu;
     if (int rc = ensure_max_lds((const void*)conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>, SMEM)) return rc;
     if (grid == 0) return TTUP_OK;
+    kernel_note("conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", CK, COUT, KS, S, TH, TW, NW, F11 ? "true" : "false");
     hipLaunchKernelGGL((conv_mfma_kernel<CK, COUT, KS, S, TH, TW, NW, F11>), dim3(grid), dim3(NW * 64), SMEM, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -3252,6 +2786,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         a.total = (long long)l.batch * a.OH * a.OW * a.cout;
         const int threads = 256;
         const long long blocks = (a.total + threads - 1) / threads;
+        kernel_note("conv_direct_f32_kernel");
         hipLaunchKernelGGL(conv_direct_f32_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, a);
         TTUP_LAUNCH_CHECK();
         return TTUP_OK;
@@ -3277,6 +2812,7 @@ int launch_conv(const PackedConv& p, const ConvLaunch& l, int dtype, hipStream_t
         if (int rc = ensure_max_lds((const void*)conv_s2_pair_kernel, SMEM)) return rc;
         const int grid = a.total_tiles < 256 * 4 ? a.total_tiles : 256 * 4;
         if (grid == 0) return TTUP_OK;
+        kernel_note("conv_s2_pair_kernel");
         hipLaunchKernelGGL(conv_s2_pair_kernel, dim3(grid), dim3(512), SMEM, st, a);
         TTUP_LAUNCH_CHECK();
         return TTUP_OK;
@@ -3364,6 +2900,7 @@ int launch_upsum(const void* base, const void* const* terms, const int* shifts, 
     long long blocks = (a.total + 255) / 256;
     if (n_active && blocks > 8192) blocks = 8192;             // grid-stride: the launch is sized for the largest batch
     TTUP_REQUIRE(!n_active || dtype == TTUP_DTYPE_F32, TTUP_EINVAL, "upsum: a device-side batch is an fp32-path feature");
+    kernel_note(dtype == TTUP_DTYPE_F32 ? "upsum_kernel<float>" : c % 8 == 0 ? "upsum_bf16x8_kernel" : "upsum_kernel<bf16>");
     if (dtype == TTUP_DTYPE_F32) hipLaunchKernelGGL(upsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (c % 8 == 0) {
         a.total /= 8;

@@ -867,19 +867,32 @@ extern "C" int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) TTUP_HIP_CHECK(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
+    std::vector<std::string> exact(n);          // the device kernel each op launched (kernel_note of its launcher), as rocprofv3 names it
     int rc = TTUP_OK;
     net->use_lane(0);
     for (int r = -1; r < reps && rc == TTUP_OK; ++r) {          // pass -1 = warm-up
         (void)hipEventRecord(ev[0], st);
         for (int i = 0; i < n && rc == TTUP_OK; ++i) {
             const Op& op = net->ops[i];
+            kernel_note_reset();
             rc = (op.kind == Op::UPSUM_HEAD || op.head) ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st);
             (void)hipEventRecord(ev[i + 1], st);
+            if (r < 0) exact[i] = kernel_noted();
         }
         (void)hipEventSynchronize(ev[n]);
         if (r >= 0) for (int i = 0; i < n; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); acc[i] += ms; }
     }
-    for (int i = 0; i < n; ++i) { ms_out[i] = (float)(acc[i] / reps); op_info(net, i, info_out + 8 * i, names_out ? names_out + 64 * i : nullptr); }
+    for (int i = 0; i < n; ++i) {
+        ms_out[i] = (float)(acc[i] / reps);
+        char nm[64];
+        op_info(net, i, info_out + 8 * i, nm);
+        if (names_out) {
+            // "<device kernel template-id><+epilogue variant>": the op-level label keeps only its '+...' suffix when the launcher left a note
+            std::string full = exact[i].empty() ? std::string(nm) : exact[i] + (strchr(nm, '+') ? strchr(nm, '+') : "");
+            memset(names_out + 64 * i, 0, 64);
+            memcpy(names_out + 64 * i, full.c_str(), full.size() < 63 ? full.size() : 63);
+        }
+    }
     for (auto& e : ev) (void)hipEventDestroy(e);
     *n_ops_out = n;
     return rc;
