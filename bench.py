@@ -289,7 +289,14 @@ def _cpu_child(style, n, threads):
         aff = len(os.sched_getaffinity(0))
     except AttributeError:
         aff = os.cpu_count()
-    print(json.dumps({'seconds': dt, 'triples': n, 'threads': torch.get_num_threads(), 'warmup_seconds': round(warm, 3), 'per_triple': per,
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    try:
+        thp = open('/sys/kernel/mm/transparent_hugepage/enabled').read().strip()
+    except OSError:
+        thp = 'unknown'
+    print(json.dumps({'rusage': {'user_s': round(ru.ru_utime, 1), 'sys_s': round(ru.ru_stime, 1), 'minor_faults': ru.ru_minflt}, 'thp': thp,
+                      'glibc_tunables': os.environ.get('GLIBC_TUNABLES'), 'seconds': dt, 'triples': n, 'threads': torch.get_num_threads(), 'warmup_seconds': round(warm, 3), 'per_triple': per,
                       'parts': {k: round(v, 3) for k, v in parts.items()}, 'torch': torch.__version__,
                       'mkldnn': bool(torch.backends.mkldnn.is_available() and torch.backends.mkldnn.enabled), 'affinity': aff,
                       'omp': {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OMP_PROC_BIND', 'OMP_PLACES', 'GOMP_CPU_AFFINITY', 'KMP_AFFINITY') if os.environ.get(k)}}), flush=True)
@@ -305,73 +312,83 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline():
-    """The CPU oracle (torch fp32, kind "port") on a bounded sample of the same workload, in the reference's two calling styles:
-    (a) batch 1 per triple with the table-variant fit, like the hub surface (interface.py:102-119), + one 120-point trajectory through
-    the uplift net; (b) micro-batch 4 with the ball-variant fit, like the evaluation path (inference/utils.py:51-59).  12 triples each,
-    in this process on its host-thread pool (8 threads: `cores`).
+CPU_POLICY = {'OMP_PROC_BIND': 'close', 'OMP_PLACES': 'cores', 'GLIBC_TUNABLES': 'glibc.malloc.hugetlb=1'}
 
-    More threads do not help this workload (BASELINE.md 4 asks for all threads): `thread_sweep` times ONE triple of
-    style (a) on all hardware threads, on the physical cores and on 32 threads, each in a FRESH child process (CPU only, its own
-    OpenMP pool: widening this process's pool to 256 threads and back left it six times slower), cut off at 20 s per triple --
-    torch's CPU convolutions at batch 1 take > 60 s per triple on 256 threads and 7 s on 128.  If a swept configuration beats the
-    8-thread rate, the line says so (`faster_config`)."""
-    from oracle import glue_ref, refine_ref, uplift_ref, wasb_ref
-    from upliftingtabletennis_amd import synth, weights
-    n = int(os.environ.get('TTUP_CPU_BASELINE_TRIPLES', '12'))
-    frames, _ = synth.synth_frames(n + 2, H_SRC, W_SRC, seed=0)
-    sd = weights.random_wasb_state_dict(0, planted=True)
-    usd = weights.random_uplift_state_dict(0, 'large')
+
+def _run_cpu_child(style, n, threads, env_add, timeout):
+    """`bench.py --cpu-child` in a fresh CPU-only process; its JSON line, or None when it did not finish inside `timeout` seconds."""
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), **env_add)
+    for k in ('TTUP_LIB', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', style, str(n), str(threads)], env=env, cwd=ROOT,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return None
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith('{'):
+            return json.loads(ln)
+    return None
+
+
+def cpu_baseline():
+    """The CPU oracle (torch fp32, kind "port": oracle/*_ref.py, pinned to the reference by the goldens) on a bounded sample of the same
+    workload, in the reference's two calling styles -- (a) batch 1 per triple with the table-variant fit, like the hub surface
+    (interface.py:102-119), + one 120-point trajectory through the uplift net; (b) micro-batches of 4 with the ball-variant fit, like the
+    evaluation path (inference/utils.py:51-59).
+
+    Every timing is a FRESH CPU-only child process (`--cpu-child`: its own OpenMP pool, OMP_NUM_THREADS set, one full-size warm-up
+    triple, no GPU) and the whole leg runs BEFORE this process touches the GPU.  A sweep over 8 / 16 / 32 / 64 / 128 threads (2 timed
+    triples each, cut off at 15 s) picks the thread count; the reported value is 8 triples at that count, `cores` = its threads.
+    Environment of the children: OMP_PROC_BIND=close, OMP_PLACES=cores, GLIBC_TUNABLES=glibc.malloc.hugetlb=1.
+
+    Why the tunable, and why rounds 3-4 (1.94 frames/s) and round 5 (0.37) disagreed on unchanged code: the eager fp32 graph allocates
+    a fresh 100-900 MB tensor per layer, glibc mmap()s each, and with the host's transparent-hugepage mode at `madvise` (the round-5/6
+    boxes) every one is faulted in as 4-KB pages -- 12.6 M page faults for four triples, a third of the CPU time in the kernel, and
+    SLOWER with more threads (they queue on the process's memory map).  With malloc asking for huge pages the same run takes 0.21 M
+    faults and 1.15 instead of 1.8-2.1 s per triple.  `plain` in the line is the best thread count WITHOUT the tunable.  The
+    rounds-3/4 figure (0.52 s per triple) was not reproducible on any thread count or policy on the round-6 boxes; those rounds did not
+    record the host's THP mode or CPU model (NOTES.md 15)."""
+    model = _cpu_model()
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    model = _cpu_model()
-    t0 = time.time()
-    for i in range(n):          # batch 1 per triple, like interface.py:102-119
-        x = glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET))[None]
-        heat = wasb_ref.wasb_forward(x, sd).numpy()
-        refine_ref.extract_position_table(heat, 1920, 1080)
-    ball, table, mask, times = synth.synth_trajectories(1, TRAJ_LEN, seed=0, pad=1)
-    rot, p3 = uplift_ref.uplift_forward(ball, table, mask, times, usd)
-    uplift_ref.transform_rotationaxes(rot, p3)
-    dt = time.time() - t0
-    base = {'value': round(n / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
-            'sample': '%d triples 1280x720, batch 1 (resize+normalise, CNN fp32, table-variant refine) + 1 trajectory of %d points; %.1f s on %d threads'
-                      % (n, TRAJ_LEN, dt, torch.get_num_threads())}
-    t0 = time.time()
-    x = np.stack([glue_ref.triple_to_tensor(frames[i], frames[i + 1], frames[i + 2], (W_NET, H_NET)) for i in range(n)])
-    for b0 in range(0, n, 4):
-        heat = wasb_ref.wasb_forward(x[b0:b0 + 4], sd).numpy()          # micro-batches of 4, inference/utils.py:51-57
-        refine_ref.extract_position_ball(heat, 1920, 1080)               # ball-variant fit, :59
-    dt4 = time.time() - t0
-    b4 = {'value': round(n / dt4, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
-          'sample': '%d triples 1280x720 in micro-batches of 4 (resize+normalise, CNN fp32, ball-variant refine), inference/utils.py:51-59; %.1f s on %d threads'
-                    % (n, dt4, torch.get_num_threads())}
-    if os.environ.get('TTUP_NO_THREAD_SWEEP') != '1':
-        def child(threads, timeout):
-            env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-            env.pop('TTUP_LIB', None)
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', 'b1', '1', str(threads)], env=env, cwd=ROOT,
-                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout)
-                for ln in r.stdout.splitlines():
-                    if ln.startswith('{'):
-                        return json.loads(ln)
-            except subprocess.TimeoutExpired:
-                return None
-            return None
-        sweep, best = [], None
-        for t in sorted({avail, max(1, avail // 2), min(32, avail)} - {torch.get_num_threads()}, reverse=True):
-            res = child(t, 30)
-            sweep.append({'threads': t, 'seconds_per_triple': round(res['seconds'], 2) if res else '> 20 (cut off)'})
-            if res and (best is None or res['seconds'] < best[1]):
-                best = (t, res['seconds'])
-        base['thread_sweep'] = sweep
-        base['thread_sweep_note'] = ('one triple of the batch-1 style per thread count, each in a fresh CPU-only process; the sample above ran at %.2f s per triple on %d threads'
-                                     % (dt / n, torch.get_num_threads()))
-        if best and best[1] < dt / n:
-            base['faster_config'] = {'threads': best[0], 'frames_per_s': round(1.0 / best[1], 4)}
+    sweep, best = [], None
+    for t in (8, 16, 32, 64, 128):
+        if t > avail:
+            continue
+        res = _run_cpu_child('b1', 2, t, CPU_POLICY, 15)
+        if res is None:
+            sweep.append({'threads': t, 'seconds_per_triple': '> %.1f (cut off at 15 s for warm-up + 2 triples)' % (15 / 3.0)})
+            continue
+        spt = res['seconds'] / res['triples']          # (includes the one uplift trajectory: 0.02 s)
+        sweep.append({'threads': t, 'seconds_per_triple': round(spt, 3), 'user_s': res['rusage']['user_s'], 'sys_s': res['rusage']['sys_s'],
+                      'minor_faults': res['rusage']['minor_faults']})
+        if best is None or spt < best[1]:
+            best = (t, spt)
+    if best is None:
+        return {'value': None, 'unit': 'frames/s', 'cores': 0, 'kind': 'port', 'sample': 'no CPU child finished', 'thread_sweep': sweep}, None
+    t = best[0]
+    n = int(os.environ.get('TTUP_CPU_BASELINE_TRIPLES', '8'))
+    res = _run_cpu_child('b1', n, t, CPU_POLICY, 90) or {}
+    plain = _run_cpu_child('b1', 2, t, {'OMP_PROC_BIND': 'close', 'OMP_PLACES': 'cores'}, 30)
+    res4 = _run_cpu_child('b4', n, t, CPU_POLICY, 90)
+    dt = res.get('seconds')
+    base = {'value': round(n / dt, 4) if dt else None, 'unit': 'frames/s', 'cores': t, 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
+            'sample': '%d triples 1280x720, batch 1 (resize+normalise, CNN fp32, table-variant refine) + 1 trajectory of %d points, after one full-size '
+                      'warm-up triple, in a fresh CPU-only process on %d OpenMP threads: %s s' % (n, TRAJ_LEN, t, ('%.1f' % dt) if dt else 'n/a'),
+            'per_triple_s': res.get('per_triple'), 'parts_s': res.get('parts'), 'rusage': res.get('rusage'),
+            'env': dict(CPU_POLICY, OMP_NUM_THREADS=str(t)), 'torch': res.get('torch'), 'mkldnn': res.get('mkldnn'), 'thp': res.get('thp'),
+            'thread_sweep': sweep,
+            'thread_sweep_note': 'fresh CPU-only process per thread count: one full-size warm-up triple, then 2 timed triples; run before this process touched the GPU',
+            'plain': None if not plain else {'frames_per_s': round(plain['triples'] / plain['seconds'], 4), 'minor_faults': plain['rusage']['minor_faults'],
+                                            'note': 'same thread count and binding without GLIBC_TUNABLES=glibc.malloc.hugetlb=1 (2 triples)'}}
+    b4 = None
+    if res4:
+        b4 = {'value': round(res4['triples'] / res4['seconds'], 4), 'unit': 'frames/s', 'cores': t, 'kind': 'port', 'cpu_model': model, 'host_threads': avail,
+              'sample': '%d triples 1280x720 in micro-batches of 4 (CNN fp32, ball-variant refine; resize+normalise outside the timing), inference/utils.py:51-59, '
+                        'after one warm-up micro-batch, fresh CPU-only process on %d OpenMP threads: %.1f s' % (res4['triples'], t, res4['seconds'])}
     return base, b4
 
 
@@ -709,6 +726,8 @@ def main():
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
     cores = pin_rank_to_cores(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))          # before the first GPU call
+    # the CPU baseline FIRST: fresh CPU-only children, nothing of this process on the GPU or the host cores yet
+    cpu_lines = cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (there is no CPU fallback); the CPU oracle is only the baseline leg')
     # TTUP_BENCH_SHARE_GPU=1 + TTUP_DIST_BACKEND=gloo: dry run of the multi-rank flow on a box with fewer GPUs than ranks
@@ -904,8 +923,8 @@ def main():
             del pipe
             torch.cuda.empty_cache()
             line.update(extras(device))
-        if not a.no_cpu_baseline and world == 1:
-            line['cpu_baseline'], line['cpu_baseline_b4'] = cpu_baseline()
+        if cpu_lines is not None:
+            line['cpu_baseline'], line['cpu_baseline_b4'] = cpu_lines
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -166,6 +166,12 @@ int ttup_slice_columns(const float* src_dev, long long rows, int width, int x0, 
  * the near-ties' -- holds the fp32 path's values and the sub-pixel fit sees what the reference's fit sees (one 168x168 fp32
  * pass per heatmap: a parity / audit mode, off by default) */
 int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on);
+/* audit crops (every > 0): of the frames f of the following forwards with (f + phase) % every == 0, ONE single-candidate heatmap
+ * (channel (f / every) % channels) gets an fp32 crop although its index is already certain; like every crop it reports
+ * |bf16 - fp32| at its candidate into the running maximum that ttup_wasb_certify_info returns.  This is the candidate-level audit
+ * extended to heatmaps WITHOUT near-ties (reference: helper_balldetection.py:50 takes the argmax of an fp32 heatmap; the bound on
+ * |bf16 - fp32| is what lets the bf16 path return the same index).  every = 0 switches it off (default). */
+int ttup_wasb_certify_audit_crops(ttup_wasb* net, int every, int phase);
 /* info_dev[0] = crops the LAST forward asked for (may exceed the budget it had); info_dev[1] = the bits of a float: the largest
  * |bf16 - fp32| seen so far at any candidate of any call (stats[6]); both copied in stream order, no synchronisation */
 int ttup_wasb_certify_info(ttup_wasb* net, int* info_dev, void* stream);

@@ -147,7 +147,7 @@ def test_one_out_of_bound_frame_between_audits_missed_is_stated_caught_is_recert
     def run(pick):
         # one audited triple per 12-triple clip at both rates, so that the pick is the only thing that differs between (a) and (b)
         worker = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=12, audit_every_fast=12,
-                                       audit_settle_clips=2, audit_seed=1)
+                                       audit_settle_clips=2, audit_seed=1, audit_crops_every=0)
         worker.process_clip(fd, table_px, 60.0)
         eps0 = worker.certify_eps
         errs = np.array([float(worker.net.heatmap_error(fm, t).item()) for t in range(12)])
@@ -160,7 +160,7 @@ def test_one_out_of_bound_frame_between_audits_missed_is_stated_caught_is_recert
     # (a) the audit looks elsewhere
     worker, eps0, errs, out, idx = run(0)
     a = worker.audit
-    assert a['frames_seen'] >= 24 and 0 < a['audited_share'] <= 1 and a['audit_every_now'] == 12          # (36 when a widening past the guard factor re-ran the clip)
+    assert a['frames_seen'] == 24 and 0 < a['audited_share'] <= 1 and a['audit_every_now'] == 12          # (a clip re-run after a widening is counted once)
     inbound = errs <= worker.certify_eps
     assert torch.equal(idx.cpu()[torch.from_numpy(inbound)], ref_idx.cpu()[torch.from_numpy(inbound)]), 'the bound holds on these triples: their indices must be the fp32 path\'s'
     if worker.certify_eps > eps0:
@@ -182,8 +182,36 @@ def test_one_out_of_bound_frame_between_audits_missed_is_stated_caught_is_recert
     assert inbound.all(), 'the neighbours of the audited triple carry the same planted frame: 1.5 x its error should cover them (%s vs eps %.3g)' % (errs[[5, 6, 7]], worker.certify_eps)
     print('(b) audit on the planted frame: eps %.4g -> %.4g, widened %d (sources %s), %d heatmaps / %d clips re-certified'
           % (eps0, worker.certify_eps, a['widened'], a['widen_sources'], a['recertified_heatmaps'], a['recertified_clips']))
+    # (c) audit crops (round 6): the strip audit looks elsewhere, but one single-candidate heatmap per 4 triples gets an fp32 crop that
+    # reports |bf16 - fp32| at ITS WINNER -- the pixel the detection rests on, not the frame's worst pixel (that is the strip audit's
+    # measure, `errs`).  For every phase: the largest error seen afterwards is at least the winner error of every picked triple, and a
+    # picked triple whose winner error breaks the old bound widens eps.  The chance that a given frame is looked at this way is (triples
+    # that contain it) / audit_crops_every per clip -- 3/4 here, 3/16 in production, on top of the strip audit's 1/64 ... 1/256.
+    twin = wasb.WASBNet(sd, resolution=(W, H), max_batch=1, dtype='f32')
+    xs = wasb.preprocess_triples(fm, (W, H))
+    hf = torch.cat([twin.forward(xs[k:k + 1], want_heatmap=True, want_peaks=True)[0] for k in range(12)])
+    n_widened = 0
+    for phase in range(4):
+        w3 = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=12, audit_every_fast=12,
+                                   audit_settle_clips=2, audit_seed=1, audit_crops_every=4)
+        w3.process_clip(fd, table_px, 60.0)
+        e0, seen0 = w3.certify_eps, w3.audit['max_err_seen']
+        hb, ib, _ = w3.net.forward_frames(fm, want_heatmap=True)
+        werr = (hb.reshape(12, -1).gather(1, ib.reshape(12, 1)) - hf.reshape(12, -1).gather(1, ib.reshape(12, 1))).abs().reshape(12).cpu().numpy()
+        w3._rng = _FixedPick(0)                                # strip audit on triple 0
+        w3._rng_crops = _FixedPick(phase)
+        w3.process_clip(fm, table_px, 60.0)
+        a3 = w3.audit
+        picked = [t for t in range(12) if (t + phase) % 4 == 0]
+        assert a3['audit_crop_frames'] == 2 * 3 and a3['audited_share'] > a3['strip_audited_share'], a3
+        assert a3['max_err_seen'] >= max(werr[picked].max(), seen0) * (1 - 1e-5), (phase, a3['max_err_seen'], werr[picked], seen0)
+        if werr[picked].max() * 1.5 > e0 * (1 + 1e-6):
+            assert w3.certify_eps > e0 and a3['widen_sources']['candidates'] >= 1, (phase, a3)
+            n_widened += 1
+        print('(c) phase %d: audit crops on triples %s, winner errors %s, eps %.4g -> %.4g' % (phase, picked, ['%.3g' % v for v in werr[picked]], e0, w3.certify_eps))
+    print('(c) %d of 4 phases widened eps from an audit crop' % n_widened)
     # adaptive rate: fast until eps has stood for audit_settle_clips clips in a row, steady afterwards, fast again after a widening
-    w2 = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=48, audit_every_fast=6, audit_settle_clips=2)
+    w2 = pipeline.StreamWorker('cuda:0', sd, usd, net_wh=(W, H), max_triples=12, traj_len=32, seq_len=50, audit_every=48, audit_every_fast=6, audit_settle_clips=2, audit_crops_every=0)
     assert w2.audit_rate() == 6
     w2.process_clip(fd, table_px, 60.0)                    # calibration (8 frames) + 12 triples at one audit per 6
     assert w2.audit['audited_frames'] == 8 + 2 and w2.audit['frames_seen'] == 12
@@ -199,6 +227,34 @@ def test_one_out_of_bound_frame_between_audits_missed_is_stated_caught_is_recert
     assert abs(w2.audit['audited_share'] - w2.audit['audited_frames'] / w2.audit['frames_seen']) < 1e-12
     w2._quiet_clips = 0
     assert w2.audit_rate() == 6
+
+
+def test_audit_crops_give_single_candidate_heatmaps_an_fp32_check():
+    """`certify_audit_crops(every, phase)` on content whose heatmaps have ONE candidate each (planted-peak weights: nothing would get an
+    fp32 crop): exactly the frames with (f + phase) % every == 0 get one, the handle's running |bf16 - fp32| maximum at candidates
+    becomes non-zero -- the error at the winners -- and NOTHING else changes: status, indices and 3x3 windows are the bf16 path's
+    whatever the phase (an audit measures; it does not decide what a frame returns)."""
+    sd = weights.random_wasb_state_dict(21, planted=True)
+    frames, _ = synth.synth_frames(14, H, W, seed=21)
+    fr = torch.from_numpy(frames).cuda()
+    net = wasb.WASBNet(sd, resolution=(W, H), max_batch=12, dtype='bf16')
+    net.calibrate(fr, n=4)
+    _, idx0, win0 = net.forward_frames(fr)
+    st0 = net.certify_status(12).cpu().numpy() & 3
+    s0 = net.certify_stats(reset=True)
+    if not (st0 == 0).all():
+        pytest.skip('premise: every heatmap of the planted-peak clip has a single candidate (status %s)' % st0)
+    assert s0['max_candidate_err'] == 0.0 or s0['crops'] == 0
+    for phase in (1, 2):
+        net.certify_audit_crops(4, phase)
+        _, idx1, win1 = net.forward_frames(fr)
+        st1 = net.certify_status(12).cpu().numpy() & 3
+        s1 = net.certify_stats(reset=True)
+        assert (st1 == 0).all() and torch.equal(idx0, idx1) and torch.equal(win0, win1), (phase, st1)
+        assert s1['exact_singles'] == 3 and s1['crops'] == 3 and s1['max_candidate_err'] > 0, s1
+    net.certify_audit_crops(0)
+    _, idx2, _ = net.forward_frames(fr)
+    assert (net.certify_status(12).cpu().numpy() & 3 == 0).all() and torch.equal(idx0, idx2)
 
 
 def test_pipelined_repair_uses_the_tickets_own_status():

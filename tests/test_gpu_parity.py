@@ -1037,3 +1037,33 @@ def test_rccl_two_rank_gather_on_device_buffers():
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                           '--master-port', '29547', script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and 'rccl2 ok' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_bench_two_rank_flow_over_rccl():
+    """The BENCH flow itself with two ranks on two GPUs over RCCL: `python bench.py --gpus 2 --steps 2` spawns its
+    ranks before touching the GPU, every rank runs the full detect -> uplift step on its own device, rank 0 prints ONE line whose
+    collective really was RCCL with two ranks, which says whether RCCL's streams moved the worker's stream -> queue mapping, and whose
+    per-rank step times are within 5 % of each other and of a single-GPU run on the same box (weak scaling: per-GPU work is fixed).
+    Needs two devices: skipped on the 1-GPU test box."""
+    import json, subprocess, sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs; the gloo dry runs (test_bench_two_rank_flow_on_one_gpu, test_bench_eight_rank_dry_run_on_one_gpu) cover the flow on one')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TTUP_BENCH_SHARE_GPU', 'TTUP_DIST_BACKEND')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
+
+    def run(gpus):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup', '1', '--no-roofline',
+                              '--no-cpu-baseline', '--no-extras'], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+    two = run(2)
+    assert two['n_gpus'] == 2 and two['rccl_ranks'] == 2 and two['scaling'] == 'weak', {k: two.get(k) for k in ('n_gpus', 'rccl_ranks', 'scaling')}
+    assert 'queue_mapping_changed' in two, sorted(two)          # reported either way; True is a finding, not a failure
+    pr = two['per_rank']
+    assert pr['ms_per_step_max'] <= 1.05 * pr['ms_per_step_min'], pr
+    one = run(1)
+    assert abs(two['ms_per_step'] - one['ms_per_step']) <= 0.05 * one['ms_per_step'], (two['ms_per_step'], one['ms_per_step'])
+    assert two['value'] >= 1.9 * one['value'], (two['value'], one['value'])

@@ -728,10 +728,55 @@ def gen_calib():
     np.savez_compressed(os.path.join(OUT, 'calib.npz'), **out)
 
 
+def _calib64_one(job):
+    import inference.utils as iu
+    ci, kp = job
+    M_int, M_ext = iu.calibrate_camera(kp)
+    return ci, np.asarray(M_int), np.asarray(M_ext)
+
+
+def gen_calib64():
+    """f4, the distribution: the reference's `calibrate_camera` on 64 seeded synthetic cameras -- poses and focal
+    lengths from the ranges the reference trains its uplift net on (uplifting/data.py:60-64, via upliftingtabletennis_amd.synth._random_camera),
+    pixel noise sigma 0.3 / 0.6 / 1.0 px, every fourth camera with one gross outlier, every fifth with one invisible keypoint.  ~30 s of
+    SciPy BFGS per camera: eight worker processes."""
+    if 'mujoco' not in sys.modules:
+        install_mujoco_standin({})
+    import multiprocessing as mp
+    import inference.utils as iu          # noqa: F401  (imported before the fork)
+    from uplifting.helper import table_points, world2cam, cam2img
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from upliftingtabletennis_amd import synth
+    rng = np.random.default_rng(64)
+    jobs, out = [], {}
+    for ci in range(64):
+        R, c, f = synth._random_camera(rng)
+        Mext = np.eye(4); Mext[:3, :3] = R; Mext[:3, 3] = -R @ c
+        Mint = np.array([[f, 0, 960.0, 0], [0, f * rng.uniform(0.98, 1.02), 540.0, 0], [0, 0, 1, 0.0]])
+        uv = cam2img(world2cam(table_points.astype(np.float64), Mext), Mint)
+        kp = np.concatenate([uv + rng.normal(0, (0.3, 0.6, 1.0)[ci % 3], uv.shape), np.ones((13, 1))], axis=1)
+        if ci % 4 == 3:
+            kp[int(rng.integers(0, 9)), :2] += rng.choice([-1, 1], 2) * rng.uniform(20, 60, 2)          # one gross outlier (not on keys 10 / 11: fixed in every subset)
+        if ci % 5 == 4:
+            kp[int(rng.integers(0, 9)), 2] = 0
+        out['calib64/%d/keypoints' % ci] = kp
+        out['calib64/%d/Mint_true' % ci] = Mint
+        out['calib64/%d/Mext_true' % ci] = Mext
+        jobs.append((ci, kp))
+    t0 = time.time()
+    with mp.get_context('fork').Pool(8) as pool:
+        for ci, mi, me in pool.imap_unordered(_calib64_one, jobs):
+            out['calib64/%d/Mint' % ci] = mi
+            out['calib64/%d/Mext' % ci] = me
+            print('calib64 camera %d done (%.0f s)' % (ci, time.time() - t0), flush=True)
+    out['n'] = np.array([64])
+    np.savez_compressed(os.path.join(OUT, 'calib64.npz'), **out)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
     which = sys.argv[1:] or ['wasb', 'refine', 'uplift', 'glue', 'full', 'table', 'trajgen', 'calib', 'e2e', 'hard', 'hard_table']
     for w_ in which:
-        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'e2e': gen_e2e, 'hard': gen_hard, 'hard_table': gen_hard_table}[w_]()
+        {'wasb': gen_wasb, 'refine': gen_refine, 'uplift': gen_uplift, 'glue': gen_glue, 'full': gen_fullsize, 'table': gen_table, 'trajgen': gen_trajgen, 'calib': gen_calib, 'calib64': gen_calib64, 'e2e': gen_e2e, 'hard': gen_hard, 'hard_table': gen_hard_table}[w_]()

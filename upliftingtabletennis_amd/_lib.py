@@ -38,6 +38,7 @@ SIGNATURES = {
     'ttup_slice_columns': (_i, [_vp, _c.c_longlong, _i, _i, _i, _vp, _vp]),
     'ttup_wasb_certify_budget': (_i, [_vp, _i]),
     'ttup_wasb_certify_exact_windows': (_i, [_vp, _i]),
+    'ttup_wasb_certify_audit_crops': (_i, [_vp, _i, _i]),
     'ttup_wasb_certify_info': (_i, [_vp, _vp, _vp]),
     'ttup_wasb_certify_status': (_i, [_vp, _i, _vp, _vp]),
     'ttup_wasb_certify_flags': (_i, [_vp, _i, _vp, _vp]),

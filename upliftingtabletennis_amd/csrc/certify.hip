@@ -61,6 +61,7 @@ struct PlanArgs {
     int* cand_idx; int* cand_cnt; int* cand_crop; int* crop_rec; int* n_crops; int* status; unsigned long long* stats; float* cand_bf;
     int K, maxc, max_crops, H, W, Hc, Wc, R, frame0, exact;
     int C, maxf;          // heatmap channels per frame (1 ball, 13 table keypoints) and crops a frame may use in all
+    int audit_mod, audit_phase;          // audit crops (ttup_wasb_certify_audit_crops): 0 = off
     const int* guard_cnt;
     float* margin;
 };
@@ -80,6 +81,7 @@ __device__ __forceinline__ void core_range(int o, int c, int full, int R, int& l
 constexpr int CERT_MAX_K = 512;
 constexpr int CERT_MAX_FRAME_CROPS = 16;
 constexpr int CERT_PENDING = 8;          // provisional status of a heatmap whose crops wait for their ids on the shared list
+constexpr int CERT_AUDIT_ONLY = 16;      // its crop only MEASURES (audit crop of a single-candidate heatmap): index and window stay the bf16 path's
 __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     // The whole wave works on the assignment (round 4, second half): in its first form lane 0 walked the sorted list in GLOBAL memory --
     // a dependent load per candidate, a read-modify-write per candidate for the final crop ids: 19 us on average and up to 63 us per
@@ -103,8 +105,12 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         const int cnt = a.cand_cnt[map];
         const int gbit = a.guard_cnt[map] > 0 ? 4 : 0;          // status bit 2: the guard band is not empty
         if (lane == 0) { atomicAdd(&a.stats[0], 1ull); a.margin[map] = __int_as_float(0x7f800000); }
-        // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too)
-        if (cnt <= 0 || (cnt == 1 && !a.exact)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }
+        // exact-window mode: a single candidate still gets its fp32 crop (the index is certain, the 3x3 window becomes fp32 too).
+        // Audit crops: so does the single candidate of ONE channel of every audit_mod-th frame -- its crop reports |bf16 - fp32| at the
+        // winner like every crop does (cand_bf / stats[6]), which is how a frame whose error exceeds eps WITHOUT producing a near-tie
+        // gets noticed between two strip audits
+        const bool audit_pick = a.audit_mod > 0 && cnt == 1 && (frame + a.audit_phase) % a.audit_mod == 0 && ch == (frame / a.audit_mod) % a.C;
+        if (cnt <= 0 || (cnt == 1 && !a.exact && !audit_pick)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }
         if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
         int* ci = a.cand_idx + (size_t)map * a.K;
         float* cb = a.cand_bf + (size_t)map * a.K;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         for (int m = 0; m < PER; ++m)
             if (lane + 64 * m < cnt) a.cand_crop[(size_t)map * a.K + lane + 64 * m] = found[m];          // slot in the frame's list for now
         __syncthreads();                                          // (every lane has read n_my_s)
-        if (lane == 0) { n_my_s = n_my; a.status[map] = CERT_PENDING | gbit; }
+        if (lane == 0) { n_my_s = n_my; a.status[map] = CERT_PENDING | gbit | ((audit_pick && !a.exact) ? CERT_AUDIT_ONLY : 0); }
     }
     __syncthreads();
     const int n_my = n_my_s;
@@ -209,12 +215,13 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         const int map = frame * a.C + ch;
         const int st = a.status[map];          // (written by lane 0 of this workgroup above: visible after the barrier)
         if (!(st & CERT_PENDING)) continue;
-        const int gbit = st & 4;
+        const int gbit = st & 4, abit = st & CERT_AUDIT_ONLY;
+        if (full && abit) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }          // (no room for the audit: still a certified single candidate)
         if (full) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
         const int cnt = a.cand_cnt[map];
         for (int k = lane; k < cnt; k += 64) a.cand_crop[(size_t)map * a.K + k] += base;
         if (lane == 0) {
-            a.status[map] = 1 | gbit;
+            a.status[map] = 1 | gbit | abit;
             atomicAdd(&a.stats[2], 1ull);
             atomicAdd(&a.stats[5], (unsigned long long)cnt);
         }
@@ -284,11 +291,14 @@ __global__ void cert_lookup_kernel(const int* __restrict__ cand_idx, const int* 
 }
 
 // ---- 4b. the fp32 winner of every heatmap that needed crops
-__global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, const int* __restrict__ status,
+__global__ void cert_resolve_kernel(const int* __restrict__ cand_idx, const int* __restrict__ cand_cnt, int* __restrict__ status,
                                     const float* __restrict__ cand_val, const float* __restrict__ cand_win, int K, int n_maps,
                                     long long* __restrict__ argmax, float* __restrict__ win, float* __restrict__ margin) {
     const int map = blockIdx.x * blockDim.x + threadIdx.x;
     if (map >= n_maps || (status[map] & 3) != 1) return;
+    // an audit crop has left its |bf16 - fp32| in stats[6] (cert_lookup_kernel): the heatmap's result is what the bf16 path returned,
+    // whatever frames an audit happens to look at (outputs do not depend on the audit phase); status back to "single candidate"
+    if (status[map] & CERT_AUDIT_ONLY) { status[map] = status[map] & 4; return; }
     const int cnt = cand_cnt[map];
     float bv = cand_val[(size_t)map * K];
     long long bi = cand_idx[(size_t)map * K];
@@ -358,6 +368,7 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     a.cand_idx = sl.cand_idx; a.cand_cnt = sl.cand_cnt; a.cand_crop = sl.cand_crop; a.crop_rec = sl.crop_rec; a.n_crops = sl.n_crops;
     a.status = sl.status; a.stats = c.stats; a.cand_bf = sl.cand_bf; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
     a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.frame0 = b0; a.C = C; a.maxf = c.maxf; a.exact = c.exact_windows ? 1 : 0; a.guard_cnt = sl.guard_cnt; a.margin = sl.margin;
+    a.audit_mod = c.audit_mod; a.audit_phase = c.audit_phase;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -407,7 +418,7 @@ int cert_finish(ttup_wasb* net, const float* x_dev, const uint8_t* frames_dev, i
                            sl.cand_val, sl.cand_win, (const float*)sl.cand_bf, c.stats, C);
         TTUP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch * C, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, (const int*)sl.status,
+    hipLaunchKernelGGL(cert_resolve_kernel, dim3(cdiv(batch * C, 64)), dim3(64), 0, st, (const int*)sl.cand_idx, (const int*)sl.cand_cnt, sl.status,
                        (const float*)sl.cand_val, (const float*)sl.cand_win, c.K, batch * C, (long long*)argmax_dev, win_dev, sl.margin);
     TTUP_LAUNCH_CHECK();
     TTUP_HIP_CHECK(hipEventRecord(sl.done, st));
@@ -582,6 +593,14 @@ extern "C" int ttup_slice_columns(const float* src_dev, long long rows, int widt
 extern "C" int ttup_wasb_certify_exact_windows(ttup_wasb* net, int on) {
     TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_exact_windows: the certified argmax is not enabled on this handle");
     net->cert.exact_windows = on != 0;
+    return TTUP_OK;
+}
+
+extern "C" int ttup_wasb_certify_audit_crops(ttup_wasb* net, int every, int phase) {
+    TTUP_REQUIRE(net && net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_audit_crops: the certified argmax is not enabled on this handle");
+    TTUP_REQUIRE(every >= 0 && phase >= 0, TTUP_EINVAL, "ttup_wasb_certify_audit_crops: every and phase must not be negative");
+    net->cert.audit_mod = every;
+    net->cert.audit_phase = every > 0 ? phase % every : 0;
     return TTUP_OK;
 }
 

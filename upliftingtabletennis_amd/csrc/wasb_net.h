@@ -47,6 +47,7 @@ struct CertState {
     int CH = 0, nchunks = 0, max_crops = 0, Hc = 0, Wc = 0;
     int budget = 0;                      // crops the next forward may use (<= max_crops): ceil(budget / CH) fp32 passes are enqueued
     bool exact_windows = false;          // every heatmap gets an fp32 crop (also single-candidate ones): all 3x3 windows are fp32 values
+    int audit_mod = 0, audit_phase = 0;  // audit crops: single-candidate heatmaps of the frames with (frame + phase) % mod == 0 get an fp32 crop as well (0 = off)
     struct ::ttup_wasb* cropnet = nullptr;  // fp32 handle at crop size, batch CH
     // Per-call state, two slots used alternately: the fp32 passes of call k run on the handle's own stream (`stream`) while the
     // bf16 micro-batches of call k+1 -- issued on another caller stream -- already fill slot (k+1)&1

@@ -110,7 +110,7 @@ class StreamWorker:
 
     def __init__(self, device, wasb_state_dict, uplift_state_dict, net_wh=(1280, 704), max_triples=256, uplift_size='large',
                  traj_len=TRAJ_LEN_DEFAULT, seq_len=50, dtype='bf16', certify=True, audit_every=256, audit_seed=0, exact_windows=False,
-                 audit_every_fast=64, audit_settle_clips=8):
+                 audit_every_fast=64, audit_settle_clips=8, audit_crops_every=16):
         from . import glue, refine, uplift, wasb, _lib
         _lib.require_gpu()
         self._glue, self._refine, self._uplift, self._lib = glue, refine, uplift, _lib
@@ -138,9 +138,16 @@ class StreamWorker:
         self.audit_settle_clips = int(audit_settle_clips)
         self._quiet_clips = 0
         self.frames_seen = 0
+        # Audit crops (round 6): one single-candidate heatmap per `audit_crops_every` triples gets an fp32 crop although its index is
+        # already certain; the crop reports |bf16 - fp32| at the winner.  The strip audit sees every pixel of a quarter-width strip of
+        # one triple per 64-256; this sees ONE pixel -- the one the detection rests on -- of one triple per 16, at 0.1 ms each
+        # (1.3 % of a step).  The phase is drawn per clip.  0 = off.
+        self.audit_crops_every = int(audit_crops_every)
+        self.audit_crop_frames = 0
         self.widen_sources = {'strip': 0, 'candidates': 0}
         self._since_audit = 0
         self._rng = np.random.default_rng(audit_seed)
+        self._rng_crops = np.random.default_rng(audit_seed + 1)          # (its own stream: tests replace _rng to steer the strip audit)
         # measurement (bench.py `ambiguous_share`): when set to a list, every collected clip appends the fp32 top-2 margins of its
         # heatmaps (`WASBNet.certify_margins`: +inf for single-candidate heatmaps)
         self.margin_log = None
@@ -162,7 +169,10 @@ class StreamWorker:
         # error exceeds eps while no audited frame's does is missed with probability 1 - (the audit rate at that time) by the strip
         # audit (the candidate-level audit still sees it when it needs a crop): the guarantee is statistical and this is its rate
         a['frames_seen'] = self.frames_seen
-        a['audited_share'] = (a['audited_frames'] / self.frames_seen) if self.frames_seen else None
+        # strip audits (every pixel of a strip of the triple, calibration frames included) + audit crops (the winner's pixel of the triple)
+        a['audit_crop_frames'] = self.audit_crop_frames
+        a['strip_audited_share'] = (a['audited_frames'] / self.frames_seen) if self.frames_seen else None
+        a['audited_share'] = ((a['audited_frames'] + self.audit_crop_frames) / self.frames_seen) if self.frames_seen else None
         a['audit_every_now'] = self.audit_rate()
         a['quiet_clips'] = self._quiet_clips
         a['widen_sources'] = dict(self.widen_sources)
@@ -184,13 +194,23 @@ class StreamWorker:
             self.certify_eps = self.net.calibrate(frames_u8, n=8, exact_windows=self.exact_windows)
         return self.certify_eps
 
-    def _start_audit(self, frames_u8):
-        """Enqueue the side-stream audit of this clip (if one is due) next to its detector pass; None otherwise."""
+    def _start_audit(self, frames_u8, rerun=False):
+        """Enqueue the side-stream audit of this clip (if one is due) next to its detector pass; None otherwise.  rerun=True: the clip
+        has been counted (and its audit drawn) already -- a re-run after eps widened past the guard factor is the same triples again."""
+        if rerun:
+            return None
         picks = self._pick_audits(frames_u8.shape[0] - 2)
         return self.net.audit_async(frames_u8, picks) if picks else None
 
     def _detect(self, frames_u8):
         self._calibrated(frames_u8)
+        if self.certify and self.audit_crops_every > 0:
+            every = self.audit_crops_every
+            phase = int(self._rng_crops.integers(every))
+            self.net.certify_audit_crops(every, phase)
+            n = int(frames_u8.shape[0]) - 2
+            if not self.__dict__.get('_rerun_pass', False):
+                self.audit_crop_frames += len(range((-phase) % every, n, every))          # frames f < n with (f + phase) % every == 0
         _, idx, win = self.net.forward_frames(frames_u8, want_heatmap=False)
         xyv = self._refine.refine_windows_device(idx, win, self.net_h, self.net_w, 1920, 1080, self._lib.REFINE_TABLE)
         # status and info belong to THIS call: both are copied right behind it in stream order, before another call can flip the
@@ -278,15 +298,19 @@ class StreamWorker:
             # (status_host[todo] now holds the re-runs' own status: 0 = single candidate under the current eps, 1 = fp32 values)
         return xyv
 
-    def _detect_blocking(self, frames_u8, full=False):
+    def _detect_blocking(self, frames_u8, full=False, counted=False):
         """One clip, start to finish, with the audit folded in: (xyv device tensor) whose every index is certified under the
         current eps; full=True: (xyv, idx, win, host status 0/1/2) of the pass that produced it.  Loops only when an audit widens
         eps past the guard factor (eps only grows)."""
+        rerun = bool(counted)          # counted=True: the clip went through submit() already (frames_seen, audits)
         while True:
             eps_used = self._calibrated(frames_u8)
-            ticket = self._start_audit(frames_u8)
+            ticket = self._start_audit(frames_u8, rerun)
+            self._rerun_pass = rerun
+            rerun = True
             xyv, idx, win, status, info = self._detect(frames_u8)
             if status is None:
+                self._rerun_pass = False
                 return (xyv, idx, win, None) if full else xyv
             n_crops, cand_err = self.net.decode_info(info.cpu().numpy())
             st = status.cpu().numpy()
@@ -297,6 +321,7 @@ class StreamWorker:
                     continue
                 xyv = out
             xyv = self._repair(frames_u8, xyv, idx, win, st)
+            self._rerun_pass = False
             return (xyv, idx, win, st & 3) if full else xyv
 
     def process_clip(self, frames_u8, table_px, fps):
@@ -376,7 +401,7 @@ class StreamWorker:
                 if out is None:
                     self.recertified_clips += 1
                     # the ticket then describes the pass that produced its detections (indices, windows, status), not the stale one
-                    out, ticket['idx'], ticket['win'], rerun_status = self._detect_blocking(ticket['frames'], full=True)
+                    out, ticket['idx'], ticket['win'], rerun_status = self._detect_blocking(ticket['frames'], full=True, counted=True)
                     st = None
                 ticket['xyv'] = out
                 ticket['host'].copy_(ticket['xyv'])

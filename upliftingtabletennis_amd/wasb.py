@@ -123,6 +123,11 @@ class WASBNet:
             if getattr(self, 'exact_windows', False):
                 self.certify_budget(2 * self.max_batch)
 
+    def certify_audit_crops(self, every, phase=0):
+        """Audit crops of the forwards that follow: of the frames f with (f + phase) % every == 0, one single-candidate heatmap gets an
+        fp32 crop as well, which reports |bf16 - fp32| at the winner (`certify_info` / `note_error`).  every = 0: off (default)."""
+        _lib.check(self._lib.ttup_wasb_certify_audit_crops(self._handle, int(every), int(phase)))
+
     def _make(self, resolution=None, max_batch=1, dtype='bf16'):
         """Another handle of this detector type with the same weights."""
         return type(self)(self._state_dict, resolution=resolution or (self.W, self.H), max_batch=max_batch, dtype=dtype, device=self.device)
