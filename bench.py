@@ -871,11 +871,13 @@ def main():
                                     'audited_frames': au['audited_frames'], 'audit_every_frames': pipe.worker.audit_every,
                                     'audit_every_frames_fast': pipe.worker.audit_every_fast, 'audit_settle_clips': pipe.worker.audit_settle_clips,
                                     'audit_every_now': au['audit_every_now'], 'frames_seen': au['frames_seen'],
-                                    'audited_share': round(au['audited_share'], 5) if au['audited_share'] else None, 'widen_sources': au['widen_sources'],
+                                    'audited_share': round(au['audited_share'], 5) if au['audited_share'] else None,
+                                    'strip_audited_share': round(au['strip_audited_share'], 5) if au.get('strip_audited_share') else None,
+                                    'audit_crops_every': pipe.worker.audit_crops_every, 'audit_crop_frames': au.get('audit_crop_frames'), 'widen_sources': au['widen_sources'],
                                     'max_err_seen': round(au['max_err_seen'], 6), 'max_candidate_err': round(cs['max_candidate_err'], 6),
                                     'max_err_over_eps': round(au['max_err_over_eps'], 4), 'eps_widened': au['widened'], 'recertified_clips': au['recertified_clips'], 'recertified_heatmaps': au['recertified_heatmaps'],
                                     'note': 'an index is the fp32 argmax whenever |bf16 - fp32| <= eps on its frame (csrc/certify.hip); eps is audited inside the timed '
-                                            'steps: one random frame per audit_every frames on the fp32 twin (side stream; per audit_every_frames_fast until eps has stood for audit_settle_clips clips in a row: audited_share = audited / processed frames) + the error at every candidate of every crop; '
+                                            'steps: one random frame per audit_every frames on the fp32 twin (side stream; per audit_every_frames_fast until eps has stood for audit_settle_clips clips in a row: strip_audited_share = those / processed frames) + audit crops (one single-candidate heatmap per audit_crops_every triples gets an fp32 crop that measures |bf16 - fp32| at its winner; audited_share counts both) + the error at every candidate of every crop; '
                                             'eps = 1.5 x the largest error seen; a new maximum widens it and the heatmaps whose guard band (2 eps .. 2.5 eps below the maximum) is not empty are run again, the whole clip when eps grows by more than a quarter at once.  Counts cover warm-up + timed steps'}
     line['host_threads_per_rank'] = host_threads
     line['cpu_affinity'] = {'cores_of_rank0': ('%d-%d (%d cores)' % (cores[0], cores[-1], len(cores))) if cores and cores == list(range(cores[0], cores[-1] + 1)) else cores, 'policy': 'contiguous block per local rank (os.sched_setaffinity before the first GPU call)'}

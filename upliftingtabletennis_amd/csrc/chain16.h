@@ -36,6 +36,13 @@ struct C16IdmTab {
 __device__ const C16IdmTab c16_idm_tab = C16IdmTab();
 
 constexpr int C16_PB = 32;                  // bytes per pixel record (16 bf16 channels)
+// work split of conv1 / conv2 / conv3 of the 24x32 tile (regions 30x38, 28x36, 26x34): rows for waves 0-3 | 4-5 | 6-7, strip pairs likewise
+// (measured against equal bands of four rows with the strip pairs dealt to the last wave first: -1.2 ... -1.7 % on the launches with
+// stored outputs, +-0 on the stage-4 form; two neighbouring splits -- conv2 at 4 | 3 | 3 rows, or 5-row bands for the older waves in
+// all three convs -- are within 0.5 % of this one)
+#define C16_SPLIT1 4, 4, 3, 1, 0, 1
+#define C16_SPLIT2 5, 2, 2, 0, 1, 1
+#define C16_SPLIT3 4, 3, 2, 0, 0, 1
 // byte offset of 16-byte chunk c8 of buffer column x inside a row of pixel records (the swizzle of bb_off<16>)
 __device__ __forceinline__ int c16_col(int x, int c8) { return x * C16_PB + ((c8 ^ ((x >> 2) & 1)) << 4); }
 
@@ -57,13 +64,23 @@ __device__ __forceinline__ u32x4 c16_pair_chunk(unsigned a0, unsigned a1, unsign
 }
 
 // One 3x3 conv of the chain with its output in LDS (conv1-3).  Byte addresses; strides in pixels.  Region RHO x RWO, RWO = 32 + RX.
-template <int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, int ORW, int OOFF>
+// Work split (SPLIT = RA, RY1, RY2 rows and PA, PY1, PY2 strip pairs for waves 0-3 | 4-5 | 6-7): the two waves of this workgroup on a
+// SIMD are waves w and w + 4, and the SIMD's arbiter serves the OLDER one first (per-wave stamps, round 6: the same eight 16-pixel
+// groups take waves 0-3 3.0-3.1 k cycles and waves 4-5 3.8-3.9 k) -- so the older waves get more of the band and the younger ones the
+// strip pairs, instead of equal bands with the strip pairs dealt to whoever comes first.
+template <int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, int ORW, int OOFF, int RA, int RY1, int RY2, int PA, int PY1, int PY2>
 __device__ __forceinline__ void c16_conv_lds(const char* s_in, char* s_out, const char* s_res, const BBFrag16& fr, bf16x8 idm,
                                              int gy0, int gx0, int H, int W, int wave, int lane) {
     constexpr int RS = RWI * C16_PB, RSR = RWR * C16_PB, OS = ORW * C16_PB;
-    constexpr int RB = (RHO + 7) / 8;
+    constexpr int RB = RA > RY1 ? (RA > RY2 ? RA : RY2) : (RY1 > RY2 ? RY1 : RY2);          // most rows a wave walks
     constexpr int RX = RWO - 32;
     static_assert(RX > 0 && RX < 16 && (RHO & 1) == 0, "two full 16-pixel groups + a ragged strip, even row count");
+    static_assert(4 * RA + 2 * RY1 + 2 * RY2 == RHO && 4 * PA + 2 * PY1 + 2 * PY2 == RX, "the split covers the band and the strip");
+    // (wave-uniform) this wave's rows [yb, yb + rows) and strip pairs [p0, p0 + np)
+    const int rows = wave < 4 ? RA : (wave < 6 ? RY1 : RY2);
+    const int yb = wave < 4 ? wave * RA : (wave < 6 ? 4 * RA + (wave - 4) * RY1 : 4 * RA + 2 * RY1 + (wave - 6) * RY2);
+    const int np = wave < 4 ? PA : (wave < 6 ? PY1 : PY2);
+    const int p0 = wave < 4 ? wave * PA : (wave < 6 ? 4 * PA + (wave - 4) * PY1 : 4 * PA + 2 * PY1 + (wave - 6) * PY2);
     const int n = lane & 15, g = lane >> 4, h = g >> 1, c8 = g & 1;
     bf16x8 af[5];
 #pragma unroll
@@ -75,9 +92,8 @@ __device__ __forceinline__ void c16_conv_lds(const char* s_in, char* s_out, cons
 #else
     const bool interior = gy0 >= 0 && gy0 + RHO <= H && gx0 >= 0 && gx0 + RWO <= W;
 #endif
-    const int yb = wave * RB;
-    // ---- the band: rows yb .. yb+RB-1, column groups 0 and 1
-    if (yb < RHO) {
+    // ---- the band: rows yb .. yb+rows-1, column groups 0 and 1
+    if (rows > 0) {
         const char* rowb = s_in + ((yb + IOFF) * RWI) * C16_PB;
         const char* pA = rowb + c16_col(IOFF + n + h, c8);                     // steps 0-2: row r+dy, column x | x+1
         const char* pC = rowb + h * RS + c16_col(IOFF + n + 2, c8);            // step 3: column x+2 of rows r | r+1
@@ -92,7 +108,7 @@ __device__ __forceinline__ void c16_conv_lds(const char* s_in, char* s_out, cons
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int y = yb + r;
-            if (y >= RHO) break;
+            if (r >= rows) break;
             bf16x8 f3[2], f4[2];
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt) {
@@ -128,11 +144,6 @@ __device__ __forceinline__ void c16_conv_lds(const char* s_in, char* s_out, cons
     {
         constexpr int RPG = RHO / 2;
         static_assert(RPG <= 16, "a strip column is two 16-lane groups");
-        constexpr int ROWS7 = RHO - 7 * RB < 0 ? 0 : (RHO - 7 * RB > RB ? RB : RHO - 7 * RB);      // band rows of the last wave
-        // the last wave's band is short or empty: it takes K7 pairs (a pair costs about three band groups), the others go one each to waves 0, 1, ...
-        constexpr int SPARE = (RB - ROWS7) * 2 / 3;
-        constexpr int K7 = RX < SPARE ? RX : (SPARE < 1 ? 1 : SPARE);
-        static_assert(RX - K7 <= 7, "at most one pair per wave besides the last wave's share");
         const int nr = n < RPG ? n : RPG - 1;              // idle lanes recompute a neighbour's pixel (same addresses: broadcast) and store nothing
         auto pair = [&](int p) __attribute__((always_inline)) {
             const int col = 32 + p;
@@ -165,10 +176,10 @@ __device__ __forceinline__ void c16_conv_lds(const char* s_in, char* s_out, cons
             // lane (n, g): row (g & 1) * RPG + n of the strip column, chunk g >> 1
             if (n < RPG) *(u32x4*)(s_out + ((nr + (g & 1) * RPG + OOFF) * ORW + col + OOFF) * C16_PB + (((g >> 1) ^ (((col + OOFF) >> 2) & 1)) << 4)) = o;
         };
-        if (wave == 7) {
+        constexpr int NPMAX = PA > PY1 ? (PA > PY2 ? PA : PY2) : (PY1 > PY2 ? PY1 : PY2);
 #pragma unroll
-            for (int p = 0; p < K7; ++p) pair(p);
-        } else if (K7 + wave < RX) pair(K7 + wave);
+        for (int k = 0; k < NPMAX; ++k)
+            if (k < np) pair(p0 + k);
     }
 #endif
 }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
     __syncthreads();
     TTUP_STAMP(1);
     C16_WSTAMP(2);
-    c16_conv_lds<SA, 0, R0H - 2, R0W - 2, false, 1, 0, SB, 0>(bufA, bufB, nullptr, fr, idm, oy0 - 3, ox0 - 3, a.H, a.W, wave, lane);
+    c16_conv_lds<SA, 0, R0H - 2, R0W - 2, false, 1, 0, SB, 0, C16_SPLIT1>(bufA, bufB, nullptr, fr, idm, oy0 - 3, ox0 - 3, a.H, a.W, wave, lane);
     TTUP_STAMP(2);
     C16_WSTAMP(3);
     // next conv's fragments: requested BEFORE the barrier, in flight across it.  (Requested a whole conv earlier into a second register
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
     __syncthreads();
     TTUP_STAMP(3);
     C16_WSTAMP(4);
-    c16_conv_lds<SB, 0, R0H - 4, R0W - 4, true, SA, 2, SA, 2>(bufB, bufA, bufA, fr, idm, oy0 - 2, ox0 - 2, a.H, a.W, wave, lane);
+    c16_conv_lds<SB, 0, R0H - 4, R0W - 4, true, SA, 2, SA, 2, C16_SPLIT2>(bufB, bufA, bufA, fr, idm, oy0 - 2, ox0 - 2, a.H, a.W, wave, lane);
     C16_WSTAMP(5);
     bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
         const bool ok = tid < BN && ty < hs && tx < ws;
         treg = *(const u32x4*)(ok ? tp + ((long long)(b * hs + ty) * ws + tx) * 16 + (u & 1) * 8 : a.st[0]);
     }
-    c16_conv_lds<SA, 2, R0H - 6, R0W - 6, false, 1, 0, S3, 0>(bufA, bufB, nullptr, fr, idm, oy0 - 1, ox0 - 1, a.H, a.W, wave, lane);
+    c16_conv_lds<SA, 2, R0H - 6, R0W - 6, false, 1, 0, S3, 0, C16_SPLIT3>(bufA, bufB, nullptr, fr, idm, oy0 - 1, ox0 - 1, a.H, a.W, wave, lane);
     C16_WSTAMP(7);
     if (NS > 0 && tid < BN) ((u32x4*)s_terms)[tid] = treg;
     bb_load_frag16(fr, a.w[3], a.bias[3], lane);
