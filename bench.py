@@ -88,7 +88,7 @@ class Pipeline:
         return self.worker.collect(ticket, self.table_px, self.fps)
 
 
-TRAFFIC_FILE = 'r5_traffic.json'      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round (tools/pmc_traffic.py)
+TRAFFIC_FILE = 'r6_traffic.json'      # profiles/: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round (tools/pmc_traffic.py)
 
 
 def _family(kernel):
