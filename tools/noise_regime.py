@@ -18,4 +18,4 @@ for _ in range(k):
 pn.collect(tk); torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / k
 cs = pn.net.certify_stats()
-print('maxc %s list %s: %.1f fps, %.1f ms/step, crops/heatmap %.3f, not certified %.4f, reruns/step %.1f' % (os.environ.get('TTUP_CERT_MAXC','4'), os.environ.get('TTUP_CERT_LIST','2'), 256/dt, dt*1e3, cs['crops']/cs['heatmaps'], cs['not_certified']/cs['heatmaps'], (pn.worker.fp32_reruns - r0)/k))
+print('maxc %s list %s: %.1f fps, %.1f ms/step, crops/heatmap %.3f, not certified %.4f (candidate list %d, crops per heatmap %d, crop list %d of %d), reruns/step %.1f' % (os.environ.get('TTUP_CERT_MAXC','8'), os.environ.get('TTUP_CERT_LIST','4'), 256/dt, dt*1e3, cs['crops']/cs['heatmaps'], cs['not_certified']/cs['heatmaps'], cs['over_candidates'], cs['over_crops_per_map'], cs['over_crop_list'], cs['heatmaps'], (pn.worker.fp32_reruns - r0)/k))

@@ -79,7 +79,7 @@ __device__ __forceinline__ void core_range(int o, int c, int full, int R, int& l
 // saturated blob (a few hundred equal pixels inside one crop core), which used to overflow a 32-entry list and send the heatmap
 // to the full-frame fp32 path.
 constexpr int CERT_MAX_K = 512;
-constexpr int CERT_MAX_FRAME_CROPS = 16;
+constexpr int CERT_MAX_FRAME_CROPS = 32;
 constexpr int CERT_PENDING = 8;          // provisional status of a heatmap whose crops wait for their ids on the shared list
 constexpr int CERT_AUDIT_ONLY = 16;      // its crop only MEASURES (audit crop of a single-candidate heatmap): index and window stay the bf16 path's
 __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         // gets noticed between two strip audits
         const bool audit_pick = a.audit_mod > 0 && cnt == 1 && (frame + a.audit_phase) % a.audit_mod == 0 && ch == (frame / a.audit_mod) % a.C;
         if (cnt <= 0 || (cnt == 1 && !a.exact && !audit_pick)) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }
-        if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
+        if (cnt > a.K) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); atomicAdd(&a.stats[8], 1ull); } continue; }
         int* ci = a.cand_idx + (size_t)map * a.K;
         float* cb = a.cand_bf + (size_t)map * a.K;
         __syncthreads();                                          // (the previous channel is done with the shared lists)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
             ++n_my;
             __syncthreads();
         }
-        if (over) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }          // (n_my_s keeps the list without this heatmap's new crops)
+        if (over) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); atomicAdd(&a.stats[9], 1ull); } continue; }          // (n_my_s keeps the list without this heatmap's new crops)
 #pragma unroll
         for (int m = 0; m < PER; ++m)
             if (lane + 64 * m < cnt) a.cand_crop[(size_t)map * a.K + lane + 64 * m] = found[m];          // slot in the frame's list for now
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         if (!(st & CERT_PENDING)) continue;
         const int gbit = st & 4, abit = st & CERT_AUDIT_ONLY;
         if (full && abit) { if (lane == 0) { a.status[map] = 0 | gbit; atomicAdd(&a.stats[1], 1ull); } continue; }          // (no room for the audit: still a certified single candidate)
-        if (full) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); } continue; }
+        if (full) { if (lane == 0) { a.status[map] = 2 | gbit; atomicAdd(&a.stats[3], 1ull); atomicAdd(&a.stats[10], 1ull); } continue; }
         const int cnt = a.cand_cnt[map];
         for (int k = lane; k < cnt; k += 64) a.cand_crop[(size_t)map * a.K + k] += base;
         if (lane == 0) {
@@ -437,14 +437,14 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     if (eps_abs < 0.f) { (void)hipDeviceSynchronize(); cert_free(net); return TTUP_OK; }
     TTUP_REQUIRE(net->dtype == TTUP_DTYPE_BF16, TTUP_EINVAL,
                  "ttup_wasb_set_certify: the certified argmax applies to bf16 handles (an fp32 handle's argmax is the fp32 argmax)");
-    TTUP_REQUIRE(eps_abs == eps_abs && crop >= 0 && max_crops_per_map >= 0 && max_crops_per_map <= 8, TTUP_EINVAL, "ttup_wasb_set_certify: bad argument");
+    TTUP_REQUIRE(eps_abs == eps_abs && crop >= 0 && max_crops_per_map >= 0 && max_crops_per_map <= CERT_MAX_FRAME_CROPS, TTUP_EINVAL, "ttup_wasb_set_certify: bad argument");
     CertState& c = net->cert;
     if (c.enabled) { c.eps = eps_abs; if (crop == 0 && max_crops_per_map == 0) return TTUP_OK; }
     (void)hipDeviceSynchronize();
     cert_free(net);
     c.eps = eps_abs;
     static const int env_maxc = getenv("TTUP_CERT_MAXC") ? atoi(getenv("TTUP_CERT_MAXC")) : 0, env_list = getenv("TTUP_CERT_LIST") ? atoi(getenv("TTUP_CERT_LIST")) : 0;
-    c.maxc = max_crops_per_map > 0 ? max_crops_per_map : (env_maxc > 0 && env_maxc <= 8 ? env_maxc : 8);
+    c.maxc = max_crops_per_map > 0 ? max_crops_per_map : (env_maxc > 0 && env_maxc <= CERT_MAX_FRAME_CROPS ? env_maxc : 8);
     c.maxf = c.maxc * net->n_out < CERT_MAX_FRAME_CROPS ? c.maxc * net->n_out : CERT_MAX_FRAME_CROPS;      // the channels of a frame share its crops
     int side = crop > 0 ? crop : 168;
     TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 24, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 24);
@@ -454,7 +454,7 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     TTUP_REQUIRE(((long long)net->H * net->W) % 4 == 0 && (net->H - c.Hc) % 8 == 0 && (net->W - c.Wc) % 8 == 0, TTUP_EINVAL,
                  "ttup_wasb_set_certify: %dx%d heatmaps with %dx%d crops cannot be certified (H*W %% 4, (H-Hc) %% 8, (W-Wc) %% 8 must be 0)", net->H, net->W, c.Hc, c.Wc);
     c.CH = net->max_batch < 64 ? net->max_batch : 64;
-    const int per_map = env_list > 0 && env_list <= 8 ? env_list : 4;
+    const int per_map = env_list > 0 && env_list <= 16 ? env_list : 4;
     c.max_crops = per_map * net->max_batch > c.CH ? per_map * net->max_batch : c.CH;   // capacity of the call's crop list: four per heatmap on average; the overflow is flagged
     if (c.max_crops < c.maxf) c.max_crops = c.maxf;          // ... and never less than ONE frame may ask for (one-sample handles: re-certification of single frames, round-4 advisor)
     // (round 4: 2 -> 4 and 4 -> 8 crops per heatmap: on pure noise weights 5.5 % of the heatmaps overflowed and went to the full-frame fp32 path --
@@ -488,8 +488,8 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     }
     TTUP_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     TTUP_HIP_CHECK(hipEventCreateWithFlags(&c.lanes_done, hipEventDisableTiming));
-    TTUP_HIP_CHECK(hipMalloc((void**)&c.stats, 8 * sizeof(unsigned long long)));
-    TTUP_HIP_CHECK(hipMemset(c.stats, 0, 8 * sizeof(unsigned long long)));
+    TTUP_HIP_CHECK(hipMalloc((void**)&c.stats, 12 * sizeof(unsigned long long)));
+    TTUP_HIP_CHECK(hipMemset(c.stats, 0, 12 * sizeof(unsigned long long)));
     TTUP_HIP_CHECK(hipMalloc((void**)&c.crop_heat, (size_t)c.CH * net->n_out * c.Hc * c.Wc * sizeof(float)));
     const int rc = ttup_wasb_create_internal(net->blob.data(), net->blob.size(), c.Hc, c.Wc, c.CH, TTUP_DTYPE_F32, c.CH, 1, &c.cropnet);
     if (rc) { cert_free(net); return rc; }
@@ -656,7 +656,7 @@ extern "C" int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host, int 
     TTUP_REQUIRE(net && out_host, TTUP_EINVAL, "ttup_wasb_certify_stats: null pointer");
     TTUP_REQUIRE(net->cert.enabled, TTUP_EINVAL, "ttup_wasb_certify_stats: the certified argmax is not enabled on this handle");
     TTUP_HIP_CHECK(hipDeviceSynchronize());
-    TTUP_HIP_CHECK(hipMemcpy(out_host, net->cert.stats, 8 * sizeof(long long), hipMemcpyDeviceToHost));
-    if (reset) TTUP_HIP_CHECK(hipMemset(net->cert.stats, 0, 8 * sizeof(long long)));
+    TTUP_HIP_CHECK(hipMemcpy(out_host, net->cert.stats, 12 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (reset) TTUP_HIP_CHECK(hipMemset(net->cert.stats, 0, 12 * sizeof(long long)));
     return TTUP_OK;
 }
