@@ -36,6 +36,11 @@ struct C16IdmTab {
 __device__ const C16IdmTab c16_idm_tab = C16IdmTab();
 
 constexpr int C16_PB = 32;                  // bytes per pixel record (16 bf16 channels)
+// L2 prefetch distance in workgroups (0 = off): see c16_chain_kernel.  Measured (two boxes, ms per launch, sum / stored-output forms):
+// off 0.7184-0.7440; 512: -1.4 %; 256: -1.3 ... -2.3 % (-1.6 ... -3.2 % on the stored-output forms); 192 like 256; 128: +0.4 %; 64: +2.7 %
+#ifndef TTUP_C16_PREFETCH
+#define TTUP_C16_PREFETCH 256
+#endif
 // work split of conv1 / conv2 / conv3 of the 24x32 tile (regions 30x38, 28x36, 26x34): rows for waves 0-3 | 4-5 | 6-7, strip pairs likewise
 // (measured against equal bands of four rows with the strip pairs dealt to the last wave first: -1.2 ... -1.7 % on the launches with
 // stored outputs, +-0 on the stage-4 form; two neighbouring splits -- conv2 at 4 | 3 | 3 rows, or 5-row bands for the older waves in
@@ -437,6 +442,30 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
     __syncthreads();
     TTUP_STAMP(1);
     C16_WSTAMP(2);
+#if TTUP_C16_PREFETCH > 0
+    unsigned pf_sink = 0;          // the register the prefetch lands in: kept alive (below) until the load has certainly arrived -- the compiler does not know about it
+    // L2 prefetch for the workgroup that takes this one's place: workgroups are dealt to the XCDs round-robin by linear id and 512 are
+    // resident (two per CU), so workgroup id + TTUP_C16_PREFETCH (a multiple of 8: same XCD, same L2) starts about one tile time from
+    // now.  One lane per 128-byte line of ITS input region reads one dword -- 320 lane-loads for 40 KB -- into a register nobody
+    // reads (an asm the compiler does not count: its later waits can only get stricter, and s_endpgm waits for everything).
+    {
+        const int lid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x + TTUP_C16_PREFETCH;
+        const int gxy = gridDim.x * gridDim.y;
+        const int pz = lid / gxy, prem = lid - pz * gxy, py = prem / (int)gridDim.x, pxr = prem - py * (int)gridDim.x;
+#ifdef TTUP_NO_XCD_MAP
+        const int pbx = pxr;
+#else
+        const int pbx = (gridDim.x & 7) == 0 ? (pxr & 7) * (gridDim.x >> 3) + (pxr >> 3) : pxr;
+#endif
+        constexpr int LPR = (R0W * C16_PB + 127) / 128;          // 128-byte lines per region row (the region starts 128-byte aligned: ox0 - 4 pixels of 32 bytes)
+        const int prow = tid / LPR, pline = tid - prow * LPR;
+        const int gyp = py * TH - L + prow, gxp = pbx * TW - L + pline * 4;          // 4 pixels per line
+        if (pz < (int)gridDim.z && prow < R0H && gyp >= 0 && gyp < a.H && gxp >= 0 && gxp < a.W) {
+            const bf16_t* pp = a.x + ((long long)(pz * a.H + gyp) * a.W + gxp) * C;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(pp) : "memory");
+        }
+    }
+#endif
     c16_conv_lds<SA, 0, R0H - 2, R0W - 2, false, 1, 0, SB, 0, C16_SPLIT1>(bufA, bufB, nullptr, fr, idm, oy0 - 3, ox0 - 3, a.H, a.W, wave, lane);
     TTUP_STAMP(2);
     C16_WSTAMP(3);
@@ -448,6 +477,10 @@ __global__ __launch_bounds__(512, 4) void c16_chain_kernel(BBArgs a) {
     C16_WSTAMP(4);
     c16_conv_lds<SB, 0, R0H - 4, R0W - 4, true, SA, 2, SA, 2, C16_SPLIT2>(bufB, bufA, bufA, fr, idm, oy0 - 2, ox0 - 2, a.H, a.W, wave, lane);
     C16_WSTAMP(5);
+#if TTUP_C16_PREFETCH > 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (everything older has long arrived: conv1 and conv2 lie between)
+    asm volatile("" :: "v"(pf_sink));
+#endif
     bb_load_frag16(fr, a.w[2], a.bias[2], lane);
     __syncthreads();
     TTUP_STAMP(4);
