@@ -153,6 +153,17 @@ def test_trajectory_batch_reads_like_the_reference_list_of_dicts(tmp_path):
     assert np.array_equal(np.load(str(tmp_path / 'ds' / 'trajectory_0004' / 'Mext.npy')), np.repeat(ex[None], 2, 0))
     assert np.array_equal(np.load(str(tmp_path / 'ds' / 'trajectory_0005' / 'velocities.npy')), want[5][0][:, 3:6])
     assert len(trajgen.TrajectoryBatch([], trajgen.save_times(), ex, mint)) == 0
+    # the reference's own return type on request: a plain list of dictionaries with independent, writable arrays
+    lst = tb.to_list()
+    assert isinstance(lst, list) and len(lst) == 6 and all(isinstance(d, dict) for d in lst)
+    import pickle, random
+    lst[0]['times'][0] = 123.0                                  # writable, and a copy: the batch is untouched
+    lst[0]['positions'][0, 0] = -7.0
+    assert tb[0]['times'][0] != 123.0 and tb[0]['positions'][0, 0] == want[0][0][0, 0]
+    random.Random(0).shuffle(lst)
+    assert len(pickle.loads(pickle.dumps(lst))) == 6
+    both = tb + [{'seed': -1}]
+    assert isinstance(both, list) and len(both) == 7 and both[-1]['seed'] == -1 and len([{'seed': -1}] + tb) == 7
 
 
 def test_every_mode_is_accepted_and_rejected_like_the_reference_worker(golden):

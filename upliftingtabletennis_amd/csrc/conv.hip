@@ -954,6 +954,9 @@ __global__ __launch_bounds__(512) void conv64_dma_kernel(ConvKArgs a) {
         // the six pieces of tile it+1 go out UNDER this tile's matrix work, one every third k-step (an LDS-DMA instruction costs 60-180
         // cycles of issue, MI355X_MICROARCH.md: in one block in front of the epilogue they were 10 % of the kernel)
         // (placement measured: every third k-step from the first, second or third -- equal within noise; all six in the first six k-steps: 2 % slower)
+        // (the hook's schedule -- a piece at k-steps 1, 4, ..., 16 of the 18 -- issues exactly six pieces; the waits below spell
+        // s_waitcnt vmcnt(0) in gfx9 / gfx950 encoding: 0x0f70 = vmcnt 0 (bits 3:0 and 15:14), expcnt 7, lgkmcnt 15)
+        static_assert(IN_PT == 6, "conv64_dma_kernel: the k-step hook issues pieces 0..5; a tile geometry with another piece count needs another schedule");
         conv64_tile_mfma<NPIX>(acc, bBc, s_w, wave, lane, [&](int s) __attribute__((always_inline)) { if (more && s % 3 == 1) issue_piece(s / 3); });
         // tile it+1 and the block input have landed -- waited for HERE, in front of this tile's stores (behind them the same wait drains them)
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)

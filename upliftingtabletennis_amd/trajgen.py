@@ -157,6 +157,21 @@ class TrajectoryBatch(collections.abc.Sequence):
                 'Mext': np.broadcast_to(self.Mext, (n, 4, 4)), 'Mint': np.broadcast_to(self.Mint, (n, 3, 3)),
                 'bounces': ch['bounces'][j, :int(ch['n_bounces'][j])], 'seed': int(ch['seeds'][j])}
 
+    def to_list(self):
+        """The reference's return type exactly (mujocosimulation.py:213-218, :238): a plain `list` of dictionaries whose arrays are
+        INDEPENDENT, writable numpy copies -- for callers that shuffle, append, pickle or edit the trajectories in place.  Costs what
+        the reference's own list costs (about 2 s per 125 000 trajectories); the views of `batch[i]` stay the fast path."""
+        out = []
+        for d in self:
+            out.append({k: (np.array(v.cpu() if torch.is_tensor(v) else v) if not isinstance(v, int) else v) for k, v in d.items()})
+        return out
+
+    def __add__(self, other):          # `trajectories += more` / `a + b` as with the reference's lists
+        return self.to_list() + (other.to_list() if isinstance(other, TrajectoryBatch) else list(other))
+
+    def __radd__(self, other):
+        return list(other) + self.to_list()
+
     def stacked(self):
         """{'rows' (R, 9), 'offsets' (N+1,), 'n_keep' (N,), 'bounces' (N, 4), 'n_bounces' (N,), 'seeds' (N,)} over all launches."""
         cat = torch.cat if any(torch.is_tensor(c['rows']) for c in self.chunks) else np.concatenate
