@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from upliftingtabletennis_amd import wasb, weights  # noqa: E402
 
 sd = weights.random_wasb_state_dict(0, planted=True)
-for (w, h, b) in ((1280, 704, 1), (168, 168, 32)):
+for (w, h, b) in ((1280, 704, 1), (168, 168, 64)):
     os.environ['TTUP_MICRO_BATCH'] = str(b)
     net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='f32')
     x = torch.randn((b, 9, h, w), device='cuda')
@@ -24,6 +24,6 @@ for (w, h, b) in ((1280, 704, 1), (168, 168, 32)):
         key = (o['cin'], o['cout'], o['k'], o['stride'], o['h'], o['w'])
         g = groups.setdefault(key, [0, 0.0, 0.0])
         g[0] += 1; g[1] += o['ms']; g[2] += o['flops']
-    for k, (cnt, ms, f) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:16]:
+    for k, (cnt, ms, f) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TTUP_TOP', '16'))]:
         print('   cin%4d cout%4d k%d s%d %4dx%4d x%-2d %.4f ms %5.1f%% %6.1f TFLOP/s' % (*k, cnt, ms, 100 * ms / tot, f / (ms * 1e-3) / 1e12 if ms > 0 else 0))
     del net

@@ -2587,12 +2587,14 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         // TTUP_CHAIN16_OLD=1 (read once per process): the round-2..5 kernel with the same compiled-out epilogues, kept for A/B runs
         static const bool old16 = getenv("TTUP_CHAIN16_OLD") != nullptr;
         const bool plain = !generic && a.nsum == 0 && !a.heat && !a.ysum && a.y;
-        if (!old16) {
-            if (plain) return launch_c16_t<BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
-            if (tail) return launch_c16_t<BB2_TH, BB2_TW, 7>(a, batch, h, w, st);
-            if (sum_stored && a.nsum == 1) return launch_c16_t<BB2_TH, BB2_TW, 1>(a, batch, h, w, st);
-            if (sum_stored && a.nsum == 2) return launch_c16_t<BB2_TH, BB2_TW, 2>(a, batch, h, w, st);
-            if (sum_stored && a.nsum == 3) return launch_c16_t<BB2_TH, BB2_TW, 3>(a, batch, h, w, st);
+        if constexpr (BB2_TH == 24 && BB2_TW == 32) {          // (c16_chain_kernel's work split is written for this tile; other -DTTUP_BB2_TH/TW experiments take the old kernel)
+            if (!old16) {
+                if (plain) return launch_c16_t<24, 32, 4>(a, batch, h, w, st);
+                if (tail) return launch_c16_t<24, 32, 7>(a, batch, h, w, st);
+                if (sum_stored && a.nsum == 1) return launch_c16_t<24, 32, 1>(a, batch, h, w, st);
+                if (sum_stored && a.nsum == 2) return launch_c16_t<24, 32, 2>(a, batch, h, w, st);
+                if (sum_stored && a.nsum == 3) return launch_c16_t<24, 32, 3>(a, batch, h, w, st);
+            }
         }
         if (plain) return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
         if (tail) return launch_bb2_t<16, BB2_TH, BB2_TW, 7>(a, batch, h, w, st);

@@ -720,6 +720,17 @@ int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, i
         TTUP_HIP_CHECK(hipEventCreateWithFlags(&net->pass_done, hipEventDisableTiming));
         net->use_lane(0);
     }
+    // measurement aid (tools/ops_report_f32.py): TTUP_DEBUG_FORCE_ROI=1 prunes EVERY sample of an fp32 handle to the cone of its central
+    // 24-pixel core, as the certified argmax's crop net does for interior crops -- per-op timings of the pruned graph (the flags leak
+    // with the process: a debugging switch)
+    if (dtype == TTUP_DTYPE_F32 && getenv("TTUP_DEBUG_FORCE_ROI") && net->H == net->W && net->H >= 2 * 72 + 24) {
+        int* flags = nullptr;
+        TTUP_HIP_CHECK(hipMalloc((void**)&flags, (size_t)max_batch * sizeof(int)));
+        std::vector<int> ones((size_t)max_batch, 1);
+        TTUP_HIP_CHECK(hipMemcpy(flags, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (int rc = compute_roi(net.get(), 72, net->H - 72)) return rc;
+        net->roi_flag = flags;
+    }
     TTUP_HIP_CHECK(hipDeviceSynchronize());
     *out = net.release();
     return TTUP_OK;
