@@ -1,7 +1,7 @@
 #!/bin/bash
 # N-way comparison of library builds on ONE box (boxes differ by +-4 %): tools/ops_report.py per build, the builds taking turns.
 #   tools/ab_multi.sh <rounds> <lib|default> <lib|default> ...        (lib: a path, or a tag T for upliftingtabletennis_amd/_ablate/libttup_T.so;
-#   <lib>+VAR=value runs that build with the environment variable set, e.g. default+TTUP_CHAIN16_OLD=1)
+#   <lib>+VAR=value runs that build with the environment variable set, e.g. default+TTUP_BB2_GENERIC=1)
 # Output: gpurun_out/abm/<tag>_<round>.log and the per-kernel medians of every build side by side.
 N=$1; shift
 cd "$(dirname "$0")/.."

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""The round-6 16-channel chain kernel (c16_chain_kernel) against the round-2..5 one (TTUP_CHAIN16_OLD=1, read once per process: child
-processes) on the same weights and inputs: fuse-layer outputs of stages 2-4 and the heatmap.  Same rounding points; the new
-kernel adds the fuse-layer terms on the matrix pipe (another fp32 summation order), so sums may land on the neighbouring bf16 value:
-reported are the share of differing values, the largest difference relative to the tap's range, and the argmax indices."""
+"""The round-6 16-channel chain kernel (c16_chain_kernel, csrc/chain16.h) against the run-time-epilogue form of the round-2..5 kernel
+(bb_chain2_kernel, TTUP_BB2_GENERIC=1, read once per process: child processes) on the same weights and inputs: fuse-layer outputs of
+stages 2-4 and the heatmap, on a ragged all-border size, a size with interior tiles, the bench size and the 13-channel table net.
+Same rounding points; the new kernel adds the fuse-layer terms on the matrix pipe (another fp32 summation order), so sums may land on
+the neighbouring bf16 value: reported are the share of differing values, the largest difference relative to the tap's range, and the
+argmax indices.  (Until the compiled-out forms of the old kernel were deleted in round 6 the comparison ran against those: stage taps
+bit-equal, heatmap within 1e-7 of its range.)"""
 import os, subprocess, sys, tempfile
 import numpy as np
 
@@ -34,8 +37,8 @@ np.savez(sys.argv[1], **out)
 def main():
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (('new', {}), ('old', {'TTUP_CHAIN16_OLD': '1'})):
-            e = dict(os.environ); e.pop('TTUP_CHAIN16_OLD', None); e.update(env)
+        for tag, env in (('new', {}), ('old', {'TTUP_BB2_GENERIC': '1'})):
+            e = dict(os.environ); e.pop('TTUP_BB2_GENERIC', None); e.update(env)
             f = os.path.join(d, tag + '.npz')
             r = subprocess.run([sys.executable, '-c', CHILD, f], env=e, capture_output=True, text=True, timeout=1800)
             if r.returncode != 0:

@@ -2,7 +2,7 @@
 // balldetection/models/wasb.py:48-64) per 24x32 output tile with every intermediate in LDS, and the fuse-layer sum that consumes the
 // branch (wasb.py:227-245) -- or, in stage 4, the 1x1 head + argmax partial (wasb.py:484, 606) -- in the last conv's epilogue.
 // Included by conv.hip (uses its BBArgs / BBFrag16 / pack2 / relu_pk / bb_key helpers).  Same tiling, LDS images, k-step order and
-// rounding points as bb_chain2_kernel (which stays as the run-time-epilogue fallback, MODE 0); what changed, from the round-5
+// rounding points as bb_chain2_kernel (csrc/conv.hip: the run-time-epilogue fallback and cross-check); what changed, from the round-5
 // counters (VALU 4.3-5.7 per MFMA, SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, phase stamps: staging 4.4 k + conv4 6.3 k of 24 k cycles):
 //   * conv1-3 store TWO 16-pixel groups per ds_write_b128: v_permlane16_swap turns (group A, group B) x (couts 4g..4g+3) into
 //     (pixel of A | pixel of B) x (8-channel chunk), 8 consecutive lanes then cover 8 different 16-byte bank groups -- the 2-way conflict

@@ -1661,7 +1661,7 @@ struct BBArgs {
 };
 // the tile's slices of the fuse-layer terms staged in LDS by the chain kernel (element offset of term k, pixels per row); a
 // separate by-value struct: writing into the kernel-argument struct would move all of it to scratch memory
-struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; f32x4 hw4; };
+struct BBTermLds { const bf16_t* s_terms; int toff[3]; int tw[3]; };
 
 // ReLU on the sign bit (one integer max, like relu_pk on bf16 pairs): negative values and -0 become +0, +NaN stays NaN
 __device__ __forceinline__ float relu_f32(float v) { const int b = __float_as_int(v); return __int_as_float(b > 0 ? b : 0); }
@@ -1746,14 +1746,12 @@ __device__ __forceinline__ void bb_load_frag16(BBFrag16& f, const bf16_t* wfrag,
 // result either overwrites that buffer in place (ORW = RWR, OOFF = ROFF: each pixel is read and written by the same lane)
 // or goes to global memory.  A wave owns whole output rows (y = wave, wave+8, ...); the 16-pixel groups of a row are
 // unrolled so every LDS address is a per-lane base plus an immediate.
-// MODE (last conv of the C=16 chain only): 0 = the fuse-sum / head epilogue reads its configuration from BBArgs at run time;
-// 1..3 = compile-time fuse sum of MODE terms (sum stored, branch tensor stored when it has consumers); 4 = plain chain;
-// 7 = stage-4 tail (3 terms, nothing stored but the heatmap).  The specialised epilogues are what the network uses: the epilogue is VALU-bound, and the run-time form spends
-// a third of its instructions on wave-uniform branches and on the cross-lane head reduction.
+// The last conv of the C=16 chain reads its fuse-sum / head configuration from BBArgs at run time here; the forms the network uses are
+// compiled out in csrc/chain16.h (c16_chain_kernel), this one is the fallback for other term layouts and the cross-check of those.
 template <int R> struct BBRow { static constexpr int value = R; };
 // NWV (C=32 only): waves that share the conv's rows -- `wave` is the wave's index among them (rows wave, wave + NWV, ...).  af32: the C=32
 // conv's 18 weight fragments already in registers (a two-group variant kept them there for the life of the workgroup: csrc/experiments).
-template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int MODE = 0, int NWV = 8>
+template <int C, int RWI, int IOFF, int RHO, int RWO, bool SECOND, int RWR, int ROFF, bool GLOBAL_OUT, int ORW, int OOFF, int NWV = 8>
 __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const bf16_t* s_res, const bf16_t* wfrag, const float* biasp,
                                         bf16_t* gout, int gy0, int gx0, int H, int W, int b, int wave, int lane,
                                         const bf16_t* wf = nullptr, const float* bfp = nullptr, bf16_t* yf = nullptr,
@@ -1814,9 +1812,7 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
     if (CAN_FOLLOW && yf) { af_f = *(const bf16x8*)(wf + lane * 8); bias_f = *(const f32x4*)(bfp + g * 4); }
     constexpr bool CAN_SUM = GLOBAL_OUT && C == 16;
     f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
-    if (CAN_SUM && MODE == 7) hw4 = tl->hw4;
-    else if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
-    const float head_one = (n == 0) ? 1.f : 0.f;          // A operand of the head's cross-lane sum (row 0 of a 16x4 matrix of ones)
+    if (CAN_SUM && ex && ex->heat) hw4 = *(const f32x4*)(ex->hw + g * 4);
     // C=16: a wave owns a BAND of consecutive output rows (pixel fragments shared between them, see bb_tap16); C=32: rows
     // wave, wave+8, ... (two output tiles per fragment read already)
     constexpr bool BAND = (C == 16);
@@ -1833,15 +1829,6 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         for (int s = 0; s < KSTEPS; ++s) { pk0[s] = row0 + n * C + koff[s]; pkl[s] = row0 + (XLAST + nl) * C + koff[s]; }
     }
     constexpr int ROWSTEP = NWV * RWI * C;
-    int tx[3] = {0, 0, 0};
-    if constexpr (CAN_SUM && MODE > 0 && MODE != 4) {
-#pragma unroll
-        for (int k = 0; k < (MODE == 7 ? 3 : MODE); ++k) {
-            // element offset of term k's slice (shift k + 1) in the staged block: the slices follow each other
-            const int toff = (k == 0 ? 0 : k == 1 ? (RHO >> 1) * (RWO >> 1) : (RHO >> 1) * (RWO >> 1) + (RHO >> 2) * (RWO >> 2)) * 16;
-            tx[k] = toff + (n >> (k + 1)) * 16 + g * 4;
-        }
-    }
     bf16_t* const so0 = GLOBAL_OUT ? nullptr : s_out + ((yb + OOFF) * ORW + n + OOFF) * C + out_ch;      // lane's output slot in the wave's first row
     // global stores: wave-uniform row base (scalar registers) + the lane's byte offset inside a 16-pixel group (one register for C-channel
     // records, one for 16-channel records) + the group as an immediate -- instead of a 64-bit per-lane address chain per store
@@ -1877,52 +1864,12 @@ __device__ __forceinline__ void bb_conv(const bf16_t* s_in, bf16_t* s_out, const
         }
         const size_t rowpix = (size_t)(b * H + gy) * W + gx0;          // (wave-uniform) first pixel of the region's row in the image
         if (GLOBAL_OUT) {
-            if (MODE != 7 && inside && valid && gout) {
+            if (inside && valid && gout) {
                 char* o = (char*)(gout + rowpix * C) + (opaque_u32(st_c) + (unsigned)(xt * 16 * C * 2));
                 if (C == 16) *(u32x2*)o = u32x2{pk[0], pk[1]};
                 else *(u32x4*)o = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
-            if constexpr (CAN_SUM && MODE == 4) {
-                // plain chain: nothing rides in the epilogue
-            } else if constexpr (CAN_SUM && MODE > 0) {
-                constexpr int NS = MODE == 7 ? 3 : MODE;
-                constexpr bool HEAD = MODE == 7;
-                float ys[4];
-                if (HEAD) {          // neither the branch tensor nor the sum is stored: no rounding in front of the head
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ys[r] = relu_f32(v[r]);
-                } else {
-                    ys[0] = bf16_to_f32((bf16_t)(pk[0] & 0xffff)); ys[1] = bf16_to_f32((bf16_t)(pk[0] >> 16));
-                    ys[2] = bf16_to_f32((bf16_t)(pk[1] & 0xffff)); ys[3] = bf16_to_f32((bf16_t)(pk[1] >> 16));
-                }
-                const bool live = inside && valid;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    // the tile origin is a multiple of 8 >= 2^sh: the term pixel of (y, x) is (y >> sh, x >> sh) of the slice --
-                    // a per-lane column part (tx, set up once) plus a wave-uniform row / group part
-                    const int sh = k + 1;
-                    const u32x2 tv = *(const u32x2*)(tl->s_terms + tx[k] + ((y >> sh) * (RWO >> sh) + ((xt * 16) >> sh)) * 16);
-                    ys[0] += bf16_to_f32((bf16_t)(tv.x & 0xffff)); ys[1] += bf16_to_f32((bf16_t)(tv.x >> 16));
-                    ys[2] += bf16_to_f32((bf16_t)(tv.y & 0xffff)); ys[3] += bf16_to_f32((bf16_t)(tv.y >> 16));
-                }
-                if (!HEAD) {
-                    const unsigned q0 = relu_pk(pack2(ys[0], ys[1])), q1 = relu_pk(pack2(ys[2], ys[3]));
-                    if (live) *(u32x2*)((char*)(ex->ysum + rowpix * 16) + (opaque_u32(st_16) + (unsigned)(xt * 16 * 32))) = u32x2{q0, q1};
-                } else {
-                    float part = relu_f32(ys[0]) * hw4[0];
-                    part = fmaf(relu_f32(ys[1]), hw4[1], part);
-                    part = fmaf(relu_f32(ys[2]), hw4[2], part);
-                    part = fmaf(relu_f32(ys[3]), hw4[3], part);
-                    // sum over the pixel's 4 lane groups on the matrix pipe (exact fp32): D[0][n] = sum_g 1 * part(n, g)
-                    const f32x4 hd = __builtin_amdgcn_mfma_f32_16x16x4f32(head_one, part, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const float hv = hd[0] + ex->hbias;
-                    if (live && g == 0) {
-                        const long long e = (long long)gy * W + gx;      // the band walk is column-group major: ties need the index test
-                        ex->heat[(size_t)b * H * W + e] = hv;
-                        if (hv > best->v || (hv == best->v && e < best->i) || (hv != hv && (best->v == best->v || e < best->i))) { best->v = hv; best->i = e; }
-                    }
-                }
-            } else if constexpr (CAN_SUM) {
+            if constexpr (CAN_SUM) {
                 if (ex && (ex->nsum > 0 || ex->heat)) {
                     // fuse-layer sum on the rounded block output, exactly what the element-wise pass read back from memory
                     float ys[4] = {bf16_to_f32((bf16_t)(pk[0] & 0xffff)), bf16_to_f32((bf16_t)(pk[0] >> 16)),
@@ -2307,9 +2254,11 @@ __global__ __launch_bounds__(512) void bb_chain_kernel(BBArgs a) {
     }
 }
 
-// One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU).
-// Used for the C=16 two-block chains, where the persistent variant's prefetch registers cost an occupancy step.
-template <int C, int TH, int TW, int MODE>
+// One tile per workgroup, weights straight from L2 into registers (lowest register footprint: two workgroups per CU): the C=16 two-block
+// chain with its fuse-sum / head epilogue configured at RUN time -- the fallback for term layouts other than HRNet's and the cross-check
+// (TTUP_BB2_GENERIC=1) of c16_chain_kernel (csrc/chain16.h), which carries the forms the network uses and superseded this kernel's
+// compiled-out variants in round 6.
+template <int C, int TH, int TW>
 __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
     constexpr int L = 4;
     constexpr int R0H = TH + 2 * L, R0W = TW + 2 * L;
@@ -2399,30 +2348,7 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     int tunit = -1;
     BBTermLds tlds;
     tlds.s_terms = s_terms;
-    tlds.hw4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (C == 16 && MODE == 7) tlds.hw4 = *(const f32x4*)(a.hw + (lane >> 4) * 4);      // head weights of the lane's 4 channels: in flight during conv3
-    if (C == 16 && MODE == 4) {
-        // plain chain: no fuse-layer terms
-    } else if (C == 16 && MODE > 0) {
-        // compiled-out form: term k has shift k + 1 (checked by the launcher), so a thread's term, slice pixel and LDS unit follow
-        // from its index with shifts alone; one branch-free load per thread (a unit outside the image reads the term's first bytes:
-        // it is only ever added to outputs that are not stored)
-        constexpr int NS = MODE == 7 ? 3 : MODE;
-        constexpr int B1 = (TH >> 1) * (TW >> 1) * 2, B2 = B1 + (TH >> 2) * (TW >> 2) * 2, B3 = B2 + (TH >> 3) * (TW >> 3) * 2;
-        constexpr int BN = NS == 1 ? B1 : NS == 2 ? B2 : B3;
-        const int k = tid < B1 ? 0 : tid < B2 ? 1 : 2, sh = k + 1;
-        const int u = tid - (k == 0 ? 0 : k == 1 ? B1 : B2);
-        const int px = u >> 1;
-        // row / column of the slice pixel: division by the (compile-time) slice width of the thread's term
-        const int pr = k == 0 ? px / (TW >> 1) : k == 1 ? px / (TW >> 2) : px / (TW >> 3);
-        const int pc = px - pr * (TW >> sh);
-        const int ty = (oy0 >> sh) + pr, tx = (ox0 >> sh) + pc;
-        const int hs = a.H >> sh, ws = a.W >> sh;
-        const bf16_t* tp = k == 0 ? a.st[0] : k == 1 ? a.st[1] : a.st[2];
-        const bool ok = tid < BN && ty < hs && tx < ws;
-        treg = *(const u32x4*)(ok ? tp + ((long long)(b * hs + ty) * ws + tx) * 16 + (u & 1) * 8 : a.st[0]);
-        tunit = tid < BN ? tid : -1;
-    } else if (C == 16) {
+    if (C == 16) {
         int base = 0;                 // in 16-byte units (two per pixel)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -2447,33 +2373,12 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
     __syncthreads();
     TTUP_STAMP(5);
     BBBest best; best.v = -INFINITY; best.i = 0x7fffffffffffffffLL;
-    bb_conv<C, R0W - 6, 0, TH, TW, true, SA, 4, true, 1, 0, MODE>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
+    bb_conv<C, R0W - 6, 0, TH, TW, true, SA, 4, true, 1, 0>(bufB, nullptr, bufA, a.w[3], a.bias[3], a.y, oy0, ox0, a.H, a.W, b, wave, lane,
                                                                    nullptr, nullptr, nullptr, &a, &best, pre, &tlds, idm);
 #ifdef TTUP_TIMING_SPLIT
     TTUP_STAMP(6);
 #endif
-    if (C == 16 && MODE == 7) {
-        // argmax partial of this tile.  (value, index) pairs become one 64-bit key -- order-preserving bits of the value (NaN on
-        // top, -0 = +0 as torch.argmax has it) above the complemented index -- so that "greater value, then lower index" is an
-        // unsigned max: 4 DPP row shifts over the 16 lanes that hold heatmap values, one LDS slot per wave (behind the tile
-        // buffers: no barrier before writing it), one barrier, 3 more shifts in wave 0.
-        unsigned long long key = 0ull;           // below every real key
-        if (lane < 16 && best.i != 0x7fffffffffffffffLL) key = bb_key(best.v, (int)best.i);
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) { const unsigned long long o = bb_dpp_shl(key, off); key = o > key ? o : key; }
-        unsigned long long* slots = (unsigned long long*)(smem + (size_t)(SZ_A + SZ_B) * 2);
-        if (lane == 0) slots[wave] = key;
-        __syncthreads();
-        if (wave == 0) {
-            key = lane < 8 ? slots[lane] : 0ull;
-#pragma unroll
-            for (int off = 4; off >= 1; off >>= 1) { const unsigned long long o = bb_dpp_shl(key, off); key = o > key ? o : key; }
-            if (lane == 0) {
-                a.pv[(size_t)b * a.tiles_per_img + tt] = bb_key_value(key);
-                a.pi[(size_t)b * a.tiles_per_img + tt] = (long long)(~(unsigned)key);
-            }
-        }
-    } else if (C == 16 && MODE == 0 && a.heat) {
+    if (C == 16 && a.heat) {
         // run-time form: lanes -> wave (shuffles) -> workgroup (through the now idle LDS)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -2499,18 +2404,18 @@ __global__ __launch_bounds__(512, 4) void bb_chain2_kernel(BBArgs a) {       // 
 #endif
 }
 
-template <int C, int TH, int TW, int MODE>
+template <int C, int TH, int TW>
 static int launch_bb2_t(const BBArgs& a, int batch, int h, int w, hipStream_t st) {
     constexpr int SA = ((TW + 8) & 1) ? TW + 8 : TW + 9, SB = ((TW + 6) & 1) ? TW + 6 : TW + 7;       // odd row strides, as in the kernel
     constexpr size_t SMEM = (size_t)((TH + 8) * SA + (TH + 6) * SB) * C * 2 + 64;       // + one argmax slot per wave
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert(2 * SMEM <= 160 * 1024 || TH * TW > 24 * 32, "the 24x32 tile runs two workgroups per CU");
-    if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW, MODE>, SMEM)) return rc;
+    if (int rc = ensure_max_lds((const void*)bb_chain2_kernel<C, TH, TW>, SMEM)) return rc;
     BBArgs k = a;
     k.H = h; k.W = w; k.tiles_x = cdiv(w, TW); k.tiles_per_img = k.tiles_x * cdiv(h, TH); k.total_tiles = k.tiles_per_img * batch;
     if (k.total_tiles == 0) return TTUP_OK;
-    kernel_note("bb_chain2_kernel<%d, %d, %d, %d>", C, TH, TW, MODE);
-    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW, MODE>), dim3(k.tiles_x, cdiv(h, TH), batch), dim3(512), SMEM, st, k);
+    kernel_note("bb_chain2_kernel<%d, %d, %d>", C, TH, TW);
+    hipLaunchKernelGGL((bb_chain2_kernel<C, TH, TW>), dim3(k.tiles_x, cdiv(h, TH), batch), dim3(512), SMEM, st, k);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
 }
@@ -2575,33 +2480,25 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
     }
     // tile shapes tuned on MI355X: larger tiles amortise the per-tile overhead and waste fewer ragged 16-pixel MFMA groups
     if (c == 16 && n_convs == 4) {
-        // the epilogue forms the network uses are compiled out (MODE of bb_conv); anything else takes the run-time form
+        // the epilogue forms the network uses are compiled out in c16_chain_kernel (csrc/chain16.h); anything else -- other term layouts,
+        // TTUP_BB2_GENERIC=1 (read once per process), other -DTTUP_BB2_TH/TW tiles -- takes the run-time form (bb_chain2_kernel)
         static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
 #ifdef TTUP_ABL_EPI4
-        return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
+        return launch_c16_t<24, 32, 4>(a, batch, h, w, st);
 #endif
-        bool shifts_ok = true;          // the compiled-out forms assume term k at 1/2^(k+1) resolution (HRNet's fuse layers)
-        for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
-        const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.ysum && !a.heat;      // a.y (the pre-fuse tensor) optional
-        const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
-        // TTUP_CHAIN16_OLD=1 (read once per process): the round-2..5 kernel with the same compiled-out epilogues, kept for A/B runs
-        static const bool old16 = getenv("TTUP_CHAIN16_OLD") != nullptr;
-        const bool plain = !generic && a.nsum == 0 && !a.heat && !a.ysum && a.y;
-        if constexpr (BB2_TH == 24 && BB2_TW == 32) {          // (c16_chain_kernel's work split is written for this tile; other -DTTUP_BB2_TH/TW experiments take the old kernel)
-            if (!old16) {
-                if (plain) return launch_c16_t<24, 32, 4>(a, batch, h, w, st);
-                if (tail) return launch_c16_t<24, 32, 7>(a, batch, h, w, st);
-                if (sum_stored && a.nsum == 1) return launch_c16_t<24, 32, 1>(a, batch, h, w, st);
-                if (sum_stored && a.nsum == 2) return launch_c16_t<24, 32, 2>(a, batch, h, w, st);
-                if (sum_stored && a.nsum == 3) return launch_c16_t<24, 32, 3>(a, batch, h, w, st);
-            }
+        if constexpr (BB2_TH == 24 && BB2_TW == 32) {
+            bool shifts_ok = true;          // the compiled-out forms assume term k at 1/2^(k+1) resolution (HRNet's fuse layers)
+            for (int k = 0; k < a.nsum && k < 3; ++k) shifts_ok = shifts_ok && a.ssh[k] == k + 1;
+            const bool sum_stored = !generic && shifts_ok && a.nsum >= 1 && a.nsum <= 3 && a.ysum && !a.heat;      // a.y (the pre-fuse tensor) optional
+            const bool tail = !generic && shifts_ok && a.nsum == 3 && a.heat && !a.y && !a.ysum;
+            const bool plain = !generic && a.nsum == 0 && !a.heat && !a.ysum && a.y;
+            if (plain) return launch_c16_t<24, 32, 4>(a, batch, h, w, st);
+            if (tail) return launch_c16_t<24, 32, 7>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 1) return launch_c16_t<24, 32, 1>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 2) return launch_c16_t<24, 32, 2>(a, batch, h, w, st);
+            if (sum_stored && a.nsum == 3) return launch_c16_t<24, 32, 3>(a, batch, h, w, st);
         }
-        if (plain) return launch_bb2_t<16, BB2_TH, BB2_TW, 4>(a, batch, h, w, st);
-        if (tail) return launch_bb2_t<16, BB2_TH, BB2_TW, 7>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 1) return launch_bb2_t<16, BB2_TH, BB2_TW, 1>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 2) return launch_bb2_t<16, BB2_TH, BB2_TW, 2>(a, batch, h, w, st);
-        if (sum_stored && a.nsum == 3) return launch_bb2_t<16, BB2_TH, BB2_TW, 3>(a, batch, h, w, st);
-        return launch_bb2_t<16, BB2_TH, BB2_TW, 0>(a, batch, h, w, st);
+        return launch_bb2_t<16, BB2_TH, BB2_TW>(a, batch, h, w, st);
     }
     if (c == 16 && n_convs == 2) return launch_bb_t<16, 1, 8, 32>(a, batch, h, w, st);
     if (c == 32 && n_convs == 2) {
