@@ -121,6 +121,9 @@ int ttup_wasb_read_tap(ttup_wasb* net, const char* name, int batch, float* out_d
 int ttup_wasb_time_ops(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, int* n_ops_out, void* stream);
 int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max_ops, float* ms_out, int* info_out, char* names_out,
                          int* n_ops_out, void* stream);
+/* time_replay: the same launches back to back, `reps` passes between one pair of events (none between the ops); ms_out[0] = average
+ * duration of a pass of the graph over one micro-batch (ABI 103). */
+int ttup_wasb_time_replay(ttup_wasb* net, int batch, int reps, float* ms_out, void* stream);
 /* measured peaks of the device (csrc/peaks.hip; SURVEY 8d "Peaks to divide by"), HIP events on `stream`, synchronises.
  * mfma: out_host[0..1] = TFLOP/s of register-resident v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16 loops on random
  * operands with `waves_per_simd` waves on every SIMD, [2..3] their durations (ms).

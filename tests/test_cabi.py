@@ -111,7 +111,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ttup_uplift_graph_info(None, out3) == _lib.EINVAL
     assert lib.ttup_uplift_stage_info(None, None) == _lib.EINVAL
     assert lib.ttup_wasb_set_certify(None, 0.1, 0, 0) == _lib.EINVAL
-    assert len(lib.ttup_build_id()) == 16 and lib.ttup_version() == 102
+    assert len(lib.ttup_build_id()) == 16 and lib.ttup_version() == 103
     with pytest.raises(ValueError):
         _lib.check(_lib.EINVAL)
     assert lib.ttup_refine_workspace_bytes(4, 704, 1280) >= 4 * 44

@@ -452,6 +452,25 @@ def test_fused_kernels_match_layerwise():
     assert (h1 - h2).abs().max().item() <= 2e-2 * scale, ((h1 - h2).abs().max().item(), scale)
 
 
+def test_graph_replay_timing_agrees_with_the_per_op_events():
+    """bench.py's whole-graph duration (ttup_wasb_time_replay: passes back to back between one pair of events) against the sum of the
+    per-op event intervals of ttup_wasb_time_graph: the same launches, so the replay lies below the sum (each interval carries an
+    event record) and not far below it; the heatmap of the pass is left intact by both."""
+    h, w, b = 288, 512, 4
+    sd = weights.random_wasb_state_dict(31)
+    net = wasb.WASBNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
+    x = torch.from_numpy(np.random.default_rng(31).standard_normal((b, 9, h, w)).astype(np.float32))
+    h0, i0, _ = net.forward(x, want_peaks=True)
+    ops = wasb.time_ops(net, reps=3)
+    ev_sum = sum(o['ms'] for o in ops)
+    rp = wasb.time_replay(net, reps=6)
+    assert 0 < rp <= ev_sum * 1.05 and rp >= 0.5 * ev_sum, (rp, ev_sum)
+    with pytest.raises(ValueError):
+        wasb.time_replay(net, batch=b, reps=0)
+    h1, i1, _ = net.forward(x, want_peaks=True)
+    assert torch.equal(h0, h1) and torch.equal(i0, i1)
+
+
 def test_conv64_fuse_followers_are_bit_identical():
     """The 64->16 / 64->32 fuse-layer convs riding in the last 64->64 conv's epilogue consume the bf16 values that conv stores
     (same K products, the accumulator-order K permutation only reorders an fp32 sum of 64 terms): heatmaps within one bf16 step

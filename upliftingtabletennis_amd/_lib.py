@@ -29,6 +29,7 @@ SIGNATURES = {
     'ttup_wasb_read_tap': (_i, [_vp, _c.c_char_p, _i, _vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _vp]),
     'ttup_wasb_time_ops': (_i, [_vp, _i, _i, _i, _vp, _vp, _c.POINTER(_i), _vp]),
     'ttup_wasb_time_graph': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _c.POINTER(_i), _vp]),
+    'ttup_wasb_time_replay': (_i, [_vp, _i, _i, _vp, _vp]),
     'ttup_peak_mfma_bf16': (_i, [_i, _i, _vp, _vp]),
     'ttup_peak_hbm': (_i, [_sz, _vp, _vp]),
     'ttup_wasb_set_certify': (_i, [_vp, _c.c_float, _i, _i]),

@@ -64,7 +64,7 @@ int device_normalise_lut(const float** lut_dev) {
 #ifndef TTUP_BUILD_ID
 #error "TTUP_BUILD_ID is not defined: build with `python -m upliftingtabletennis_amd.build` (it hashes the sources into the library)"
 #endif
-extern "C" int ttup_version(void) { return 102; }      // 102 (round 6): ttup_wasb_certify_audit_crops, certify_stats copies twelve counters, up to 32 crops per heatmap
+extern "C" int ttup_version(void) { return 103; }      // 102 (round 6): ttup_wasb_certify_audit_crops, certify_stats copies twelve counters, up to 32 crops per heatmap; 103: ttup_wasb_time_replay
 extern "C" const char* ttup_build_id(void) { return TTUP_BUILD_ID; }
 extern "C" const char* ttup_last_error(void) { return ttup::get_error(); }
 extern "C" int ttup_device_count(void) {

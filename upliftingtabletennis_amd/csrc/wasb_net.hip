@@ -909,6 +909,33 @@ extern "C" int ttup_wasb_time_graph(ttup_wasb* net, int batch, int reps, int max
     return rc;
 }
 
+// The same launches back to back, `reps` passes between ONE pair of events (no event between the ops: an event record between two
+// kernels is a packet of its own on the queue, and the per-op intervals of ttup_wasb_time_graph each include one).  ms_out[0] = the
+// average duration of a pass: what one lane of the pipeline spends on a micro-batch.
+extern "C" int ttup_wasb_time_replay(ttup_wasb* net, int batch, int reps, float* ms_out, void* stream) {
+    TTUP_REQUIRE(net && ms_out, TTUP_EINVAL, "ttup_wasb_time_replay: null pointer");
+    TTUP_REQUIRE(batch > 0 && batch <= net->micro && reps > 0, TTUP_EINVAL, "ttup_wasb_time_replay: batch must be in [1,%d]", net->micro);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    TTUP_HIP_CHECK(hipEventCreate(&e0));
+    TTUP_HIP_CHECK(hipEventCreate(&e1));
+    int rc = TTUP_OK;
+    net->use_lane(0);
+    for (int r = -1; r < reps && rc == TTUP_OK; ++r) {          // pass -1 = warm-up
+        if (r == 0) (void)hipEventRecord(e0, st);
+        for (const Op& op : net->ops) {
+            rc = (op.kind == Op::UPSUM_HEAD || op.head) ? run_head_op(net, batch, net->heat_scratch, net->argmax_scratch, net->win_scratch, st) : run_op(net, op, batch, st);
+            if (rc != TTUP_OK) break;
+        }
+    }
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (rc == TTUP_OK) { (void)hipEventElapsedTime(&ms, e0, e1); ms_out[0] = ms / reps; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
 extern "C" int ttup_preprocess_triples(const uint8_t* frames_dev, int n_frames, int src_h, int src_w, int dst_h, int dst_w,
                                        float* out_dev, void* stream) {
     TTUP_REQUIRE(frames_dev && out_dev, TTUP_EINVAL, "ttup_preprocess_triples: null pointer");

@@ -471,6 +471,20 @@ def slice_columns(x, x0, w):
     return out
 
 
+def time_replay(net, batch=None, reps=10):
+    """Milliseconds per pass of the CNN graph over one micro-batch: `reps` passes launched back to back on the current stream between
+    ONE pair of HIP events inside the library (ttup_wasb_time_replay) -- no event between the ops, unlike time_ops(in_graph=True),
+    whose per-op intervals each carry an event record."""
+    import numpy as _np
+    lib = net._lib
+    micro = lib.ttup_wasb_micro_batch(net._handle)
+    batch = micro if batch is None else min(batch, micro)
+    ms = _np.zeros(1, _np.float32)
+    with torch.cuda.device(net.device):
+        _lib.check(lib.ttup_wasb_time_replay(net._handle, batch, int(reps), ms.ctypes.data_as(ctypes.c_void_p), _lib.stream_ptr()))
+    return float(ms[0])
+
+
 _OP_KINDS = {0: 'conv', 1: 'upsum', 2: 'bneck_trans', 3: 'bb_chain', 4: 'stem', 5: 'upsum_head'}
 
 
