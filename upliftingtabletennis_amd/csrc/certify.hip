@@ -453,7 +453,9 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     // the scan reads float4 quads of whole heatmaps; a crop is exact only when its (clamped) origin is a multiple of 8
     TTUP_REQUIRE(((long long)net->H * net->W) % 4 == 0 && (net->H - c.Hc) % 8 == 0 && (net->W - c.Wc) % 8 == 0, TTUP_EINVAL,
                  "ttup_wasb_set_certify: %dx%d heatmaps with %dx%d crops cannot be certified (H*W %% 4, (H-Hc) %% 8, (W-Wc) %% 8 must be 0)", net->H, net->W, c.Hc, c.Wc);
-    c.CH = net->max_batch < 64 ? net->max_batch : 64;
+    static const int env_ch = getenv("TTUP_CERT_CH") ? atoi(getenv("TTUP_CERT_CH")) : 0;          // crops per fp32 pass (experiment knob, read once)
+    const int ch_cap = env_ch >= 8 && env_ch <= 512 ? env_ch : 128;          // 128 against 64: varied content +1.7 %, parity mode and noise weights +1.1 % (fewer, fuller passes; round 6)
+    c.CH = net->max_batch < ch_cap ? net->max_batch : ch_cap;
     const int per_map = env_list > 0 && env_list <= 16 ? env_list : 4;
     c.max_crops = per_map * net->max_batch > c.CH ? per_map * net->max_batch : c.CH;   // capacity of the call's crop list: four per heatmap on average; the overflow is flagged
     if (c.max_crops < c.maxf) c.max_crops = c.maxf;          // ... and never less than ONE frame may ask for (one-sample handles: re-certification of single frames, round-4 advisor)
