@@ -470,6 +470,9 @@ def extras(device):
         for _ in range(2):
             pn.step()
         torch.cuda.synchronize()
+        # counters of the timed region only: the first warm-up clip runs on the default crop budget (one crop per heatmap) before
+        # the worker has seen what this content asks for, and sends what does not fit to the full-frame fp32 path
+        cs_warm, reruns_warm = pn.net.certify_stats(reset=True), pn.worker.fp32_reruns
         k = 4
         t0 = time.perf_counter()
         tk = None
@@ -484,9 +487,13 @@ def extras(device):
         cs, au = pn.net.certify_stats(), pn.worker.audit
         out['noise_weights_fps'] = {'value': round(TRIPLES / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2),
                                     'config': 'the headline workload on seeded NOISE weights (weights.random_wasb_state_dict(0, planted=False)), certified argmax on',
-                                    'eps_abs': round(au['eps'], 6), 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3),
+                                    'eps_abs': round(au['eps'], 6), 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3), 'small_core_crop_share': round(cs['small_crops'] / max(1, cs['crops']), 3),
                                     'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
-                                    'fp32_full_frame_reruns': pn.worker.fp32_reruns, 'max_err_over_eps': round(au['max_err_over_eps'], 4)}
+                                    'fp32_full_frame_reruns': pn.worker.fp32_reruns - reruns_warm, 'max_err_over_eps': round(au['max_err_over_eps'], 4),
+                                    'not_certified_causes': {'candidate_list': cs['over_candidates'], 'crops_per_heatmap': cs['over_crops_per_map'], 'crop_list': cs['over_crop_list']},
+                                    'counters': 'timed region only (%d heatmaps)' % cs['heatmaps'],
+                                    'warmup': {'heatmaps': cs_warm['heatmaps'], 'not_certified': cs_warm['not_certified'], 'fp32_full_frame_reruns': reruns_warm,
+                                               'note': 'two warm-up steps; the first one runs on the default crop budget of one crop per heatmap'}}
         del pn
         torch.cuda.empty_cache()
     except Exception as e:          # the regime leg must not take the headline line down
@@ -515,7 +522,7 @@ def extras(device):
         out['exact_windows_fps'] = {'value': round(TRIPLES / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2),
                                     'config': 'the headline workload in parity mode (StreamWorker(exact_windows=True) / TTUP_EXACT_WINDOWS=1): an fp32 crop for EVERY heatmap, '
                                               'all 3x3 windows in fp32',
-                                    'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
+                                    'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3), 'small_core_crop_share': round(cs['small_crops'] / max(1, cs['crops']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
                                     'fp32_full_frame_reruns': pe.worker.fp32_reruns}
         del pe
         torch.cuda.empty_cache()
@@ -650,7 +657,7 @@ def extras(device):
         pv.worker.margin_log = None
         out['varied_content_fps'] = {'value': round(TRIPLES / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt * 1e3, 2),
                                      'config': 'the headline pipeline and weights on four alternating clips: blob sigma 1.3 / 2 / 3 / 4 px, brightness gain 0.7 / 1.0 / 1.3 / 1.6, own background and noise each',
-                                     'eps_abs': round(au['eps'], 6), 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3),
+                                     'eps_abs': round(au['eps'], 6), 'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3), 'small_core_crop_share': round(cs['small_crops'] / max(1, cs['crops']), 3),
                                      'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
                                      'eps_widened': au['widened'] - au0['widened'], 'recertified_clips': au['recertified_clips'] - au0['recertified_clips'],
                                      'recertified_heatmaps': au['recertified_heatmaps'] - au0['recertified_heatmaps'],

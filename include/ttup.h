@@ -186,13 +186,14 @@ int ttup_wasb_certify_flags(ttup_wasb* net, int batch, int* flags_dev, void* str
 int ttup_wasb_certify_margins(ttup_wasb* net, int batch, float* margin_dev, void* stream);
 /* crops the following forward calls may use (default: max_batch, i.e. one per heatmap): the call enqueues ceil(budget / 64) fp32
  * passes sized on the device, so a caller that knows its typical crop count (stats / status of earlier calls) saves the empty
- * passes; heatmaps beyond the budget are flagged 2 */
+ * passes; heatmaps beyond the budget are flagged 2 (64: 128 since ABI 103, TTUP_CERT_CH) */
 int ttup_wasb_certify_budget(ttup_wasb* net, int max_crops);
 /* running counters of the handle since creation / the last reset, copied to TWELVE long longs on the host (synchronises): [0] heatmaps,
  * [1] single candidate, [2] resolved on fp32 crops, [3] not certified (= [8] + [9] + [10]), [4] crops, [5] candidates of the resolved
  * heatmaps, [6] low word = bits of the largest |bf16 - fp32| seen at a candidate, [7] single-candidate heatmaps that got a crop
  * (exact-window mode / audit crops), [8] not certified: candidate list overflow, [9]: more crops than one heatmap / frame may add,
- * [10]: the call's crop list was full, [11] reserved.  (ABI version 100 copied eight.) */
+ * [10]: the call's crop list was full, [11] crops of class 2 among [4] (candidates within a 14-position core: pruned to a smaller cone;
+ * ABI 103).  (ABI version 100 copied eight.) */
 int ttup_wasb_certify_stats(ttup_wasb* net, long long* out_host12, int reset);
 /* scheduling priority of the handle's internal streams (high != 0: greatest device priority); synchronises */
 int ttup_wasb_set_priority(ttup_wasb* net, int high);

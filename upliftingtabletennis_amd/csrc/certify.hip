@@ -62,14 +62,16 @@ struct PlanArgs {
     int K, maxc, max_crops, H, W, Hc, Wc, R, frame0, exact;
     int C, maxf;          // heatmap channels per frame (1 ball, 13 table keypoints) and crops a frame may use in all
     int audit_mod, audit_phase;          // audit crops (ttup_wasb_certify_audit_crops): 0 = off
+    int small;                           // class-2 crops (conv.h Roi): valid core positions R + 1 .. R + small of a crop whose candidates all fit there; 0 = off
     const int* guard_cnt;
     float* margin;
 };
 
 // valid core of a crop along one axis: positions whose value AND 3x3 neighbourhood are exact
-__device__ __forceinline__ void core_range(int o, int c, int full, int R, int& lo, int& hi) {
+// (small > 0: a class-2 crop, pruned to the cone of the positions R + 1 .. R + small: only those are exact)
+__device__ __forceinline__ void core_range(int o, int c, int full, int R, int small, int& lo, int& hi) {
     lo = (o == 0) ? 0 : o + R + 1;
-    hi = (o + c == full) ? full : o + c - R - 1;
+    hi = (o + c == full) ? full : (small > 0 ? o + R + 1 + small : o + c - R - 1);
 }
 
 // ---- 2. one workgroup (one wave) per FRAME, its C heatmaps (channels) in turn: the wave sorts a heatmap's candidates by index (the
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
     __shared__ int s_idx[CERT_MAX_K];            // as scanned, then the crop slot of every sorted candidate
     __shared__ float s_bf[CERT_MAX_K];
     __shared__ int s_sorted[CERT_MAX_K];
-    __shared__ int my_y0[CERT_MAX_FRAME_CROPS], my_x0[CERT_MAX_FRAME_CROPS];
+    __shared__ int my_y0[CERT_MAX_FRAME_CROPS], my_x0[CERT_MAX_FRAME_CROPS], my_small[CERT_MAX_FRAME_CROPS];
     __shared__ int n_my_s, s_base;
     constexpr int PER = CERT_MAX_K / 64;         // candidates per lane
     const int lane = threadIdx.x;
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         while (true) {
             for (int c = c_from; c < n_my; ++c) {
                 int ylo, yhi, xlo, xhi;
-                core_range(my_y0[c], a.Hc, a.H, a.R, ylo, yhi);
-                core_range(my_x0[c], a.Wc, a.W, a.R, xlo, xhi);
+                core_range(my_y0[c], a.Hc, a.H, a.R, my_small[c], ylo, yhi);
+                core_range(my_x0[c], a.Wc, a.W, a.R, my_small[c], xlo, xhi);
 #pragma unroll
                 for (int m = 0; m < PER; ++m)
                     if (found[m] < 0 && cy[m] >= ylo && cy[m] < yhi && cx[m] >= xlo && cx[m] < xhi) found[m] = c;
@@ -172,18 +174,23 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
                     if (nxhi - nxlo >= span_x) continue;
                     xlo = nxlo; xhi = nxhi; yhi = yj;
                 }
-                auto origin = [](int c, int crop, int full) {
-                    int o = ((c - crop / 2 + 4) >> 3) << 3;
+                // Class 2 (round 6): a cluster that fits a core of a.small positions with the same rounding slack (span <= small - 8)
+                // -- every single candidate does -- is centred on the core R + 1 .. R + small instead of the crop's centre; its fp32 pass
+                // is pruned to the cone of THAT core, which ends 8 pixels short of the crop's last row / column (conv.h Roi).
+                const int sm = (a.small > 0 && yhi - ylo <= a.small - 8 && xhi - xlo <= a.small - 8) ? a.small : 0;
+                const int mid = sm ? a.R + 1 + sm / 2 : -1;          // crop position of the cluster's centre (-1: the crop's own centre)
+                auto origin = [mid](int c, int crop, int full) {
+                    int o = ((c - (mid < 0 ? crop / 2 : mid) + 4) >> 3) << 3;
                     return o < 0 ? 0 : (o > full - crop ? full - crop : o);
                 };
                 int y0 = origin((ylo + yhi) / 2, a.Hc, a.H), x0 = origin((xlo + xhi) / 2, a.Wc, a.W);
                 {
                     int cylo, cyhi, cxlo, cxhi;
-                    core_range(y0, a.Hc, a.H, a.R, cylo, cyhi);
-                    core_range(x0, a.Wc, a.W, a.R, cxlo, cxhi);
-                    if (!(fy >= cylo && fy < cyhi && fx >= cxlo && fx < cxhi)) { y0 = origin(fy, a.Hc, a.H); x0 = origin(fx, a.Wc, a.W); }      // (cannot happen for spans < 15; kept as a guard)
+                    core_range(y0, a.Hc, a.H, a.R, sm, cylo, cyhi);
+                    core_range(x0, a.Wc, a.W, a.R, sm, cxlo, cxhi);
+                    if (!(fy >= cylo && fy < cyhi && fx >= cxlo && fx < cxhi)) { y0 = origin(fy, a.Hc, a.H); x0 = origin(fx, a.Wc, a.W); }      // (cannot happen for spans < 15 / small - 7; kept as a guard)
                 }
-                my_y0[n_my] = y0; my_x0[n_my] = x0;
+                my_y0[n_my] = y0; my_x0[n_my] = x0; my_small[n_my] = sm;
             }
             ++n_my;
             __syncthreads();
@@ -203,9 +210,14 @@ __global__ __launch_bounds__(64) void cert_plan_kernel(PlanArgs a) {
         s_base = base;
         for (int c = 0; c < n_my && base + c < a.max_crops; ++c) {          // (records also for a list that fills up half way: the slots are run)
             int* rec = a.crop_rec + 4 * (base + c);
-            rec[0] = frame; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = 0;
+            rec[0] = frame; rec[1] = my_y0[c]; rec[2] = my_x0[c]; rec[3] = my_small[c] > 0 ? 1 : 0;
         }
         if (!(base + n_my > a.max_crops)) atomicAdd(&a.stats[4], (unsigned long long)n_my);
+        if (!(base + n_my > a.max_crops)) {
+            int ns = 0;
+            for (int c = 0; c < n_my; ++c) ns += my_small[c] > 0;
+            if (ns) atomicAdd(&a.stats[11], (unsigned long long)ns);
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -242,7 +254,7 @@ __global__ void cert_active_kernel(const int* n_crops, int* n_active, int CH, in
     // region for the flagged samples only)
     for (int j = 0; j < v; ++j) {
         const int* rec = crop_rec + 4 * (c * CH + j);
-        roi_flag[c * CH + j] = (rec[1] <= 0 || rec[2] <= 0 || rec[1] + Hc >= H || rec[2] + Wc >= W) ? 0 : 1;
+        roi_flag[c * CH + j] = (rec[1] <= 0 || rec[2] <= 0 || rec[1] + Hc >= H || rec[2] + Wc >= W) ? 0 : (rec[3] ? 2 : 1);
     }
 }
 
@@ -369,6 +381,7 @@ int cert_scan(ttup_wasb* net, const float* heat, const long long* argmax, int b0
     a.status = sl.status; a.stats = c.stats; a.cand_bf = sl.cand_bf; a.K = c.K; a.maxc = c.maxc; a.max_crops = c.budget;
     a.H = net->H; a.W = net->W; a.Hc = c.Hc; a.Wc = c.Wc; a.R = c.R; a.frame0 = b0; a.C = C; a.maxf = c.maxf; a.exact = c.exact_windows ? 1 : 0; a.guard_cnt = sl.guard_cnt; a.margin = sl.margin;
     a.audit_mod = c.audit_mod; a.audit_phase = c.audit_phase;
+    a.small = c.small;
     hipLaunchKernelGGL(cert_plan_kernel, dim3(mb), dim3(64), 0, st, a);
     TTUP_LAUNCH_CHECK();
     return TTUP_OK;
@@ -443,11 +456,15 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     (void)hipDeviceSynchronize();
     cert_free(net);
     c.eps = eps_abs;
+    c.small = 0;
     static const int env_maxc = getenv("TTUP_CERT_MAXC") ? atoi(getenv("TTUP_CERT_MAXC")) : 0, env_list = getenv("TTUP_CERT_LIST") ? atoi(getenv("TTUP_CERT_LIST")) : 0;
     c.maxc = max_crops_per_map > 0 ? max_crops_per_map : (env_maxc > 0 && env_maxc <= CERT_MAX_FRAME_CROPS ? env_maxc : 8);
     c.maxf = c.maxc * net->n_out < CERT_MAX_FRAME_CROPS ? c.maxc * net->n_out : CERT_MAX_FRAME_CROPS;      // the channels of a frame share its crops
-    int side = crop > 0 ? crop : 168;
-    TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 24, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 24);
+    // Crop side: 2 R + the core.  The origin of a crop is a multiple of 8 (the 1/8-resolution branch), so a crop centred on a candidate
+    // has it within 4 pixels of its centre: the core must hold 8 positions + the 3x3 window = 2 R + 16 at least.
+    static const int env_crop = getenv("TTUP_CERT_CROP") ? atoi(getenv("TTUP_CERT_CROP")) : 0;          // experiment knob, read once
+    int side = crop > 0 ? crop : (env_crop > 0 ? env_crop : 168);
+    TTUP_REQUIRE(side % 8 == 0 && side >= 2 * c.R + 16, TTUP_EINVAL, "ttup_wasb_set_certify: crop %d must be a multiple of 8 and at least %d", side, 2 * c.R + 16);
     c.Hc = side < net->H ? side : net->H;
     c.Wc = side < net->W ? side : net->W;
     // the scan reads float4 quads of whole heatmaps; a crop is exact only when its (clamped) origin is a multiple of 8
@@ -499,7 +516,11 @@ extern "C" int ttup_wasb_set_certify(ttup_wasb* net, float eps_abs, int crop, in
     // heatmap rows / columns [R, side - R) are ever read (lookup kernel), and every layer only has to produce what those depend on
     static const bool no_cone = getenv("TTUP_NO_CONE") != nullptr || getenv("TTUP_F32_EXACT") != nullptr || getenv("TTUP_F32_DIRECT") != nullptr;
     if (!no_cone && c.Hc == c.Wc && c.Hc > 2 * c.R + 2 && c.Hc < net->H && c.Wc < net->W) {
-        const int rc2 = compute_roi(c.cropnet, c.R, c.Hc - c.R);
+        // class 2: a 16-pixel heatmap region (14 candidate positions + their 3x3 windows) at the crop's corner-aligned end of the core
+        // range -- its cone is the crop's first 160 rows / columns, i.e. one 16-pixel tile row / column less in the full-resolution layers
+        static const bool no_small = getenv("TTUP_CERT_SMALL") != nullptr && atoi(getenv("TTUP_CERT_SMALL")) == 0;
+        c.small = (!no_small && c.Hc >= 2 * c.R + 24) ? 14 : 0;
+        const int rc2 = compute_roi(c.cropnet, c.R, c.Hc - c.R, c.R, c.small ? c.R + c.small + 2 : c.R);
         if (rc2) { cert_free(net); return rc2; }
     }
     c.enabled = true;

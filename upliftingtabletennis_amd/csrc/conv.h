@@ -28,7 +28,19 @@ struct PackedConv {
 // Part of a tensor that an op has to produce: rows [y0, y1), columns [x0, x1) of sample b, applied only where flag[b] != 0 (device
 // memory, one int per sample of the pass).  The fp32 crop net of the certified argmax is pruned to the cone of its 24-pixel core (csrc/wasb_net.hip compute_roi): a
 // kernel may compute any superset of the region -- what lies outside is never read by an op that matters.  flag == nullptr: no pruning.
-struct Roi { int y0 = 0, y1 = 0, x0 = 0, x1 = 0; const int* flag = nullptr; };
+// Two classes of pruned samples (round 6): flag[b] == 1 -> [y0, y1) x [x0, x1) (crops with the 24-pixel core), flag[b] == 2 -> the `s`
+// rectangle (crops whose candidates fit a 16-pixel core in the crop's corner-aligned 160 x 160 part: one 16-pixel tile column / row
+// less in every full-resolution layer).
+struct Roi {
+    int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+    int sy0 = 0, sy1 = 0, sx0 = 0, sx1 = 0;          // class 2 (sy1 == 0: same as class 1)
+    const int* flag = nullptr;
+    // true when pixel (y, x) of a sample with flag value f (!= 0) lies outside what the op has to produce
+    __host__ __device__ bool outside(int f, int y, int x) const {
+        if (f == 2 && sy1 > 0) return y < sy0 || y >= sy1 || x < sx0 || x >= sx1;
+        return y < y0 || y >= y1 || x < x0 || x >= x1;
+    }
+};
 
 struct ConvLaunch {
     const void* src0 = nullptr;   // NHWC, c0 channels

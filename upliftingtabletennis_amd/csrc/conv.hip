@@ -2749,7 +2749,7 @@ __global__ void upsum_kernel(UpsumArgs a) {
         const int x = (int)(p % a.W); p /= a.W;
         const int y = (int)(p % a.H);
         const int b = (int)(p / a.H);
-        if (a.roi.flag && a.roi.flag[b] != 0 && (y < a.roi.y0 || y >= a.roi.y1 || x < a.roi.x0 || x >= a.roi.x1)) continue;
+        if (a.roi.flag) { const int f = a.roi.flag[b]; if (f != 0 && a.roi.outside(f, y, x)) continue; }
         float v = ld((const T*)a.base + i);
         for (int k = 0; k < a.n; ++k) {
             const int sh = a.shift[k], hh = a.H >> sh, ww = a.W >> sh;
@@ -2860,7 +2860,8 @@ __global__ void head_kernel(const T* src, const float* w, const float* bias, int
         if (roi.flag) {
             const long long bq = i / hw, rem = i - bq * hw;
             const int y = (int)(rem / W), xq = (int)(rem % W);
-            if (roi.flag[bq] != 0 && (y < roi.y0 || y >= roi.y1 || xq < roi.x0 || xq >= roi.x1)) continue;
+            const int f = roi.flag[bq];
+            if (f != 0 && roi.outside(f, y, xq)) continue;
         }
         float x[CIN];
 #pragma unroll

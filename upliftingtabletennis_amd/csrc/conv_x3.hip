@@ -35,6 +35,7 @@ struct ConvX3Args {
     const int* n_active;
     // cone pruning (conv.h Roi): of a sample b with roi_flag[b] != 0 only the tiles [r_ty0, r_ty0 + r_nty) x [r_tx0, r_tx0 + r_ntx) are produced
     const int* roi_flag; int r_ty0, r_tx0, r_nty, r_ntx;
+    int s_ty0, s_tx0, s_nty, s_ntx;          // the tile range of the samples with roi_flag[b] == 2 (conv.h Roi, class 2)
 };
 
 // The operand split is fp32 vector arithmetic (v - hi parts) that the compiler turns into `v_pk_add_f32 ... neg_lo neg_hi` -- packed
@@ -109,8 +110,10 @@ __global__ __launch_bounds__(NW * 64) void conv_x3_kernel(ConvX3Args a) {
         if (!a.roi_flag) return false;
         const int tl = blockIdx.x + (item / nchunk) * gridDim.x;
         const int b = tl / tiles_per_img, t = tl % tiles_per_img;
-        if (a.roi_flag[b] == 0) return false;
+        const int f = a.roi_flag[b];
+        if (f == 0) return false;
         const int ty = t / tiles_x, tx = t % tiles_x;
+        if (f == 2) return ty < a.s_ty0 || ty >= a.s_ty0 + a.s_nty || tx < a.s_tx0 || tx >= a.s_tx0 + a.s_ntx;
         return ty < a.r_ty0 || ty >= a.r_ty0 + a.r_nty || tx < a.r_tx0 || tx >= a.r_tx0 + a.r_ntx;
     };
     auto next_item = [&](int item) {          // first item >= `item` that is not skipped (all chunks of a tile share the decision)
@@ -317,6 +320,13 @@ int launch_x3(const PackedConv& p, const ConvLaunch& l, hipStream_t st) {
                      "conv x3: output region [%d,%d)x[%d,%d) outside %dx%d", l.roi.y0, l.roi.y1, l.roi.x0, l.roi.x1, a.OH, a.OW);
         a.r_ty0 = l.roi.y0 / TH; a.r_nty = cdiv(l.roi.y1, TH) - a.r_ty0;
         a.r_tx0 = l.roi.x0 / TW; a.r_ntx = cdiv(l.roi.x1, TW) - a.r_tx0;
+    }
+    a.s_ty0 = a.r_ty0; a.s_nty = a.r_nty; a.s_tx0 = a.r_tx0; a.s_ntx = a.r_ntx;
+    if (l.roi.flag && l.roi.sy1 > 0) {
+        TTUP_REQUIRE(l.roi.sy0 >= 0 && l.roi.sx0 >= 0 && l.roi.sy1 > l.roi.sy0 && l.roi.sx1 > l.roi.sx0 && l.roi.sy1 <= a.OH && l.roi.sx1 <= a.OW, TTUP_EINVAL,
+                     "conv x3: class-2 output region [%d,%d)x[%d,%d) outside %dx%d", l.roi.sy0, l.roi.sy1, l.roi.sx0, l.roi.sx1, a.OH, a.OW);
+        a.s_ty0 = l.roi.sy0 / TH; a.s_nty = cdiv(l.roi.sy1, TH) - a.s_ty0;
+        a.s_tx0 = l.roi.sx0 / TW; a.s_ntx = cdiv(l.roi.sx1, TW) - a.s_tx0;
     }
     TTUP_REQUIRE(p.cout % (MT * 16) == 0 && p.mt3 == MT, TTUP_EINVAL, "conv x3: cout %d packed in blocks of %d, launched with %d", p.cout, p.mt3 * 16, MT * 16);
     const int blocks = p.cout / (MT * 16);

@@ -41,6 +41,7 @@ struct CertState {
     float eps = 0.f;                     // bound on |bf16 heatmap - fp32 heatmap| (absolute, calibrated by the caller)
     static constexpr float GUARD = 1.25f;   // a heatmap with an empty guard band stays certified when eps is widened by up to this factor
     int R = 72;                          // receptive-field radius of one heatmap pixel (measured: 71)
+    int small = 0;                       // class-2 crops: candidates that fit the core positions R + 1 .. R + small get a crop pruned to that core's cone (0 = off)
     int K = 256;                         // candidates kept per heatmap (<= CERT_MAX_K, csrc/certify.hip): the flat top of a saturated blob fits
     int maxc = 8;                        // new crops a heatmap may add (ttup.h: max_crops_per_map, 0 = 8)
     int maxf = 8;                        // crops per frame, set by ttup_wasb_set_certify to min(16, maxc * channels): the channels of a frame share them
@@ -123,7 +124,7 @@ struct ttup_wasb {
 namespace ttup {
 int run_ops(ttup_wasb* net, int mb, hipStream_t st);
 // regions of every op's output that the heatmap rows / columns [lo, hi) depend on (fp32 layer-by-layer graphs only)
-int compute_roi(ttup_wasb* net, int lo, int hi);
+int compute_roi(ttup_wasb* net, int lo, int hi, int lo2 = 0, int hi2 = 0);          // [lo2, hi2): the heatmap region of the class-2 samples (conv.h Roi); empty = one class
 // certified argmax (csrc/certify.hip)
 void cert_free(ttup_wasb* net);
 int cert_begin(ttup_wasb* net, int batch, hipStream_t caller);                                   // reset per-call state

@@ -597,42 +597,55 @@ int run_ops(ttup_wasb* net, int mb, hipStream_t st) { return run_graph(net, mb, 
 // every tensor, the union of what its consumers read.  A 3x3 conv reads one pixel around its outputs (times the stride), a fuse sum
 // reads the same pixels of its base and pixel >> shift of every upsampled term.  The recorded regions are SUPERSETS by construction
 // (kernels round them out to whole tiles): every value an op reads inside its own region has been produced.
-int compute_roi(ttup_wasb* net, int lo, int hi) {
+int compute_roi(ttup_wasb* net, int lo, int hi, int lo2, int hi2) {
     TTUP_REQUIRE(net && net->dtype == TTUP_DTYPE_F32 && net->t_out >= 0, TTUP_EINVAL, "compute_roi: an fp32 handle is expected");
     const size_t nt = net->tensors.size();
     struct R { int y0, y1, x0, x1; bool any; };
-    std::vector<R> need(nt, R{0, 0, 0, 0, false});
-    auto add = [&](int t, int y0, int y1, int x0, int x1) {
-        const Tensor& tn = net->tensors[t];
-        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > tn.h ? tn.h : y1; x1 = x1 > tn.w ? tn.w : x1;
-        if (y1 <= y0 || x1 <= x0) return;
-        R& r = need[t];
-        if (!r.any) r = R{y0, y1, x0, x1, true};
-        else { r.y0 = y0 < r.y0 ? y0 : r.y0; r.y1 = y1 > r.y1 ? y1 : r.y1; r.x0 = x0 < r.x0 ? x0 : r.x0; r.x1 = x1 > r.x1 ? x1 : r.x1; }
-    };
-    add(net->t_out, lo, hi, lo, hi);
-    net->op_roi.assign(net->ops.size(), Roi());
-    for (int k = (int)net->ops.size() - 1; k >= 0; --k) {
-        const Op& op = net->ops[k];
-        TTUP_REQUIRE(op.kind == Op::CONV || op.kind == Op::UPSUM, TTUP_EINVAL, "compute_roi: fused op in an fp32 graph");
-        TTUP_REQUIRE(op.conv2 < 0 && op.lin16 < 0 && op.lin32 < 0 && op.pair < 0 && op.res2 < 0 && op.res3 < 0, TTUP_EINVAL, "compute_roi: fused epilogue in an fp32 graph");
-        const R d = need[op.dst];
-        Roi& o = net->op_roi[k];
-        if (!d.any) { o.y0 = 0; o.y1 = 1; o.x0 = 0; o.x1 = 1; continue; }          // nothing in the cone reads this op: one pixel
-        o.y0 = d.y0; o.y1 = d.y1; o.x0 = d.x0; o.x1 = d.x1;
-        if (op.kind == Op::CONV) {
-            const PackedConv& p = net->convs[op.conv];
-            const int s_ = p.stride, pad = p.k / 2;
-            add(op.src0, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
-            if (op.src1 >= 0) add(op.src1, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
-            if (op.residual >= 0) add(op.residual, d.y0, d.y1, d.x0, d.x1);
-        } else {
-            add(op.src0, d.y0, d.y1, d.x0, d.x1);
-            for (int j = 0; j < op.n_terms; ++j) { const int sh = op.shifts[j]; add(op.terms[j], d.y0 >> sh, ((d.y1 - 1) >> sh) + 1, d.x0 >> sh, ((d.x1 - 1) >> sh) + 1); }
+    // one backward walk from the heatmap region [l, h) x [l, h): out[k] = the region of op k's output in the cone (any == false: none)
+    auto walk = [&](int l, int h, std::vector<R>& out) -> int {
+        std::vector<R> need(nt, R{0, 0, 0, 0, false});
+        auto add = [&](int t, int y0, int y1, int x0, int x1) {
+            const Tensor& tn = net->tensors[t];
+            y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > tn.h ? tn.h : y1; x1 = x1 > tn.w ? tn.w : x1;
+            if (y1 <= y0 || x1 <= x0) return;
+            R& r = need[t];
+            if (!r.any) r = R{y0, y1, x0, x1, true};
+            else { r.y0 = y0 < r.y0 ? y0 : r.y0; r.y1 = y1 > r.y1 ? y1 : r.y1; r.x0 = x0 < r.x0 ? x0 : r.x0; r.x1 = x1 > r.x1 ? x1 : r.x1; }
+        };
+        add(net->t_out, l, h, l, h);
+        out.assign(net->ops.size(), R{0, 1, 0, 1, false});          // nothing in the cone reads the op: one pixel
+        for (int k = (int)net->ops.size() - 1; k >= 0; --k) {
+            const Op& op = net->ops[k];
+            TTUP_REQUIRE(op.kind == Op::CONV || op.kind == Op::UPSUM, TTUP_EINVAL, "compute_roi: fused op in an fp32 graph");
+            TTUP_REQUIRE(op.conv2 < 0 && op.lin16 < 0 && op.lin32 < 0 && op.pair < 0 && op.res2 < 0 && op.res3 < 0, TTUP_EINVAL, "compute_roi: fused epilogue in an fp32 graph");
+            const R d = need[op.dst];
+            if (!d.any) continue;
+            out[k] = d;
+            if (op.kind == Op::CONV) {
+                const PackedConv& p = net->convs[op.conv];
+                const int s_ = p.stride, pad = p.k / 2;
+                add(op.src0, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
+                if (op.src1 >= 0) add(op.src1, d.y0 * s_ - pad, (d.y1 - 1) * s_ + pad + 1, d.x0 * s_ - pad, (d.x1 - 1) * s_ + pad + 1);
+                if (op.residual >= 0) add(op.residual, d.y0, d.y1, d.x0, d.x1);
+            } else {
+                add(op.src0, d.y0, d.y1, d.x0, d.x1);
+                for (int j = 0; j < op.n_terms; ++j) { const int sh = op.shifts[j]; add(op.terms[j], d.y0 >> sh, ((d.y1 - 1) >> sh) + 1, d.x0 >> sh, ((d.x1 - 1) >> sh) + 1); }
+            }
         }
+        return TTUP_OK;
+    };
+    std::vector<R> r1, r2;
+    if (int rc = walk(lo, hi, r1)) return rc;
+    const bool two = hi2 > lo2;
+    if (two) { if (int rc = walk(lo2, hi2, r2)) return rc; }
+    net->op_roi.assign(net->ops.size(), Roi());
+    for (size_t k = 0; k < net->ops.size(); ++k) {
+        Roi& o = net->op_roi[k];
+        o.y0 = r1[k].y0; o.y1 = r1[k].y1; o.x0 = r1[k].x0; o.x1 = r1[k].x1;
+        if (two) { o.sy0 = r2[k].y0; o.sy1 = r2[k].y1; o.sx0 = r2[k].x0; o.sx1 = r2[k].x1; }
     }
     if (getenv("TTUP_DEBUG_ROI")) {
-        double full = 0, kept = 0;
+        double full = 0, kept = 0, kept2 = 0;
         for (size_t k = 0; k < net->ops.size(); ++k) {
             const Op& op = net->ops[k];
             const Tensor& d = net->tensors[op.dst];
@@ -640,12 +653,15 @@ int compute_roi(ttup_wasb* net, int lo, int hi) {
             double w = (double)d.h * d.w;
             if (op.kind == Op::CONV) { const PackedConv& p = net->convs[op.conv]; w *= (double)p.cout * p.cin_total * p.k * p.k; } else w *= d.c;
             full += w; kept += w * ((double)(o.y1 - o.y0) * (o.x1 - o.x0)) / ((double)d.h * d.w);
-            fprintf(stderr, "roi op %2zu %s dst %3dx%3dx%3d -> [%d,%d)x[%d,%d)\n", k, op.kind == Op::CONV ? "conv " : "upsum", d.h, d.w, d.c, o.y0, o.y1, o.x0, o.x1);
+            kept2 += w * ((double)(o.sy1 - o.sy0) * (o.sx1 - o.sx0)) / ((double)d.h * d.w);
+            fprintf(stderr, "roi op %2zu %s dst %3dx%3dx%3d -> [%d,%d)x[%d,%d)  class 2 [%d,%d)x[%d,%d)\n", k, op.kind == Op::CONV ? "conv " : "upsum", d.h, d.w, d.c, o.y0, o.y1, o.x0, o.x1,
+                    o.sy0, o.sy1, o.sx0, o.sx1);
         }
-        fprintf(stderr, "roi: %.1f %% of the graph's multiply-adds kept\n", 100.0 * kept / full);
+        fprintf(stderr, "roi: %.1f %% of the graph's multiply-adds kept (class 2: %.1f %%)\n", 100.0 * kept / full, 100.0 * kept2 / full);
     }
     net->out_roi = Roi();
     net->out_roi.y0 = lo; net->out_roi.y1 = hi; net->out_roi.x0 = lo; net->out_roi.x1 = hi;
+    if (two) { net->out_roi.sy0 = lo2; net->out_roi.sy1 = hi2; net->out_roi.sx0 = lo2; net->out_roi.sx1 = hi2; }
     return TTUP_OK;
 }
 }
@@ -726,9 +742,9 @@ int ttup_wasb_create_internal(const void* blob, size_t blob_bytes, int height, i
     if (dtype == TTUP_DTYPE_F32 && getenv("TTUP_DEBUG_FORCE_ROI") && net->H == net->W && net->H >= 2 * 72 + 24) {
         int* flags = nullptr;
         TTUP_HIP_CHECK(hipMalloc((void**)&flags, (size_t)max_batch * sizeof(int)));
-        std::vector<int> ones((size_t)max_batch, 1);
+        std::vector<int> ones((size_t)max_batch, atoi(getenv("TTUP_DEBUG_FORCE_ROI")) == 2 ? 2 : 1);          // = 2: the class-2 regions (16-pixel core)
         TTUP_HIP_CHECK(hipMemcpy(flags, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (int rc = compute_roi(net.get(), 72, net->H - 72)) return rc;
+        if (int rc = compute_roi(net.get(), 72, net->H - 72, 72, 88)) return rc;
         net->roi_flag = flags;
     }
     TTUP_HIP_CHECK(hipDeviceSynchronize());

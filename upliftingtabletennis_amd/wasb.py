@@ -285,7 +285,7 @@ class WASBNet:
             _lib.check(self._lib.ttup_wasb_certify_stats(self._handle, out.ctypes.data_as(ctypes.c_void_p), 1 if reset else 0))
         return dict(heatmaps=int(out[0]), single=int(out[1]), resolved=int(out[2]), not_certified=int(out[3]), crops=int(out[4]), candidates=int(out[5]),
                     max_candidate_err=float(out[6:7].astype(np.uint32).view(np.float32)[0]), exact_singles=int(out[7]),
-                    over_candidates=int(out[8]), over_crops_per_map=int(out[9]), over_crop_list=int(out[10]))
+                    over_candidates=int(out[8]), over_crops_per_map=int(out[9]), over_crop_list=int(out[10]), small_crops=int(out[11]))
 
     def fix_uncertified(self, idx, win, frames_u8=None, x=None, status=None):
         """Heatmaps the certified argmax flagged 2 (candidate / crop budget exceeded) are re-run on the full-frame fp32 path, so that
