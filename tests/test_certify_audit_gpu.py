@@ -257,6 +257,33 @@ def test_audit_crops_give_single_candidate_heatmaps_an_fp32_check():
     assert (net.certify_status(12).cpu().numpy() & 3 == 0).all() and torch.equal(idx0, idx2)
 
 
+def test_class2_crops_reproduce_the_fp32_path_at_every_alignment():
+    """Crops of class 2 (round 6: the candidates of a crop fit a 14-position core, the crop is centred on THAT core and its fp32 pass
+    pruned to the core's cone -- the crop's first 160 rows / columns): in parity mode every heatmap of a planted-peak clip gets one, at
+    whatever (y mod 8, x mod 8) the ball sits; index and fp32 3x3 window must be the full-frame fp32 path's, bit for bit, and the
+    counters must show that the class was used."""
+    res = (640, 352)
+    sd = weights.random_wasb_state_dict(23, planted=True)
+    net = wasb.WASBNet(sd, resolution=res, max_batch=12, dtype='bf16')
+    phases, n_small, n_crops = set(), 0, 0
+    for k in range(4):
+        fr = torch.from_numpy(synth.synth_frames(14, 720, 1280, seed=60 + k)[0]).cuda()
+        if k == 0:
+            net.calibrate(fr, n=4, exact_windows=True)
+            net.certify_stats(reset=True)
+        _, idx, win = net.forward_frames(fr)
+        st = net.certify_status(12).cpu().numpy() & 3
+        ref_idx, ref_win, _ = _fp32_peaks(sd, fr, res)
+        assert (st == 1).all(), st
+        assert torch.equal(idx, ref_idx) and torch.equal(win, ref_win), (k, (idx != ref_idx).nonzero().flatten().tolist())
+        for v in idx.cpu().tolist():
+            phases.add(((v // res[0]) % 8, (v % res[0]) % 8))
+        s1 = net.certify_stats(reset=True)
+        n_small += s1['small_crops']; n_crops += s1['crops']
+    print('\n%d crops, %d of class 2, %d (y, x) alignments mod 8' % (n_crops, n_small, len(phases)))
+    assert n_crops == 48 and n_small >= 40 and len(phases) >= 16, (n_crops, n_small, len(phases))          # (a single candidate always fits class 2)
+
+
 def test_pipelined_repair_uses_the_tickets_own_status():
     """collect() of clip k runs after submit() of clip k+1 has flipped the handle's per-call slot: the heatmaps of clip k that the
     crop budget could not settle (status 2) must be repaired from clip k's OWN status.  A tiny budget and a wide eps on noise
