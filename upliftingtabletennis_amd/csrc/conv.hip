@@ -560,7 +560,11 @@ __device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_
         if (s + 1 < 18) {
             const int s1 = s + 1, dy1 = s1 % 3, g1 = s1 / 3, c1 = g1 / 3, dx1 = g1 % 3;
             if (dy1 == 0) load_b(brow[g1 & 1], c1, dx1);
+#ifdef TTUP_ABL_NOAFRAG          // timing experiment (wrong results): the weight fragments of step 0 serve every step -- what the LDS reads of the A operand cost
+            af[s1 & 1][0] = af[s & 1][0]; af[s1 & 1][1] = af[s & 1][1]; af[s1 & 1][2] = af[s & 1][2]; af[s1 & 1][3] = af[s & 1][3];
+#else
             load_a(af[s1 & 1], c1 * 9 + dy1 * 3 + dx1);
+#endif
         }
         hook(s);
 #ifndef TTUP_NO_FRAG_PIPELINE
