@@ -49,8 +49,8 @@ GFLOP_PER_FRAME_EXECUTED = 331.3   # 344.07 minus the elided stage-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)          # (the driver's own flags: --steps 20 --warmup 5)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-certify', action='store_true', help='plain bf16 argmax (no fp32 re-evaluation of near-ties)')
@@ -444,6 +444,25 @@ def from_host_leg(pipe, steps):
                       'with the previous step (three device buffers); the first upload of the run is inside the timed region' % host.shape[0]}
 
 
+def _settle(worker, run_step, least=2, most=16):
+    """Warm-up of a regime leg: steps until the worker's strip audit has dropped to its steady rate (one triple per `audit_every`
+    after `audit_settle_clips` clips without a widening; before that one per `audit_every_fast`) -- the rate a long-running stream sees --
+    at least `least`, at most `most`.  Returns the number of steps run."""
+    n = 0
+    while n < least or (n < most and worker.audit_rate() not in (0, worker.audit_every)):
+        run_step()
+        n += 1
+    return n
+
+
+def _audit_note(worker, au0, k, warm):
+    """Audit activity of a leg's timed region (differences against `au0`, the counters at its start)."""
+    au = worker.audit
+    return {'warmup_steps': warm, 'audit_every_in_timed_region': au['audit_every_now'],
+            'strip_audits_per_step': round((au['audited_frames'] - au0['audited_frames']) / max(1, k), 2),
+            'audit_crops_per_step': round((au['audit_crop_frames'] - au0['audit_crop_frames']) / max(1, k), 2)}
+
+
 def extras(device):
     """Driver-timed legs for the other BASELINE configs (N=1 only): CNN only (config 2), uplift only (config 3),
     trajectory generator (config 5), and the RK4 + Gauss-Newton fit named by north_star (extension)."""
@@ -467,9 +486,9 @@ def extras(device):
     # certification load, and with it the throughput, depend on the weight set; the headline is the planted-peak regime
     try:
         pn = Pipeline(device, seed=0, certify=True, planted=False)
-        for _ in range(2):
-            pn.step()
+        warm = _settle(pn.worker, pn.step)
         torch.cuda.synchronize()
+        au0 = pn.worker.audit
         # counters of the timed region only: the first warm-up clip runs on the default crop budget (one crop per heatmap) before
         # the worker has seen what this content asks for, and sends what does not fit to the full-frame fp32 path
         cs_warm, reruns_warm = pn.net.certify_stats(reset=True), pn.worker.fp32_reruns
@@ -491,9 +510,9 @@ def extras(device):
                                     'single_candidate_share': round(cs['single'] / max(1, cs['heatmaps']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
                                     'fp32_full_frame_reruns': pn.worker.fp32_reruns - reruns_warm, 'max_err_over_eps': round(au['max_err_over_eps'], 4),
                                     'not_certified_causes': {'candidate_list': cs['over_candidates'], 'crops_per_heatmap': cs['over_crops_per_map'], 'crop_list': cs['over_crop_list']},
-                                    'counters': 'timed region only (%d heatmaps)' % cs['heatmaps'],
+                                    'counters': 'timed region only (%d heatmaps)' % cs['heatmaps'], 'audit': _audit_note(pn.worker, au0, k, warm),
                                     'warmup': {'heatmaps': cs_warm['heatmaps'], 'not_certified': cs_warm['not_certified'], 'fp32_full_frame_reruns': reruns_warm,
-                                               'note': 'two warm-up steps; the first one runs on the default crop budget of one crop per heatmap'}}
+                                               'note': 'the warm-up steps (until the strip audit is at its steady rate); the first one runs on the default crop budget of one crop per heatmap'}}
         del pn
         torch.cuda.empty_cache()
     except Exception as e:          # the regime leg must not take the headline line down
@@ -503,10 +522,10 @@ def extras(device):
     # (tests/test_e2e_gpu.py); the production mode keeps the bf16 window of single-candidate heatmaps
     try:
         pe = Pipeline(device, seed=0, certify=True, planted=True, exact_windows=True)
-        for _ in range(2):
-            pe.step()
+        warm = _settle(pe.worker, pe.step)
         torch.cuda.synchronize()
         pe.net.certify_stats(reset=True)
+        au0, reruns0 = pe.worker.audit, pe.worker.fp32_reruns
         k = 4
         t0 = time.perf_counter()
         tk = None
@@ -523,7 +542,7 @@ def extras(device):
                                     'config': 'the headline workload in parity mode (StreamWorker(exact_windows=True) / TTUP_EXACT_WINDOWS=1): an fp32 crop for EVERY heatmap, '
                                               'all 3x3 windows in fp32',
                                     'crops_per_heatmap': round(cs['crops'] / max(1, cs['heatmaps']), 3), 'small_core_crop_share': round(cs['small_crops'] / max(1, cs['crops']), 3), 'not_certified_share': round(cs['not_certified'] / max(1, cs['heatmaps']), 4),
-                                    'fp32_full_frame_reruns': pe.worker.fp32_reruns}
+                                    'fp32_full_frame_reruns': pe.worker.fp32_reruns - reruns0, 'audit': _audit_note(pe.worker, au0, k, warm)}
         del pe
         torch.cuda.empty_cache()
     except Exception as e:
@@ -635,8 +654,12 @@ def extras(device):
             base = np.clip(np.rint(base.astype(np.float32) * gain), 0, 255).astype(np.uint8)
             reps = (TRIPLES + 2 + len(base) - 1) // len(base)
             clips.append(torch.from_numpy(np.concatenate([base] * reps)[:TRIPLES + 2]).to(device))
-        for cl in clips:                     # warm-up: every clip once (the audits settle eps for this content)
-            pv.worker.collect(pv.worker.submit(cl), pv.table_px, pv.fps)
+        turn = [0]
+
+        def one():                           # warm-up: the clips in turn until the audits have settled eps and their rate for this content
+            pv.worker.collect(pv.worker.submit(clips[turn[0] % len(clips)]), pv.table_px, pv.fps)
+            turn[0] += 1
+        warm = _settle(pv.worker, one, least=len(clips), most=24)
         pv.net.certify_stats(reset=True)
         au0 = pv.worker.audit                # counters at the start of the timed region: the line reports the timed region's own
         pv.worker.margin_log = []            # fp32 top-2 margins of the timed region's heatmaps (ambiguous_share)
@@ -662,7 +685,7 @@ def extras(device):
                                      'eps_widened': au['widened'] - au0['widened'], 'recertified_clips': au['recertified_clips'] - au0['recertified_clips'],
                                      'recertified_heatmaps': au['recertified_heatmaps'] - au0['recertified_heatmaps'],
                                      'counters': 'timed region only (eps_widened / recertified_* are differences against the end of the warm-up)',
-                                     'eps_widened_in_warmup': au0['widened']}
+                                     'eps_widened_in_warmup': au0['widened'], 'audit': _audit_note(pv.worker, au0, k, warm)}
         if mg.size:
             # "reference-ambiguous" heatmaps: the fp32 winner leads the best other candidate by less than DELTA_REF, the measured bound
             # on |HIP fp32 heatmap - reference heatmap| x 2 (tests/test_fullsize_configs.py::test_certified_argmax_matches_the_reference_on_near_ties)
