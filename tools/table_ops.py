@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Per-op timings of the table detector's graph (3 input channels, 13 heads: the head is a separate kernel) beside the ball detector's on
+the same box: replay time per micro-batch of 8, the six longest ops, the first and last ops.  (`forward(x)` entry: the stem reads fp32 NCHW.)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ.setdefault('TTUP_SYNTHETIC_WEIGHTS', '1')
