@@ -554,6 +554,16 @@ __device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_
     };
     load_b(brow[0], 0, 0);
     load_a(af[0], 0);
+#ifdef TTUP_ABL_MFMA32          // timing experiment (wrong results): the k-step's eight 16x16x32 MFMAs as four 32x32x16 ones on the same operand registers, two accumulator chains
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    f32x16 c32[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c32[t][m * 4 + r] = acc[m][t][r];
+#endif
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
         const int dy = s % 3, gi = s / 3;                       // gi = (plane, tap column) group: c = gi / 3, dx = gi % 3
@@ -570,14 +580,27 @@ __device__ __forceinline__ void conv64_tile_mfma(f32x4 (&acc)[4][2], const bf16_
 #ifndef TTUP_NO_FRAG_PIPELINE
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef TTUP_ABL_MFMA32
+#pragma unroll
+        for (int m = 0; m < 4; ++m) c32[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][m], brow[gi & 1][dy + (m & 1)], c32[m & 1], 0, 0, 0);
+#else
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][m], brow[gi & 1][dy + t], acc[m][t], 0, 0, 0);
+#endif
 #ifndef TTUP_NO_FRAG_PIPELINE
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+#ifdef TTUP_ABL_MFMA32
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][t][r] = c32[t][m * 4 + r];
+#endif
 }
 
 // ------------------------------------------------------------------ 3x3 64 -> 64 with resident weights
