@@ -881,7 +881,7 @@ def test_bench_two_rank_flow_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TTUP_BENCH_SHARE_GPU='1', TTUP_DIST_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29533',
-           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--no-roofline', '--no-cpu-baseline']
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-roofline', '--no-cpu-baseline']
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -1073,7 +1073,7 @@ def test_bench_two_rank_flow_over_rccl():
     env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
 
     def run(gpus):
-        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup', '1', '--no-roofline',
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '6', '--warmup', '3', '--no-roofline',
                               '--no-cpu-baseline', '--no-extras'], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
