@@ -15,7 +15,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, %r)
 from upliftingtabletennis_amd import wasb, weights
 out = {}
-for k, (h, w, b, seed, table) in enumerate(((104, 168, 3, 43, 0), (288, 512, 5, 44, 0), (704, 1280, 2, 45, 0), (288, 512, 2, 46, 1))):
+for k, (h, w, b, seed, table) in enumerate(((104, 168, 3, 43, 0), (288, 512, 5, 44, 0), (704, 1280, 2, 45, 0), (288, 512, 2, 46, 1), (96, 160, 3, 47, 0), (64, 32, 2, 48, 0))):
     if table:
         sd = weights.random_wasb_state_dict(seed, in_ch=3, head_out=13)
         net = wasb.MyHRNet(sd, resolution=(w, h), max_batch=b, dtype='bf16')
@@ -37,8 +37,11 @@ np.savez(sys.argv[1], **out)
 def main():
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (('new', {}), ('old', {'TTUP_BB2_GENERIC': '1'})):
-            e = dict(os.environ); e.pop('TTUP_BB2_GENERIC', None); e.update(env)
+        # `python tools/chain16_ab.py stream`: the streaming form (csrc/experiments/chain16s.h.inc -- not compiled; when it is wired in
+        # again, TTUP_C16_STREAM=1 selects it) against the tile form instead
+        pair = (('new', {'TTUP_C16_STREAM': '1'}), ('old', {})) if sys.argv[1:] == ['stream'] else (('new', {}), ('old', {'TTUP_BB2_GENERIC': '1'}))
+        for tag, env in pair:
+            e = dict(os.environ); e.pop('TTUP_BB2_GENERIC', None); e.pop('TTUP_C16_STREAM', None); e.update(env)
             f = os.path.join(d, tag + '.npz')
             r = subprocess.run([sys.executable, '-c', CHILD, f], env=e, capture_output=True, text=True, timeout=1800)
             if r.returncode != 0:

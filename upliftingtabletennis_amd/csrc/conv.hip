@@ -2510,7 +2510,7 @@ int launch_bb_chain(const PackedConv* const* convs, int n_convs, const void* x, 
         // the epilogue forms the network uses are compiled out in c16_chain_kernel (csrc/chain16.h); anything else -- other term layouts,
         // TTUP_BB2_GENERIC=1 (read once per process), other -DTTUP_BB2_TH/TW tiles -- takes the run-time form (bb_chain2_kernel)
         static const bool generic = getenv("TTUP_BB2_GENERIC") != nullptr;
-#ifdef TTUP_ABL_EPI4
+#ifdef TTUP_ABL_EPI4          // timing build (wrong results): the plain chain for every launch
         return launch_c16_t<24, 32, 4>(a, batch, h, w, st);
 #endif
         if constexpr (BB2_TH == 24 && BB2_TW == 32) {
