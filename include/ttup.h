@@ -135,7 +135,7 @@ int ttup_peak_hbm(size_t bytes, double* out_host, void* stream);
  * balldetection/helper_balldetection.py:50 takes torch.argmax of the fp32 heatmap).  eps_abs bounds |bf16 heatmap - fp32 heatmap|
  * (calibrated by the caller on its own frames; upliftingtabletennis_amd.wasb.WASBNet.calibrate).  Once set, every forward that
  * returns peaks re-evaluates the pixels within 2*eps_abs of the bf16 maximum on fp32 receptive-field crops (crop x crop pixels,
- * 0 = 168, the smallest that holds the 72-pixel receptive-field radius on both sides; at most max_crops_per_map per heatmap, 0 = 8) inside the same call, without host synchronisation, and returns the
+ * 0 = 168 = the 72-pixel receptive-field radius on both sides of a 24-pixel core; a multiple of 8, at least 160 (ABI 103); at most max_crops_per_map per heatmap, 0 = 8) inside the same call, without host synchronisation, and returns the
  * fp32 winner and its fp32 3x3 window.  eps_abs < 0 switches it off.  csrc/certify.hip.
  * status (after a forward, per heatmap; ttup_wasb_certify_status): 0 = one candidate (the bf16 index is certain), 1 = resolved on
  * fp32 crops, 2 = not certified (candidate / crop budget exceeded; the bf16 index is returned).
